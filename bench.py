@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EmbeddingForward on the reference's manual_benchmark shape.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], reference README.md:104): fp16 sum, 10,000,000 x 256 table,
+batch 65,536 per GPU, fixed hotness 64, power-law alpha = 1.15, int32 indices, fp32 accumulation.
+One step = one EmbeddingForward over one batch.  Steps cycle through several DISTINCT index
+batches (consecutive batches of one generator stream), so cache warmth between steps comes only
+from the hot rows that real consecutive batches share.  With N > 1 (torchrun, one process per
+GPU) the global batch N x 65,536 is sharded by sample, the table is replicated, and the forward
+needs no collective (weak scaling).
+
+Metric = whole-job algorithmic GB/s with the reference's formula
+(benchmarks/manual_benchmark.cu:256-260): sizeof(elem) * B * (H + 1) * W bytes per step and GPU.
+
+Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+
+WORKLOADS = {
+    # name: (rows, width, batch, hotness, alpha, elem, csr, weighted)
+    "c2": dict(rows=10_000_000, width=256, batch=65536, hotness=64, alpha=1.15, elem="f16",
+               csr=False, weighted=False,
+               desc="fp16 sum, 10Mx256 table, batch 65536, hotness 64, alpha 1.15 (manual_benchmark shape)"),
+    "c3": dict(rows=10_000_000, width=128, batch=65536, hotness=128, alpha=1.15, elem="f32",
+               csr=True, weighted=True,
+               desc="fp32 weighted-sum CSR (hotness U[0,128], mean 64), 10Mx128 table, batch 65536"),
+    "c1": dict(rows=1024, width=32, batch=1024, hotness=8, alpha=1.15, elem="f32",
+               csr=False, weighted=False, desc="fp32 sum, 1kx32 table, batch 1024, hotness 8"),
+}
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    p.add_argument("--alpha", type=float, default=None, help="override the workload's alpha")
+    p.add_argument("--index-batches", type=int, default=4, help="distinct index batches cycled through")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the cold-cache and alpha=0 companions")
+    p.add_argument("--cold-iters", type=int, default=20)
+    return p.parse_args()
+
+
+def fill_table(torch, rows, width, dtype, device, seed):
+    """Uniform(-1,1) table filled on the device in chunks (values do not affect timing; the
+    host RNG of the reference would need 2.56 G sequential draws)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    table = torch.empty((rows, width), dtype=dtype, device=device)
+    chunk = 1 << 20
+    for lo in range(0, rows, chunk):
+        hi = min(rows, lo + chunk)
+        table[lo:hi] = (torch.rand((hi - lo, width), device=device, generator=g) * 2 - 1).to(dtype)
+    return table
+
+
+def make_batches(harness, np, cfg, alpha, n_batches, rank, world, index_dtype):
+    """Per step t the global batch is world x B consecutive samples of ONE generator stream;
+    this rank owns shard `rank`.  Returns a list of dict(indices, offsets, weights) (numpy)."""
+    B, H = cfg["batch"], cfg["hotness"]
+    out = []
+    if not cfg["csr"]:
+        total = n_batches * world * B
+        idx = harness.generate_indices(cfg["rows"], total, H, alpha=alpha, index=index_dtype)
+        idx = idx.reshape(n_batches, world, B * H)
+        for t in range(n_batches):
+            out.append(dict(indices=np.ascontiguousarray(idx[t, rank]), offsets=None, weights=None))
+        return out
+    # CSR: the reference recipe (offsets + weights from engine 123456); one recipe call per
+    # (step, rank) with a distinct batch prefix is not expressible, so take one long batch.
+    a = harness.allocate_forward(cfg["rows"], cfg["width"], n_batches * world * B, H, alpha=alpha,
+                                 is_csr=True, elem=np.float32 if cfg["elem"] == "f32" else np.float16,
+                                 index=index_dtype, with_table=False)
+    off = a["offsets"].astype(np.int64)
+    for t in range(n_batches):
+        s0 = (t * world + rank) * B
+        lo, hi = off[s0], off[s0 + B]
+        out.append(dict(indices=np.ascontiguousarray(a["indices"][lo:hi]),
+                        offsets=(off[s0:s0 + B + 1] - lo).astype(np.int32),
+                        weights=np.ascontiguousarray(a["weights"][lo:hi]) if cfg["weighted"] else None))
+    return out
+
+
+def algorithmic_bytes(cfg, batch):
+    """Reference formulas, benchmarks/manual_benchmark.cu:250-261."""
+    es = 2 if cfg["elem"] == "f16" else 4
+    if cfg["csr"]:
+        nnz = int(batch["offsets"][-1])
+        return es * (nnz - 1 + cfg["batch"]) * cfg["width"]
+    return es * cfg["batch"] * (cfg["hotness"] + 1) * cfg["width"]
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import cuembed_amd as ce
+    from cuembed_amd import harness
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cfg = dict(WORKLOADS[args.workload])
+    alpha = cfg["alpha"] if args.alpha is None else args.alpha
+    tdtype = torch.float16 if cfg["elem"] == "f16" else torch.float32
+    B, H, W = cfg["batch"], cfg["hotness"], cfg["width"]
+
+    ce._lib.lib()  # fail loudly if the HIP library is absent
+    table = fill_table(torch, cfg["rows"], W, tdtype, device, seed=1234 + rank)
+    nb = max(1, args.index_batches)
+    host_batches = make_batches(harness, np, cfg, alpha, nb, rank, world, np.int32)
+    dev_batches = []
+    for hb in host_batches:
+        dev_batches.append({k: (None if v is None else torch.from_numpy(v).to(device))
+                            for k, v in hb.items()})
+    out = torch.empty((B, W), dtype=tdtype, device=device)
+    bytes_per_step = [algorithmic_bytes(cfg, hb) for hb in host_batches]
+
+    def step(t):
+        b = dev_batches[t % nb]
+        ce.embedding_forward(table, b["indices"], b["offsets"], b["weights"], batch_size=B,
+                             num_hots=0 if cfg["csr"] else H, mode="sum", out=out)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        step(t)
+    # ---- timed region: exactly K steps between barrier+sync ---------------------------
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        starts[t].record()
+        step(t)
+        stops[t].record()
+    barrier()
+    wall = time.perf_counter() - t0
+    assert ce._lib.lib().cuembed_peek_last_error() == 0
+    kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
+    step_bytes = sum(bytes_per_step[t % nb] for t in range(args.steps))
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=device)
+    bytes_t = torch.tensor([float(step_bytes)], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(bytes_t, op=dist.ReduceOp.SUM)
+    wall_max = float(wall_t.item())
+    total_bytes = float(bytes_t.item())
+
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = (step_bytes / args.steps) / (avg_kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "achieved HBM GB/s (% of peak), EmbeddingForward w=256 hot=64 at 1/2/4/8 MI355X",
+        "value": round(total_bytes / wall_max / 1e9, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall_max / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16 table, f32 accumulate" if cfg["elem"] == "f16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": cfg["desc"], "name": args.workload, "alpha": alpha,
+                   "global_batch": world * B, "per_gpu_batch": B, "index_dtype": "int32",
+                   "index_batches_cycled": nb, "parallelism": "batch-shard x%d, table replicated" % world,
+                   "algorithmic_bytes_per_step_per_gpu": bytes_per_step[0]},
+        "pct_of_hbm_peak": round(100.0 * total_bytes / wall_max / 1e9 / (HBM_PEAK_GBPS * world), 2),
+        "roofline": {"bound": "hbm", "kernel": "GatherReduceKernel", "achieved": round(achieved, 2),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "avg_kernel_ms": round(avg_kernel_ms, 5),
+                     "min_kernel_ms": round(min(kernel_ms), 5)},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(traffic_file) and args.alpha is None:
+        with open(traffic_file) as f:
+            tr = json.load(f)
+        result["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+        result["roofline"]["traffic_source"] = tr.get("source")
+
+    if rank == 0 and not args.no_extras:
+        result["extras"] = extras(args, torch, ce, harness, np, cfg, table, out, device, dev_batches,
+                                  bytes_per_step)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(torch, np, cfg, table, host_batches[0], out, step)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def extras(args, torch, ce, harness, np, cfg, table, out, device, dev_batches, bytes_per_step):
+    """Companion measurements on rank 0 (not part of `value`):
+    cold  = the reference's default protocol (manual_benchmark.cu:199-248): every iteration is
+            timed alone with HIP events after a 1.02 GB cache-flushing reduction;
+    alpha0 = the same workload with uniform indices (the genuinely HBM-bound case)."""
+    B, H = cfg["batch"], cfg["hotness"]
+    ex = {}
+    flush = torch.ones(256_000_000, dtype=torch.int32, device=device)
+    sink = torch.zeros((), dtype=torch.int32, device=device)
+
+    def timed_cold(batches, nbytes):
+        ms = []
+        for it in range(args.cold_iters):
+            sink.add_(flush.max())
+            b = batches[it % len(batches)]
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ce.embedding_forward(table, b["indices"], b["offsets"], b["weights"], batch_size=B,
+                                 num_hots=0 if cfg["csr"] else H, mode="sum", out=out)
+            z.record()
+            z.synchronize()
+            ms.append(a.elapsed_time(z))
+        avg = sum(ms) / len(ms)
+        return {"ms": round(avg, 5), "GBps": round(nbytes / (avg * 1e-3) / 1e9, 2),
+                "pct_of_hbm_peak": round(100 * nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2),
+                "iters": len(ms)}
+
+    ex["cold_cache_flush_between_iters"] = timed_cold(dev_batches, bytes_per_step[0])
+    if not cfg["csr"]:
+        idx0 = harness.generate_indices(cfg["rows"], 2 * B, H, alpha=0.0, index=np.int32).reshape(2, -1)
+        b0 = [dict(indices=torch.from_numpy(np.ascontiguousarray(idx0[i])).to(device), offsets=None,
+                   weights=None) for i in range(2)]
+        n = 50
+        for t in range(5):
+            ce.embedding_forward(table, b0[t % 2]["indices"], num_hots=H, out=out)
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for t in range(n):
+            ce.embedding_forward(table, b0[t % 2]["indices"], num_hots=H, out=out)
+        z.record()
+        z.synchronize()
+        ms = a.elapsed_time(z) / n
+        ex["alpha0_uniform_back_to_back"] = {
+            "ms": round(ms, 5), "GBps": round(bytes_per_step[0] / (ms * 1e-3) / 1e9, 2),
+            "pct_of_hbm_peak": round(100 * bytes_per_step[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2)}
+        ex["alpha0_uniform_cold"] = timed_cold(b0, bytes_per_step[0])
+    del flush
+    return ex
+
+
+def cpu_baseline(torch, np, cfg, table, host_batch, out, step):
+    """The CPU oracle (a port of the reference's EmbeddingForwardCpu loop order) timed on this
+    box's host cores on a bounded sample of the same workload, and used to check the GPU result."""
+    from oracle import oracle as O
+    O.build(ref=False)
+    B, H, W = cfg["batch"], cfg["hotness"], cfg["width"]
+    es = 2 if cfg["elem"] == "f16" else 4
+    host_table = table.cpu().numpy()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, O.max_threads()))
+    if cfg["csr"]:
+        S1, SN = 4096, min(B, 32768)
+    else:
+        S1, SN = min(B, 8192), B
+
+    def run(nsamples, nthreads):
+        if cfg["csr"]:
+            off = host_batch["offsets"][:nsamples + 1]
+            idx = host_batch["indices"][:off[-1]]
+            w = None if host_batch["weights"] is None else host_batch["weights"][:off[-1]]
+            t = time.perf_counter()
+            r = O.embedding_forward(host_table, idx, off, w, batch_size=nsamples, num_hots=0, threads=nthreads)
+            dt = time.perf_counter() - t
+            nbytes = es * (int(off[-1]) - 1 + nsamples) * W
+        else:
+            idx = host_batch["indices"][:nsamples * H]
+            t = time.perf_counter()
+            r = O.embedding_forward(host_table, idx, num_hots=H, threads=nthreads)
+            dt = time.perf_counter() - t
+            nbytes = es * nsamples * (H + 1) * W
+        return r, dt, nbytes
+
+    r1, dt1, nb1 = run(S1, 1)
+    rn, dtn, nbn = run(SN, threads)
+    # parity of the GPU result on the same samples (bit-exact)
+    step(0)
+    torch.cuda.synchronize()
+    gpu = out[:SN].cpu().numpy()
+    view = np.uint16 if es == 2 else np.uint32
+    parity = bool((gpu.view(view) == rn.view(view)).all())
+    return {"value": round(nbn / dtn / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": "oracle/cuembed_oracle.cpp forward, first %d samples of batch 0 on %d threads "
+                      "(%.2f s); single thread on %d samples: %.4f GB/s (%.2f s)"
+                      % (SN, threads, dtn, S1, nb1 / dt1 / 1e9, dt1),
+            "single_thread_value": round(nb1 / dt1 / 1e9, 4), "host_cores": cores,
+            "gpu_matches_oracle_bit_exact": parity}
+
+
+if __name__ == "__main__":
+    main()

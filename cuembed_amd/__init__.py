@@ -1,0 +1,18 @@
+"""cuembed_amd -- MI355X-native (gfx950 / CDNA4) embedding lookup.
+
+The gather-reduce hot path of NVIDIA/cuEmbed (EmbeddingForward, EmbeddingBackward,
+Transpose and the index helpers) as hand-written HIP kernels behind
+ * a header-only C++ host API   (cuembed_amd/csrc/cuembed/include/*.hpp),
+ * a C ABI shared library       (include/cuembed_amd.h, cuembed_amd/lib/libcuembed_amd.so),
+ * this Python host layer       (cuembed_amd.ops, cuembed_amd.torch_ops).
+"""
+from . import _lib  # noqa: F401
+from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBackward,  # noqa: F401
+                  EmbeddingForward, ExtractRowIdsForConcat, ExtractRowIdsFromCSR,
+                  ExtractRowIdsFromFixed, Transpose, compressed_grad_workspace_bytes,
+                  compute_compressed_grad_indices, embedding_backward, embedding_forward,
+                  extract_row_ids_for_concat, extract_row_ids_from_csr,
+                  extract_row_ids_from_fixed, forward_launch_shape, transpose,
+                  transpose_workspace_bytes)
+
+__version__ = "0.1.0"

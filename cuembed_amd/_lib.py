@@ -1,0 +1,65 @@
+"""ctypes binding of libcuembed_amd.so (the C ABI declared in include/cuembed_amd.h).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be
+loaded, importing the symbol table raises.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libcuembed_amd.so")
+
+_lib = None
+
+_VP = ctypes.c_void_p
+_I = ctypes.c_int
+
+
+class CuembedLibraryError(RuntimeError):
+    pass
+
+
+def _declare(L):
+    L.cuembed_embedding_forward.restype = None
+    L.cuembed_embedding_forward.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _VP]
+    L.cuembed_embedding_backward.restype = None
+    L.cuembed_embedding_backward.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP]
+    L.cuembed_transpose.restype = None
+    L.cuembed_transpose.argtypes = [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP,
+                                    ctypes.POINTER(ctypes.c_size_t), _VP]
+    L.cuembed_compute_compressed_grad_indices.restype = None
+    L.cuembed_compute_compressed_grad_indices.argtypes = [_VP, _I, _I, _VP, _VP,
+                                                          ctypes.POINTER(ctypes.c_size_t), _VP]
+    L.cuembed_extract_row_ids_from_fixed.restype = None
+    L.cuembed_extract_row_ids_from_fixed.argtypes = [_I, _I, _I, _VP, _VP]
+    L.cuembed_extract_row_ids_from_csr.restype = None
+    L.cuembed_extract_row_ids_from_csr.argtypes = [_VP, _I, _I, _I, _VP, _VP]
+    L.cuembed_extract_row_ids_for_concat.restype = None
+    L.cuembed_extract_row_ids_for_concat.argtypes = [_I, _I, _VP, _VP]
+    L.cuembed_forward_launch_shape.restype = None
+    L.cuembed_forward_launch_shape.argtypes = [_I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]
+    L.cuembed_peek_last_error.restype = _I
+    L.cuembed_peek_last_error.argtypes = []
+    L.cuembed_version.restype = ctypes.c_char_p
+    L.cuembed_version.argtypes = []
+
+
+def lib():
+    """The loaded shared library; raises CuembedLibraryError when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CuembedLibraryError(
+                "cuembed_amd: %s not found. Build it with `python -m cuembed_amd.build` "
+                "(needs hipcc); there is no CPU or PyTorch fallback." % LIB_PATH)
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise CuembedLibraryError("cuembed_amd: cannot load %s: %s" % (LIB_PATH, e))
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def version():
+    return lib().cuembed_version().decode()

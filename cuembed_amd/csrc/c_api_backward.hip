@@ -1,0 +1,64 @@
+// C ABI: backward entry points = explicit instantiations of
+// cuembed::EmbeddingBackward (reference instantiation list:
+// utils/src/embedding_gpu_backward.cu:84-87).
+#include "c_api_common.hpp"
+#include "cuembed/include/embedding_lookup.hpp"
+
+using cuembed_c_api::Stream;
+
+namespace {
+template <typename ElemT, typename IndexT>
+void Backward(const void* grad_y, int embed_width, int num_rows, int nnz, const IndexT* t_idx,
+              const IndexT* t_sid, const IndexT* t_remap, const void* t_w, int skip_init,
+              void* grad, IndexT* inverse_mapping, cuembed_stream_t stream) {
+  cuembed::EmbeddingBackward<ElemT, IndexT>(
+      static_cast<const ElemT*>(grad_y), embed_width, num_rows, nnz, t_idx, t_sid, t_remap,
+      static_cast<const ElemT*>(t_w), skip_init != 0, static_cast<ElemT*>(grad), inverse_mapping,
+      Stream(stream));
+}
+}  // namespace
+
+extern "C" {
+
+#define CUEMBED_DEFINE_BACKWARD(SUFFIX, CELEM, ELEM, INDEX)                                  \
+  void cuembed_embedding_backward_##SUFFIX(                                                  \
+      const CELEM* grad_y, int embed_width, int num_grad_embedding_rows, int nnz,            \
+      const INDEX* transpose_indices, const INDEX* transpose_sample_ids,                     \
+      const INDEX* transpose_remapped_indices, const CELEM* transpose_weights,               \
+      int skip_grad_init, CELEM* grad_embedding, INDEX* inverse_mapping,                     \
+      cuembed_stream_t stream) {                                                             \
+    Backward<ELEM, INDEX>(grad_y, embed_width, num_grad_embedding_rows, nnz,                 \
+                          transpose_indices, transpose_sample_ids,                           \
+                          transpose_remapped_indices, transpose_weights, skip_grad_init,     \
+                          grad_embedding, inverse_mapping, stream);                          \
+  }
+CUEMBED_DEFINE_BACKWARD(f32_i32, float, float, int32_t)
+CUEMBED_DEFINE_BACKWARD(f32_i64, float, float, int64_t)
+CUEMBED_DEFINE_BACKWARD(f16_i32, void, __half, int32_t)
+CUEMBED_DEFINE_BACKWARD(f16_i64, void, __half, int64_t)
+#undef CUEMBED_DEFINE_BACKWARD
+
+void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_width,
+                                int num_grad_embedding_rows, int nnz,
+                                const void* transpose_indices, const void* transpose_sample_ids,
+                                const void* transpose_remapped_indices, int index_type,
+                                const void* transpose_weights, int skip_grad_init,
+                                void* grad_embedding, void* inverse_mapping,
+                                cuembed_stream_t stream) {
+#define BWD(E, I)                                                                             \
+  Backward<E, I>(grad_y, embed_width, num_grad_embedding_rows, nnz,                           \
+                 static_cast<const I*>(transpose_indices),                                    \
+                 static_cast<const I*>(transpose_sample_ids),                                 \
+                 static_cast<const I*>(transpose_remapped_indices), transpose_weights,        \
+                 skip_grad_init, grad_embedding, static_cast<I*>(inverse_mapping), stream)
+  switch ((elem_type << 1) | index_type) {
+    case 0: BWD(float, int32_t); break;
+    case 1: BWD(float, int64_t); break;
+    case 2: BWD(__half, int32_t); break;
+    case 3: BWD(__half, int64_t); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef BWD
+}
+
+}  // extern "C"

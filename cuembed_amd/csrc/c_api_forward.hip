@@ -1,0 +1,108 @@
+// C ABI: forward entry points = explicit instantiations of
+// cuembed::EmbeddingForward (reference instantiation list:
+// utils/src/embedding_gpu_forward.cu:69-76; int64 offsets as used by
+// examples/pytorch/cuembed_embedding.cu:39-49).
+#include "c_api_common.hpp"
+#include "cuembed/include/embedding_lookup.hpp"
+
+using cuembed::CombineMode;
+using cuembed_c_api::Stream;
+
+namespace {
+template <typename ElemT, typename IndexT, typename OffsetT>
+void Forward(const void* params, int embed_width, const IndexT* indices, const OffsetT* offsets,
+             const void* weights, int batch_size, int num_hots, int mode, int fp16_math,
+             void* ret, cuembed_stream_t stream) {
+  CUEMBED_ASSERT(mode == CUEMBED_SUM || mode == CUEMBED_MEAN || mode == CUEMBED_CONCAT);
+  const CombineMode m = mode == CUEMBED_SUM    ? CombineMode::kSum
+                        : mode == CUEMBED_MEAN ? CombineMode::kMean
+                                               : CombineMode::kConcat;
+  const ElemT* p = static_cast<const ElemT*>(params);
+  const ElemT* w = static_cast<const ElemT*>(weights);
+  ElemT* r = static_cast<ElemT*>(ret);
+  if (fp16_math)
+    cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, true>(
+        p, embed_width, indices, offsets, w, batch_size, num_hots, m, r, Stream(stream));
+  else
+    cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, false>(
+        p, embed_width, indices, offsets, w, batch_size, num_hots, m, r, Stream(stream));
+}
+}  // namespace
+
+extern "C" {
+
+#define CUEMBED_DEFINE_FORWARD(SUFFIX, CELEM, ELEM, INDEX, OFFSET)                          \
+  void cuembed_embedding_forward_##SUFFIX(                                                  \
+      const CELEM* params, int embed_width, const INDEX* indices, const OFFSET* offsets,    \
+      const CELEM* weights, int batch_size, int num_hots, int mode, int fp16_math,          \
+      CELEM* ret, cuembed_stream_t stream) {                                                \
+    Forward<ELEM, INDEX, OFFSET>(params, embed_width, indices, offsets, weights, batch_size, \
+                                 num_hots, mode, fp16_math, ret, stream);                   \
+  }
+CUEMBED_DEFINE_FORWARD(f32_i32_o32, float, float, int32_t, int32_t)
+CUEMBED_DEFINE_FORWARD(f32_i32_o64, float, float, int32_t, int64_t)
+CUEMBED_DEFINE_FORWARD(f32_i64_o32, float, float, int64_t, int32_t)
+CUEMBED_DEFINE_FORWARD(f32_i64_o64, float, float, int64_t, int64_t)
+CUEMBED_DEFINE_FORWARD(f16_i32_o32, void, __half, int32_t, int32_t)
+CUEMBED_DEFINE_FORWARD(f16_i32_o64, void, __half, int32_t, int64_t)
+CUEMBED_DEFINE_FORWARD(f16_i64_o32, void, __half, int64_t, int32_t)
+CUEMBED_DEFINE_FORWARD(f16_i64_o64, void, __half, int64_t, int64_t)
+#undef CUEMBED_DEFINE_FORWARD
+
+void cuembed_embedding_forward(const void* params, int elem_type, int embed_width,
+                               const void* indices, int index_type, const void* offsets,
+                               int offset_type, const void* weights, int batch_size,
+                               int num_hots, int mode, int fp16_math, void* ret,
+                               cuembed_stream_t stream) {
+#define FWD(E, I, O)                                                                          \
+  Forward<E, I, O>(params, embed_width, static_cast<const I*>(indices),                       \
+                   static_cast<const O*>(offsets), weights, batch_size, num_hots, mode,       \
+                   fp16_math, ret, stream)
+  const int key = (elem_type << 2) | (index_type << 1) | (offsets ? offset_type : 0);
+  switch (key) {
+    case 0: FWD(float, int32_t, int32_t); break;
+    case 1: FWD(float, int32_t, int64_t); break;
+    case 2: FWD(float, int64_t, int32_t); break;
+    case 3: FWD(float, int64_t, int64_t); break;
+    case 4: FWD(__half, int32_t, int32_t); break;
+    case 5: FWD(__half, int32_t, int64_t); break;
+    case 6: FWD(__half, int64_t, int32_t); break;
+    case 7: FWD(__half, int64_t, int64_t); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef FWD
+}
+
+void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width, int batch_size,
+                                  int num_hots, int is_csr, int is_weighted, int mode,
+                                  int* out) {
+  cuembed::detail::ForwardLaunch f;
+  const bool concat = mode == CUEMBED_CONCAT;
+  if (elem_type == CUEMBED_F32) {
+    f = index_type == CUEMBED_I32
+            ? cuembed::detail::PlanForward<float, int32_t>(embed_width, nullptr, nullptr, batch_size,
+                                                           num_hots, is_csr, is_weighted, concat)
+            : cuembed::detail::PlanForward<float, int64_t>(embed_width, nullptr, nullptr, batch_size,
+                                                           num_hots, is_csr, is_weighted, concat);
+  } else {
+    f = index_type == CUEMBED_I32
+            ? cuembed::detail::PlanForward<_Float16, int32_t>(embed_width, nullptr, nullptr,
+                                                              batch_size, num_hots, is_csr,
+                                                              is_weighted, concat)
+            : cuembed::detail::PlanForward<_Float16, int64_t>(embed_width, nullptr, nullptr,
+                                                              batch_size, num_hots, is_csr,
+                                                              is_weighted, concat);
+  }
+  out[0] = f.split.elems_per_lane;
+  out[1] = f.split.lanes_per_row;
+  out[2] = f.split.rows_per_block;
+  out[3] = static_cast<int>(f.grid);
+  out[4] = static_cast<int>(f.stage_bytes);
+  out[5] = f.staged ? 1 : 0;
+}
+
+int cuembed_peek_last_error(void) { return static_cast<int>(hipPeekAtLastError()); }
+
+const char* cuembed_version(void) { return "cuembed_amd 0.1.0 gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// C ABI: index transformations = explicit instantiations of cuembed::Transpose,
+// ComputeCompressedGradIndices and ExtractRowIds* (reference instantiation list:
+// utils/src/embedding_gpu_transpose.cu:95-98).
+#include "c_api_common.hpp"
+#include "cuembed/include/index_transforms.hpp"
+
+using cuembed_c_api::Stream;
+
+extern "C" {
+
+#define CUEMBED_DEFINE_TRANSPOSE(SUFFIX, INDEX, CWEIGHT, WEIGHT)                              \
+  void cuembed_transpose_##SUFFIX(const INDEX* rows, const INDEX* cols,                       \
+                                  const CWEIGHT* weights, int nnz, INDEX* transpose_rows,     \
+                                  INDEX* transpose_cols, CWEIGHT* transpose_weights,          \
+                                  char* work, size_t* lwork, cuembed_stream_t stream) {       \
+    cuembed::Transpose<INDEX, WEIGHT>(rows, cols, static_cast<const WEIGHT*>(weights), nnz,   \
+                                      transpose_rows, transpose_cols,                         \
+                                      static_cast<WEIGHT*>(transpose_weights), work, lwork,   \
+                                      Stream(stream));                                        \
+  }
+CUEMBED_DEFINE_TRANSPOSE(i32_f32, int32_t, float, float)
+CUEMBED_DEFINE_TRANSPOSE(i64_f32, int64_t, float, float)
+CUEMBED_DEFINE_TRANSPOSE(i32_f16, int32_t, void, __half)
+CUEMBED_DEFINE_TRANSPOSE(i64_f16, int64_t, void, __half)
+#undef CUEMBED_DEFINE_TRANSPOSE
+
+#define CUEMBED_DEFINE_COMPRESS(SUFFIX, INDEX)                                                \
+  void cuembed_compute_compressed_grad_indices_##SUFFIX(                                      \
+      const INDEX* indices, int nnz, INDEX* remapped_indices, char* work, size_t* lwork,      \
+      cuembed_stream_t stream) {                                                              \
+    cuembed::ComputeCompressedGradIndices<INDEX>(indices, nnz, remapped_indices, work, lwork, \
+                                                 Stream(stream));                             \
+  }
+CUEMBED_DEFINE_COMPRESS(i32, int32_t)
+CUEMBED_DEFINE_COMPRESS(i64, int64_t)
+#undef CUEMBED_DEFINE_COMPRESS
+
+#define CUEMBED_DEFINE_EXTRACT(SUFFIX, INDEX)                                                 \
+  void cuembed_extract_row_ids_from_fixed_##SUFFIX(int batch_size, int num_hots,              \
+                                                   INDEX* row_ids, cuembed_stream_t stream) { \
+    cuembed::ExtractRowIdsFromFixed<INDEX>(batch_size, num_hots, row_ids, Stream(stream));    \
+  }                                                                                           \
+  void cuembed_extract_row_ids_for_concat_##SUFFIX(int nnz, INDEX* row_ids,                   \
+                                                   cuembed_stream_t stream) {                 \
+    cuembed::ExtractRowIdsForConcat<INDEX>(nnz, row_ids, Stream(stream));                     \
+  }
+CUEMBED_DEFINE_EXTRACT(i32, int32_t)
+CUEMBED_DEFINE_EXTRACT(i64, int64_t)
+#undef CUEMBED_DEFINE_EXTRACT
+
+#define CUEMBED_DEFINE_EXTRACT_CSR(SUFFIX, INDEX, OFFSET)                                     \
+  void cuembed_extract_row_ids_from_csr_##SUFFIX(const OFFSET* offsets, int batch_size,       \
+                                                 INDEX* row_ids, cuembed_stream_t stream) {   \
+    cuembed::ExtractRowIdsFromCSR<INDEX, OFFSET>(offsets, batch_size, row_ids,                \
+                                                 Stream(stream));                             \
+  }
+CUEMBED_DEFINE_EXTRACT_CSR(i32_o32, int32_t, int32_t)
+CUEMBED_DEFINE_EXTRACT_CSR(i32_o64, int32_t, int64_t)
+CUEMBED_DEFINE_EXTRACT_CSR(i64_o32, int64_t, int32_t)
+CUEMBED_DEFINE_EXTRACT_CSR(i64_o64, int64_t, int64_t)
+#undef CUEMBED_DEFINE_EXTRACT_CSR
+
+void cuembed_transpose(const void* rows, const void* cols, const void* weights, int nnz,
+                       int index_type, int weight_type, void* transpose_rows,
+                       void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
+                       cuembed_stream_t stream) {
+#define TR(I, W)                                                                              \
+  cuembed::Transpose<I, W>(static_cast<const I*>(rows), static_cast<const I*>(cols),          \
+                           static_cast<const W*>(weights), nnz, static_cast<I*>(transpose_rows), \
+                           static_cast<I*>(transpose_cols), static_cast<W*>(transpose_weights), \
+                           work, lwork, Stream(stream))
+  switch ((index_type << 1) | weight_type) {
+    case 0: TR(int32_t, float); break;
+    case 1: TR(int32_t, __half); break;
+    case 2: TR(int64_t, float); break;
+    case 3: TR(int64_t, __half); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef TR
+}
+
+void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
+                                             void* remapped_indices, char* work, size_t* lwork,
+                                             cuembed_stream_t stream) {
+  if (index_type == CUEMBED_I32)
+    cuembed::ComputeCompressedGradIndices<int32_t>(static_cast<const int32_t*>(indices), nnz,
+                                                   static_cast<int32_t*>(remapped_indices), work,
+                                                   lwork, Stream(stream));
+  else if (index_type == CUEMBED_I64)
+    cuembed::ComputeCompressedGradIndices<int64_t>(static_cast<const int64_t*>(indices), nnz,
+                                                   static_cast<int64_t*>(remapped_indices), work,
+                                                   lwork, Stream(stream));
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
+void cuembed_extract_row_ids_from_fixed(int batch_size, int num_hots, int index_type,
+                                        void* row_ids, cuembed_stream_t stream) {
+  if (index_type == CUEMBED_I32)
+    cuembed::ExtractRowIdsFromFixed<int32_t>(batch_size, num_hots,
+                                             static_cast<int32_t*>(row_ids), Stream(stream));
+  else if (index_type == CUEMBED_I64)
+    cuembed::ExtractRowIdsFromFixed<int64_t>(batch_size, num_hots,
+                                             static_cast<int64_t*>(row_ids), Stream(stream));
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
+void cuembed_extract_row_ids_for_concat(int nnz, int index_type, void* row_ids,
+                                        cuembed_stream_t stream) {
+  if (index_type == CUEMBED_I32)
+    cuembed::ExtractRowIdsForConcat<int32_t>(nnz, static_cast<int32_t*>(row_ids), Stream(stream));
+  else if (index_type == CUEMBED_I64)
+    cuembed::ExtractRowIdsForConcat<int64_t>(nnz, static_cast<int64_t*>(row_ids), Stream(stream));
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
+void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int batch_size,
+                                      int index_type, void* row_ids, cuembed_stream_t stream) {
+#define EX(I, O)                                                                              \
+  cuembed::ExtractRowIdsFromCSR<I, O>(static_cast<const O*>(offsets), batch_size,             \
+                                      static_cast<I*>(row_ids), Stream(stream))
+  switch ((index_type << 1) | offset_type) {
+    case 0: EX(int32_t, int32_t); break;
+    case 1: EX(int32_t, int64_t); break;
+    case 2: EX(int64_t, int32_t); break;
+    case 3: EX(int64_t, int64_t); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef EX
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// MI355X (gfx950 / CDNA4) embedding lookup -- EmbeddingBackward host API.
+// Included by embedding_lookup.hpp; see that file for the conventions.
+#ifndef CUEMBED_INCLUDE_EMBEDDING_BACKWARD_HPP_
+#define CUEMBED_INCLUDE_EMBEDDING_BACKWARD_HPP_
+
+#include "cuembed/include/embedding_lookup.hpp"
+
+namespace cuembed {
+
+namespace detail {
+
+constexpr int kMaxSegmentLen = 128;
+constexpr int kMinSegmentLen = 8;
+//! Lanes wanted in flight on the whole chip before segments are shortened:
+//! 256 CUs x 2048 lanes x 0.4 (the reference's 40 % target,
+//! embedding_lookup.cuh:312, :365-375, evaluated for MI355X without a device query).
+constexpr int64_t kBackwardTargetLanes = static_cast<int64_t>(256) * 2048 * 4 / 10;
+
+inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
+  int len = kMaxSegmentLen;
+  while (len > kMinSegmentLen && (nnz / len) * lanes_per_row < kBackwardTargetLanes) len /= 2;
+  return len;
+}
+
+template <typename GradT, typename IndexT, int N>
+inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
+                             const IndexT* sample_ids, const GradT* weights, int64_t nnz,
+                             GradT* grad_out, RowSplit split, hipStream_t stream) {
+  const int segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
+  const int64_t num_segments = (nnz + segment_len - 1) / segment_len;
+  const dim3 block(split.lanes_per_row, split.rows_per_block, 1);
+  const dim3 grid(static_cast<unsigned>((num_segments + split.rows_per_block - 1) /
+                                        split.rows_per_block),
+                  1, 1);
+  if (weights != nullptr)
+    SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, 0, stream>>>(
+        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);
+  else
+    SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, 0, stream>>>(
+        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);
+}
+
+}  // namespace detail
+
+/**
+ * @brief Embedding backward: scatter-add `grad_y` rows into the gradient of the
+ * table, from index-sorted COO lookups (the output of Transpose()).  Full
+ * gradient (`transpose_remapped_indices == nullptr`, `grad_embedding` has one row
+ * per table row) or compressed gradient (`transpose_remapped_indices` from
+ * ComputeCompressedGradIndices(), `grad_embedding` has `num_unique` rows and
+ * `inverse_mapping[num_unique]` receives the table row of each).  Same contract
+ * as the reference (embedding_lookup.cuh:397-483): the output must be zero
+ * before the scatter; `skip_grad_init` means the caller already zeroed it.
+ */
+template <typename GradT, typename IndexT>
+void EmbeddingBackward(const GradT* grad_y,
+                       const int embed_width,
+                       const int num_grad_embedding_rows,
+                       const int nnz,
+                       const IndexT* transpose_indices,
+                       const IndexT* transpose_sample_ids,
+                       const IndexT* transpose_remapped_indices,
+                       const GradT* transpose_weights,
+                       const bool skip_grad_init,
+                       GradT* grad_embedding,
+                       IndexT* inverse_mapping,
+                       const hipStream_t stream = 0) {
+  static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value,
+                "EmbeddingBackward: gradients must be float or __half");
+  using ElemT = detail::DeviceElemT<GradT>;
+
+  const IndexT* rows =
+      transpose_remapped_indices != nullptr ? transpose_remapped_indices : transpose_indices;
+
+  if (transpose_remapped_indices != nullptr && nnz > 0) {
+    CUEMBED_ASSERT(inverse_mapping != nullptr);
+    const int threads = detail::kDefaultBlockThreads;
+    detail::CompactRunHeadsKernel<IndexT><<<(nnz + threads - 1) / threads, threads, 0, stream>>>(
+        transpose_indices, transpose_remapped_indices, inverse_mapping, nnz);
+  }
+  if (!skip_grad_init) {
+    (void)hipMemsetAsync(grad_embedding, 0,
+                         static_cast<size_t>(num_grad_embedding_rows) *
+                             static_cast<size_t>(embed_width) * sizeof(GradT),
+                         stream);
+  }
+  if (nnz <= 0) return;
+
+  const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
+  const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
+  ElemT* out = reinterpret_cast<ElemT*>(grad_embedding);
+  const detail::RowSplit split = detail::SplitRow<ElemT>(embed_width, grad_y, grad_embedding);
+  constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
+  if (split.elems_per_lane == kMaxN)
+    detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w,
+                                                   nnz, out, split, stream);
+  else if (split.elems_per_lane == kMaxN / 2)
+    detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows,
+                                                       transpose_sample_ids, w, nnz, out, split,
+                                                       stream);
+  else
+    detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows,
+                                                       transpose_sample_ids, w, nnz, out, split,
+                                                       stream);
+}
+
+}  // namespace cuembed
+
+#endif  // CUEMBED_INCLUDE_EMBEDDING_BACKWARD_HPP_

@@ -1,0 +1,238 @@
+// MI355X (gfx950 / CDNA4) embedding lookup -- header-only host API.
+//
+// Drop-in for the reference's cuembed/include/embedding_lookup.cuh: the same
+// function templates in the same namespace with the same parameter order and
+// the same abort-on-misuse contract; `hipStream_t` replaces `cudaStream_t`.
+//   EmbeddingForward  <-> embedding_lookup.cuh:245-308
+//   EmbeddingBackward <-> embedding_lookup.cuh:423-483
+// The launch heuristics are this library's own (64-lane wavefronts, 256 CUs);
+// they do not change results.  Every call is asynchronous on `stream`, allocates
+// nothing and keeps no state; all pointers are device (or managed) pointers
+// owned by the caller.
+#ifndef CUEMBED_INCLUDE_EMBEDDING_LOOKUP_HPP_
+#define CUEMBED_INCLUDE_EMBEDDING_LOOKUP_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <type_traits>
+
+#include "cuembed/include/embedding_types.hpp"
+#include "cuembed/include/gather_reduce_kernels.hpp"
+#include "cuembed/include/scatter_add_kernels.hpp"
+
+//! Contract violations print the failed condition and abort, exactly like the
+//! reference (embedding_lookup.cuh:151-158).
+#define CUEMBED_ASSERT(condition)                                           \
+  do {                                                                      \
+    if (!(condition)) {                                                     \
+      std::cerr << "Check failed: " #condition << " at " << __FILE__ << ":" \
+                << __LINE__ << std::endl;                                   \
+      std::abort();                                                         \
+    }                                                                       \
+  } while (0)
+
+namespace cuembed {
+
+namespace detail {
+
+constexpr int kDefaultBlockThreads = 256;
+//! Index (+weight) staging budget per workgroup.  Small enough that eight
+//! 256-thread workgroups still fit a CU's 160 KiB LDS.
+constexpr int kMaxStageBytes = 16 * 1024;
+
+//! How a row is split over lanes and how many samples share a workgroup.
+struct RowSplit {
+  int elems_per_lane;   //!< N: 16, 8 or 4 bytes worth of elements
+  int lanes_per_row;    //!< width / N  (<= 1024)
+  int rows_per_block;   //!< samples (forward) or nz-segments (backward) per workgroup
+};
+
+//! Widest naturally aligned access that the row stride AND every base pointer
+//! allow (the reference's DivideRowIntoVectors, embedding_lookup.cuh:160-181,
+//! looks at the row size only and would fault on an unaligned view).
+template <typename ElemT>
+inline RowSplit SplitRow(const int embed_width, const void* p0, const void* p1) {
+  const size_t row_bytes = static_cast<size_t>(embed_width) * sizeof(ElemT);
+  CUEMBED_ASSERT(embed_width > 0);
+  CUEMBED_ASSERT(row_bytes % 4 == 0);
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) |
+                         static_cast<uintptr_t>(row_bytes);
+  int bytes_per_lane = 4;
+  if (bits % 16 == 0) bytes_per_lane = 16;
+  else if (bits % 8 == 0) bytes_per_lane = 8;
+  CUEMBED_ASSERT(reinterpret_cast<uintptr_t>(p0) % 4 == 0 &&
+                 reinterpret_cast<uintptr_t>(p1) % 4 == 0);
+  RowSplit s;
+  s.elems_per_lane = bytes_per_lane / static_cast<int>(sizeof(ElemT));
+  s.lanes_per_row = embed_width / s.elems_per_lane;
+  CUEMBED_ASSERT(s.lanes_per_row <= kMaxBlockThreads);
+  s.rows_per_block =
+      s.lanes_per_row >= kDefaultBlockThreads ? 1 : kDefaultBlockThreads / s.lanes_per_row;
+  return s;
+}
+
+//! Complete launch description of one forward call.
+struct ForwardLaunch {
+  RowSplit split;
+  size_t stage_bytes;  //!< dynamic LDS: staged indices (+ weights)
+  bool staged;         //!< fixed-hotness indices staged in LDS
+  unsigned grid;
+};
+
+//! Forward launch heuristics (counterpart of GetKernelLaunchParams,
+//! embedding_lookup.cuh:186-208): 256-thread workgroups of
+//! `rows_per_block` samples; fixed-hotness indices are staged in LDS when the
+//! workgroup's share fits kMaxStageBytes (halving the samples per workgroup
+//! first), otherwise -- and always for CSR and concat -- they are read from
+//! global memory.
+template <typename ElemT, typename IndexT>
+inline ForwardLaunch PlanForward(const int embed_width, const void* params, const void* ret,
+                                 const int batch, const int num_hots, const bool is_csr,
+                                 const bool weighted, const bool concat) {
+  ForwardLaunch f;
+  f.split = SplitRow<ElemT>(embed_width, params, ret);
+  f.stage_bytes = 0;
+  f.staged = false;
+  if (!is_csr && !concat) {
+    const size_t per_sample =
+        static_cast<size_t>(num_hots) * (sizeof(IndexT) + (weighted ? sizeof(ElemT) : 0));
+    int rows = f.split.rows_per_block;
+    while (rows > 1 && rows * per_sample > static_cast<size_t>(kMaxStageBytes)) rows /= 2;
+    if (rows * per_sample <= static_cast<size_t>(kMaxStageBytes)) {
+      f.staged = true;
+      f.split.rows_per_block = rows;
+      f.stage_bytes = rows * per_sample;
+    }
+  }
+  f.grid = static_cast<unsigned>((batch + f.split.rows_per_block - 1) / f.split.rows_per_block);
+  return f;
+}
+
+template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N>
+inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indices,
+                               const OffsetT* offsets, const ElemT* weights, int batch,
+                               int num_hots, bool is_mean, ElemT* out, const ForwardLaunch& f,
+                               hipStream_t stream) {
+  const bool weighted = weights != nullptr;
+  const dim3 block(f.split.lanes_per_row, f.split.rows_per_block, 1);
+  const dim3 grid(f.grid, 1, 1);
+#define CUEMBED_LAUNCH_GR(W, SRC)                                                         \
+  GatherReduceKernel<ElemT, AccT, IndexT, OffsetT, N, W, SRC>                             \
+      <<<grid, block, f.stage_bytes, stream>>>(table, width, batch, indices, offsets,     \
+                                               num_hots, weights, is_mean, out)
+  if (f.staged) {
+    if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kLdsStaged);
+    else CUEMBED_LAUNCH_GR(false, IndexSource::kLdsStaged);
+  } else {
+    if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kGlobal);
+    else CUEMBED_LAUNCH_GR(false, IndexSource::kGlobal);
+  }
+#undef CUEMBED_LAUNCH_GR
+}
+
+template <typename ElemT, typename IndexT, int N>
+inline void LaunchGatherConcat(const ElemT* table, int width, const IndexT* indices, int batch,
+                               int num_hots, ElemT* out, const ForwardLaunch& f,
+                               hipStream_t stream) {
+  const dim3 block(f.split.lanes_per_row, f.split.rows_per_block, 1);
+  const dim3 grid(f.grid, 1, 1);
+  GatherConcatKernel<ElemT, IndexT, N>
+      <<<grid, block, 0, stream>>>(table, width, batch, indices, num_hots, out);
+}
+
+}  // namespace detail
+
+/**
+ * @brief Embedding forward: gather the rows named by `indices` and combine them
+ * per sample.  Fixed hotness (`offsets == nullptr`, `num_hots > 0`) or CSR
+ * (`offsets[batch_size + 1]`, `num_hots == 0`).  Same contract as the reference
+ * (embedding_lookup.cuh:210-308).
+ *
+ * @tparam InputT   table element type (float or __half)
+ * @tparam OutputT  result element type (must equal InputT)
+ * @tparam IndexT   int32_t or int64_t
+ * @tparam OffsetT  CSR offset type (int32_t or int64_t)
+ * @tparam fp16_math accumulate __half tables in fp16 instead of fp32
+ *
+ * @param params      table, row-major [rows x embed_width]
+ * @param embed_width elements per row (row bytes must be a multiple of 4)
+ * @param indices     lookup indices (fixed: [batch x num_hots]; CSR: [nnz])
+ * @param offsets     CSR offsets or nullptr
+ * @param weights     per-lookup weights (same layout as indices) or nullptr
+ * @param batch_size  number of samples
+ * @param num_hots    fixed hotness, 0 for CSR
+ * @param mode        kSum, kMean or kConcat (concat: fixed hotness, unweighted)
+ * @param ret         output: [batch x width] (sum/mean), [batch x num_hots x width] (concat)
+ * @param stream      HIP stream
+ */
+template <typename InputT,
+          typename OutputT,
+          typename IndexT,
+          typename OffsetT,
+          bool fp16_math = false>
+void EmbeddingForward(const InputT* params,
+                      const int embed_width,
+                      const IndexT* indices,
+                      const OffsetT* offsets,
+                      const GetElemT<InputT>* weights,
+                      const int batch_size,
+                      const int num_hots,
+                      const CombineMode mode,
+                      OutputT* ret,
+                      const hipStream_t stream = 0) {
+  static_assert(std::is_same<InputT, OutputT>::value,
+                "EmbeddingForward: OutputT must equal InputT");
+  using HostElemT = GetElemT<InputT>;
+  static_assert(std::is_same<HostElemT, float>::value || std::is_same<HostElemT, __half>::value,
+                "EmbeddingForward: table elements must be float or __half");
+  using ElemT = detail::DeviceElemT<HostElemT>;
+  using AccT = typename std::conditional<fp16_math && detail::IsHalf<ElemT>::value, ElemT,
+                                         float>::type;
+
+  // Same argument contract as the reference (embedding_lookup.cuh:261-267).
+  CUEMBED_ASSERT(weights == nullptr || mode != CombineMode::kConcat);
+  CUEMBED_ASSERT((offsets != nullptr && num_hots == 0) || (offsets == nullptr && num_hots > 0));
+  CUEMBED_ASSERT(offsets == nullptr || mode != CombineMode::kConcat);
+  if (batch_size <= 0) return;
+
+  const ElemT* table = reinterpret_cast<const ElemT*>(params);
+  const ElemT* w = reinterpret_cast<const ElemT*>(weights);
+  ElemT* out = reinterpret_cast<ElemT*>(ret);
+  const detail::ForwardLaunch split = detail::PlanForward<ElemT, IndexT>(
+      embed_width, params, ret, batch_size, num_hots, offsets != nullptr, weights != nullptr,
+      mode == CombineMode::kConcat);
+  constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
+  const int elems_per_lane = split.split.elems_per_lane;
+
+  if (mode == CombineMode::kConcat) {
+    if (elems_per_lane == kMaxN)
+      detail::LaunchGatherConcat<ElemT, IndexT, kMaxN>(table, embed_width, indices, batch_size,
+                                                       num_hots, out, split, stream);
+    else if (elems_per_lane == kMaxN / 2)
+      detail::LaunchGatherConcat<ElemT, IndexT, kMaxN / 2>(table, embed_width, indices,
+                                                           batch_size, num_hots, out, split, stream);
+    else
+      detail::LaunchGatherConcat<ElemT, IndexT, kMaxN / 4>(table, embed_width, indices,
+                                                           batch_size, num_hots, out, split, stream);
+    return;
+  }
+  const bool is_mean = mode == CombineMode::kMean;
+  if (elems_per_lane == kMaxN)
+    detail::LaunchGatherReduce<ElemT, AccT, IndexT, OffsetT, kMaxN>(
+        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
+  else if (elems_per_lane == kMaxN / 2)
+    detail::LaunchGatherReduce<ElemT, AccT, IndexT, OffsetT, kMaxN / 2>(
+        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
+  else
+    detail::LaunchGatherReduce<ElemT, AccT, IndexT, OffsetT, kMaxN / 4>(
+        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
+}
+
+}  // namespace cuembed
+
+#include "cuembed/include/embedding_backward.hpp"
+
+#endif  // CUEMBED_INCLUDE_EMBEDDING_LOOKUP_HPP_

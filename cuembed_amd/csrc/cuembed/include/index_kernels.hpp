@@ -1,0 +1,95 @@
+// MI355X (gfx950 / CDNA4) small integer kernels behind index_transforms.hpp.
+// Counterparts of the reference's index_transforms_kernels.cuh:28-81; all
+// results are integers and bit-exact.
+#ifndef CUEMBED_INCLUDE_INDEX_KERNELS_HPP_
+#define CUEMBED_INCLUDE_INDEX_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace cuembed {
+namespace detail {
+
+constexpr int kSequenceItemsPerThread = 4;
+//! Samples whose offsets one workgroup stages in LDS for ExpandCsrKernel.
+constexpr int kCsrSamplesPerBlock = 1024;
+
+//! out[t] = t / divisor.  Grid-free of tails: each workgroup covers
+//! blockDim.x * kSequenceItemsPerThread consecutive items, lane-interleaved so
+//! every store instruction of a wave is one contiguous 256/512-byte segment.
+template <typename OutT>
+__global__ void FillQuotientKernel(const int64_t count, const int divisor, OutT* __restrict__ out) {
+  const int64_t base =
+      static_cast<int64_t>(blockIdx.x) * blockDim.x * kSequenceItemsPerThread + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kSequenceItemsPerThread; ++k) {
+    const int64_t t = base + static_cast<int64_t>(k) * blockDim.x;
+    if (t < count) out[t] = static_cast<OutT>(divisor == 1 ? t : t / divisor);
+  }
+}
+
+//! row_ids[i] = b for i in [offsets[b], offsets[b+1]).
+//! The reference launches one 256-thread block per sample for ~hotness elements
+//! (index_transforms_kernels.cuh:28-37).  Here a workgroup owns
+//! kCsrSamplesPerBlock consecutive samples: their offsets are staged in LDS, and
+//! the workgroup then writes its contiguous slice of row_ids with coalesced
+//! stores, each lane locating its sample by a binary search in LDS.
+template <typename OffsetT, typename IndexT>
+__global__ void __launch_bounds__(256)
+ExpandCsrKernel(const OffsetT* __restrict__ offsets, const int batch, IndexT* __restrict__ row_ids) {
+  __shared__ int64_t bounds[kCsrSamplesPerBlock + 1];
+  const int first_sample = blockIdx.x * kCsrSamplesPerBlock;
+  const int nsamples =
+      (batch - first_sample < kCsrSamplesPerBlock) ? batch - first_sample : kCsrSamplesPerBlock;
+  for (int s = threadIdx.x; s <= nsamples; s += blockDim.x) {
+    bounds[s] = static_cast<int64_t>(offsets[first_sample + s]);
+  }
+  __syncthreads();
+  const int64_t lo_pos = bounds[0];
+  const int64_t hi_pos = bounds[nsamples];
+  for (int64_t pos = lo_pos + threadIdx.x; pos < hi_pos; pos += blockDim.x) {
+    // largest s with bounds[s] <= pos  (empty bags have bounds[s] == bounds[s+1])
+    int lo = 0, hi = nsamples;  // invariant: bounds[lo] <= pos < bounds[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (bounds[mid] <= pos) lo = mid;
+      else hi = mid;
+    }
+    row_ids[pos] = static_cast<IndexT>(first_sample + lo);
+  }
+}
+
+//! out_rows[i] = rows[pos[i]], out_weights[i] = weights[pos[i]]
+//! (second half of the weighted transpose; the reference moves a
+//! (sample id, weight) struct through the sort instead,
+//! index_transforms_kernels.cuh:50-81).
+template <typename IndexT, typename WeightT>
+__global__ void GatherByPositionKernel(const uint32_t* __restrict__ pos,
+                                       const IndexT* __restrict__ rows,
+                                       const WeightT* __restrict__ weights,
+                                       const int64_t count,
+                                       IndexT* __restrict__ out_rows,
+                                       WeightT* __restrict__ out_weights) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t p = pos[i];
+  out_rows[i] = rows[p];
+  out_weights[i] = weights[p];
+}
+
+//! flag(i) = 1 when lookup i starts a new run of equal indices, 0 for i == 0
+//! (reference: FlagNonzero + the memset of element 0, index_transforms.cuh
+//! :252-257, :307-315).  Used as a transform iterator feeding the scan.
+template <typename IndexT>
+struct RunHeadFlag {
+  const IndexT* indices;
+  __host__ __device__ __forceinline__ IndexT operator()(size_t i) const {
+    return (i > 0 && indices[i] != indices[i - 1]) ? IndexT(1) : IndexT(0);
+  }
+};
+
+}  // namespace detail
+}  // namespace cuembed
+
+#endif  // CUEMBED_INCLUDE_INDEX_KERNELS_HPP_

@@ -1,0 +1,197 @@
+// MI355X (gfx950 / CDNA4) embedding lookup -- index transformations (host API).
+//
+// Drop-in for the reference's cuembed/include/index_transforms.cuh: same
+// function templates, parameter order, two-phase workspace query
+// (`work == nullptr` => `*lwork` receives the bytes needed, nothing runs) and
+// stream-ordered asynchronous execution; `hipStream_t` replaces `cudaStream_t`.
+//   ExtractRowIdsFromFixed       <-> index_transforms.cuh:45-55
+//   ExtractRowIdsFromCSR         <-> index_transforms.cuh:66-74
+//   ExtractRowIdsForConcat       <-> index_transforms.cuh:85-93
+//   Transpose                    <-> index_transforms.cuh:224-250
+//   ComputeCompressedGradIndices <-> index_transforms.cuh:278-323
+// Every result is integer (or a permutation of the inputs) and bit-exact.
+#ifndef CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_
+#define CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cassert>
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "cuembed/include/embedding_lookup.hpp"
+#include "cuembed/include/index_kernels.hpp"
+
+namespace cuembed {
+
+namespace detail {
+inline size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int kIndexBlockThreads = 256;
+}  // namespace detail
+
+/*!
+ * \brief row_ids[t] = t / num_hots for t in [0, batch_size * num_hots):
+ * num_hots = 3 -> [0, 0, 0, 1, 1, 1, 2, 2, 2, ...]
+ */
+template <typename IndexT>
+void ExtractRowIdsFromFixed(const int batch_size,
+                            const int num_hots,
+                            IndexT* row_ids,
+                            const hipStream_t stream = 0) {
+  const int64_t nnz = static_cast<int64_t>(batch_size) * num_hots;
+  if (nnz <= 0) return;
+  const int threads = detail::kIndexBlockThreads;
+  const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
+  detail::FillQuotientKernel<IndexT>
+      <<<static_cast<unsigned>((nnz + per_block - 1) / per_block), threads, 0, stream>>>(
+          nnz, num_hots, row_ids);
+}
+
+/*!
+ * \brief Expand CSR offsets to one sample id per lookup:
+ * offsets = [0, 2, 3, 5] -> row_ids = [0, 0, 1, 2, 2].
+ * row_ids[i] = b for i in [offsets[b], offsets[b + 1]).
+ */
+template <typename IndexT, typename OffsetT>
+void ExtractRowIdsFromCSR(const OffsetT* offsets,
+                          const int batch_size,
+                          IndexT* row_ids,
+                          const hipStream_t stream = 0) {
+  if (batch_size <= 0) return;
+  const int threads = detail::kIndexBlockThreads;
+  const int blocks = (batch_size + detail::kCsrSamplesPerBlock - 1) / detail::kCsrSamplesPerBlock;
+  detail::ExpandCsrKernel<OffsetT, IndexT>
+      <<<blocks, threads, 0, stream>>>(offsets, batch_size, row_ids);
+}
+
+/*!
+ * \brief row_ids = [0, 1, 2, ..., nnz - 1] (every lookup is its own output row).
+ */
+template <typename IndexT>
+void ExtractRowIdsForConcat(const int nnz, IndexT* row_ids, const hipStream_t stream = 0) {
+  if (nnz <= 0) return;
+  const int threads = detail::kIndexBlockThreads;
+  const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
+  detail::FillQuotientKernel<IndexT>
+      <<<static_cast<unsigned>((nnz + per_block - 1) / per_block), threads, 0, stream>>>(
+          nnz, 1, row_ids);
+}
+
+/**
+ * @brief Reorder sample-major COO lookups into index-major order: a STABLE sort
+ * of (rows[i] [, weights[i]]) by the key cols[i].
+ *
+ * Naming follows the reference's code, not its README (index_transforms.cuh
+ * :95-137; callers pass rows = sample ids, cols = lookup indices):
+ *   transpose_rows    <- cols sorted ascending               (table row ids)
+ *   transpose_cols    <- rows carried along, input order kept inside a run
+ *   transpose_weights <- weights carried along (only when weights != nullptr)
+ *
+ * Two-phase: call with work == nullptr to get *lwork, then with a buffer of at
+ * least that many bytes.
+ */
+template <typename IndexT, typename WeightT>
+void Transpose(const IndexT* rows,
+               const IndexT* cols,
+               const WeightT* weights,
+               const int nnz,
+               IndexT* transpose_rows,
+               IndexT* transpose_cols,
+               WeightT* transpose_weights,
+               char* work,
+               size_t* lwork,
+               const hipStream_t stream = 0) {
+  using KeyT = typename std::make_unsigned<IndexT>::type;  // ids are non-negative
+  const unsigned int begin_bit = 0;
+  const unsigned int end_bit = sizeof(IndexT) * 8;
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
+  const KeyT* keys_in = reinterpret_cast<const KeyT*>(cols);
+  KeyT* keys_out = reinterpret_cast<KeyT*>(transpose_rows);
+
+  if (weights == nullptr) {
+    // keys = lookup index, values = sample id: one radix sort does it all.
+    size_t sort_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_in, keys_out, rows, transpose_cols,
+                                    n, begin_bit, end_bit, stream);
+    if (work == nullptr) {
+      *lwork = sort_bytes;
+      return;
+    }
+    assert(*lwork >= sort_bytes);
+    if (n == 0) return;
+    (void)rocprim::radix_sort_pairs(work, sort_bytes, keys_in, keys_out, rows, transpose_cols, n,
+                                    begin_bit, end_bit, stream);
+    return;
+  }
+
+  // Weighted: sort (key, original position) and gather sample id + weight
+  // through the sorted positions -- the payload that rides through every radix
+  // pass stays 4 bytes instead of a (sample id, weight) struct.
+  const size_t pos_bytes = detail::AlignUp(n * sizeof(uint32_t), 256);
+  size_t sort_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_in, keys_out,
+                                  static_cast<const uint32_t*>(nullptr),
+                                  static_cast<uint32_t*>(nullptr), n, begin_bit, end_bit, stream);
+  const size_t required = 2 * pos_bytes + sort_bytes;
+  if (work == nullptr) {
+    *lwork = required;
+    return;
+  }
+  assert(*lwork >= required);
+  if (n == 0) return;
+  uint32_t* pos_in = reinterpret_cast<uint32_t*>(work);
+  uint32_t* pos_out = reinterpret_cast<uint32_t*>(work + pos_bytes);
+  void* sort_work = work + 2 * pos_bytes;
+
+  const int threads = detail::kIndexBlockThreads;
+  const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
+  const unsigned blocks = static_cast<unsigned>((nnz + per_block - 1) / per_block);
+  detail::FillQuotientKernel<uint32_t><<<blocks, threads, 0, stream>>>(nnz, 1, pos_in);
+  (void)rocprim::radix_sort_pairs(sort_work, sort_bytes, keys_in, keys_out, pos_in, pos_out, n,
+                                  begin_bit, end_bit, stream);
+  detail::GatherByPositionKernel<IndexT, WeightT>
+      <<<(nnz + threads - 1) / threads, threads, 0, stream>>>(pos_out, rows, weights, nnz,
+                                                               transpose_cols, transpose_weights);
+}
+
+/**
+ * @brief Map sorted lookup indices to dense ids 0..num_unique-1:
+ * indices = [4, 4, 7, 8, 8, 8, 18] -> remapped_indices = [0, 0, 1, 2, 2, 2, 3].
+ * (num_unique = remapped_indices[nnz - 1] + 1, read back by the caller.)
+ * One fused pass: an inclusive scan over run-head flags generated on the fly.
+ * Two-phase workspace query as for Transpose().
+ */
+template <typename IndexT>
+void ComputeCompressedGradIndices(const IndexT* indices,
+                                  const int nnz,
+                                  IndexT* remapped_indices,
+                                  char* work,
+                                  size_t* lwork,
+                                  const hipStream_t stream = 0) {
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
+  auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0),
+                                                detail::RunHeadFlag<IndexT>{indices});
+  size_t scan_bytes = 0;
+  (void)rocprim::inclusive_scan(nullptr, scan_bytes, flags, remapped_indices, n,
+                                rocprim::plus<IndexT>(), stream);
+  if (work == nullptr) {
+    *lwork = scan_bytes;
+    return;
+  }
+  assert(*lwork >= scan_bytes);
+  if (n == 0) return;
+  (void)rocprim::inclusive_scan(work, scan_bytes, flags, remapped_indices, n,
+                                rocprim::plus<IndexT>(), stream);
+}
+
+}  // namespace cuembed
+
+#endif  // CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_

@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's C++ host API on torch device tensors.
+
+Each function validates its arguments the way the reference does (raising
+instead of aborting, like the reference's torch binding does with AT_ASSERT),
+then enqueues the HIP kernels on torch's current stream through the C ABI.
+torch is used for device memory and streams only.
+
+    embedding_forward              <-> cuembed::EmbeddingForward   (embedding_lookup.cuh:245-308)
+    embedding_backward             <-> cuembed::EmbeddingBackward  (embedding_lookup.cuh:423-483)
+    transpose                      <-> cuembed::Transpose          (index_transforms.cuh:224-250)
+    compute_compressed_grad_indices<-> ComputeCompressedGradIndices(index_transforms.cuh:278-323)
+    extract_row_ids_from_fixed/csr/for_concat <-> index_transforms.cuh:45-93
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+SUM, MEAN, CONCAT = 0, 1, 2
+_MODES = {"sum": SUM, "mean": MEAN, "concat": CONCAT, SUM: SUM, MEAN: MEAN, CONCAT: CONCAT}
+_ELEM = {torch.float32: 0, torch.float16: 1}
+_INDEX = {torch.int32: 0, torch.int64: 1}
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _check_dev(name, t, device=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("cuembed_amd: %s must live on the GPU (no CPU fallback exists)" % name)
+    if device is not None and t.device != device:
+        raise RuntimeError("cuembed_amd: %s is on %s, expected %s" % (name, t.device, device))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _elem_code(name, t):
+    if t.dtype not in _ELEM:
+        raise TypeError("%s must be float32 or float16, got %s" % (name, t.dtype))
+    return _ELEM[t.dtype]
+
+
+def _index_code(name, t):
+    if t.dtype not in _INDEX:
+        raise TypeError("%s must be int32 or int64, got %s" % (name, t.dtype))
+    return _INDEX[t.dtype]
+
+
+def forward_launch_shape(elem_dtype, index_dtype, embed_width, batch_size, num_hots, is_csr=False,
+                         is_weighted=False, mode="sum"):
+    """Launch shape the forward kernel would use (pure host arithmetic)."""
+    out = (ctypes.c_int * 6)()
+    _lib.lib().cuembed_forward_launch_shape(_ELEM[elem_dtype], _INDEX[index_dtype], embed_width,
+                                            batch_size, num_hots, int(is_csr), int(is_weighted),
+                                            _MODES[mode], out)
+    return dict(elems_per_lane=out[0], lanes_per_row=out[1], samples_per_block=out[2],
+                grid=out[3], lds_bytes=out[4], staged=bool(out[5]))
+
+
+def embedding_forward(params, indices, offsets=None, weights=None, batch_size=None, num_hots=0,
+                      mode="sum", fp16_math=False, out=None):
+    """out[s] = combine_j weights[s,j] * params[indices[s,j]].
+
+    Fixed hotness: offsets=None, num_hots>0 (indices holds batch_size*num_hots ids).
+    CSR: offsets[batch_size+1], num_hots=0.  mode: "sum" | "mean" | "concat".
+    Returns [batch, width] (sum/mean) or [batch, num_hots, width] (concat)."""
+    if mode not in _MODES:
+        raise ValueError("mode must be 'sum', 'mean' or 'concat'")
+    m = _MODES[mode]
+    _check_dev("params", params)
+    dev = params.device
+    _check_dev("indices", indices, dev)
+    if params.dim() != 2:
+        raise ValueError("params must be [rows, width]")
+    et = _elem_code("params", params)
+    it = _index_code("indices", indices)
+    # --- the reference's argument contract (embedding_lookup.cuh:261-267) ---
+    if weights is not None and m == CONCAT:
+        raise ValueError("concat does not take weights")
+    if not ((offsets is not None and num_hots == 0) or (offsets is None and num_hots > 0)):
+        raise ValueError("either CSR (offsets given, num_hots == 0) or fixed hotness "
+                         "(offsets None, num_hots > 0)")
+    if offsets is not None and m == CONCAT:
+        raise ValueError("CSR layout does not support concat")
+    width = params.shape[1]
+    if (width * params.element_size()) % 4 != 0:
+        raise ValueError("row size must be a multiple of 4 bytes")
+    ot = 0
+    if offsets is not None:
+        _check_dev("offsets", offsets, dev)
+        ot = _index_code("offsets", offsets)
+        if batch_size is None:
+            batch_size = offsets.numel() - 1
+        if offsets.numel() < batch_size + 1:
+            raise ValueError("offsets must hold batch_size + 1 entries")
+    else:
+        if batch_size is None:
+            if indices.numel() % num_hots:
+                raise ValueError("indices.numel() is not a multiple of num_hots")
+            batch_size = indices.numel() // num_hots
+        if indices.numel() < batch_size * num_hots:
+            raise ValueError("indices must hold batch_size * num_hots entries")
+    if weights is not None:
+        _check_dev("weights", weights, dev)
+        if weights.dtype != params.dtype:
+            raise TypeError("weights must have the table's dtype")
+        if weights.numel() < indices.numel():
+            raise ValueError("weights must have one entry per index")
+    shape = (batch_size, num_hots, width) if m == CONCAT else (batch_size, width)
+    if out is None:
+        out = torch.empty(shape, dtype=params.dtype, device=dev)
+    else:
+        _check_dev("out", out, dev)
+        if out.dtype != params.dtype or out.numel() != batch_size * (num_hots if m == CONCAT else 1) * width:
+            raise ValueError("out has the wrong dtype or size")
+    if batch_size > 0:
+        _lib.lib().cuembed_embedding_forward(
+            _ptr(params), et, width, _ptr(indices), it, _ptr(offsets), ot, _ptr(weights),
+            batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _stream(params))
+    return out
+
+
+def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, transpose_sample_ids,
+                       transpose_remapped_indices=None, transpose_weights=None,
+                       skip_grad_init=False, grad_embedding=None, inverse_mapping=None):
+    """Scatter-add grad_y rows into the table gradient from index-sorted COO lookups.
+
+    Full gradient: transpose_remapped_indices=None, num_grad_embedding_rows = table rows.
+    Compressed: remapped indices given, num_grad_embedding_rows = num_unique; also returns
+    inverse_mapping[num_unique].  With skip_grad_init=True the caller's grad_embedding must
+    already be zero.  Returns (grad_embedding, inverse_mapping or None)."""
+    _check_dev("grad_y", grad_y)
+    dev = grad_y.device
+    if grad_y.dim() != 2:
+        raise ValueError("grad_y must be [rows, width]")
+    et = _elem_code("grad_y", grad_y)
+    _check_dev("transpose_indices", transpose_indices, dev)
+    _check_dev("transpose_sample_ids", transpose_sample_ids, dev)
+    it = _index_code("transpose_indices", transpose_indices)
+    if transpose_sample_ids.dtype != transpose_indices.dtype:
+        raise TypeError("transpose_sample_ids must have the dtype of transpose_indices")
+    nnz = transpose_indices.numel()
+    if transpose_sample_ids.numel() != nnz:
+        raise ValueError("transpose_sample_ids must have nnz entries")
+    width = grad_y.shape[1]
+    compressed = transpose_remapped_indices is not None
+    if compressed:
+        _check_dev("transpose_remapped_indices", transpose_remapped_indices, dev)
+        if transpose_remapped_indices.dtype != transpose_indices.dtype or \
+                transpose_remapped_indices.numel() != nnz:
+            raise ValueError("transpose_remapped_indices must match transpose_indices")
+    if transpose_weights is not None:
+        _check_dev("transpose_weights", transpose_weights, dev)
+        if transpose_weights.dtype != grad_y.dtype or transpose_weights.numel() != nnz:
+            raise ValueError("transpose_weights must be nnz entries of grad_y's dtype")
+    if grad_embedding is None:
+        if skip_grad_init:
+            grad_embedding = torch.zeros((num_grad_embedding_rows, width), dtype=grad_y.dtype, device=dev)
+        else:
+            grad_embedding = torch.empty((num_grad_embedding_rows, width), dtype=grad_y.dtype, device=dev)
+    else:
+        _check_dev("grad_embedding", grad_embedding, dev)
+        if grad_embedding.dtype != grad_y.dtype or grad_embedding.numel() != num_grad_embedding_rows * width:
+            raise ValueError("grad_embedding has the wrong dtype or size")
+    if compressed:
+        if inverse_mapping is None:
+            inverse_mapping = torch.empty((num_grad_embedding_rows,), dtype=transpose_indices.dtype, device=dev)
+        else:
+            _check_dev("inverse_mapping", inverse_mapping, dev)
+            if inverse_mapping.dtype != transpose_indices.dtype:
+                raise TypeError("inverse_mapping must have the index dtype")
+    else:
+        inverse_mapping = None
+    _lib.lib().cuembed_embedding_backward(
+        _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices),
+        _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
+        int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), _stream(grad_y))
+    return grad_embedding, inverse_mapping
+
+
+def transpose_workspace_bytes(nnz, index_dtype, weight_dtype=None):
+    """Phase 1 of the reference's two-phase call: scratch bytes Transpose needs."""
+    lwork = ctypes.c_size_t(0)
+    wt = 0 if weight_dtype is None else _ELEM[weight_dtype]
+    fake = ctypes.c_void_p(256)  # only nullness of `weights` matters for the query
+    _lib.lib().cuembed_transpose(None, None, None if weight_dtype is None else fake, nnz,
+                                 _INDEX[index_dtype], wt, None, None, None, None,
+                                 ctypes.byref(lwork), None)
+    return lwork.value
+
+
+def transpose(rows, cols, weights=None, workspace=None):
+    """Stable sort of (rows[i][, weights[i]]) by key cols[i] (callers pass rows = sample ids,
+    cols = lookup indices).  Returns (sorted cols, rows carried along, weights carried along)."""
+    _check_dev("rows", rows)
+    dev = rows.device
+    _check_dev("cols", cols, dev)
+    it = _index_code("rows", rows)
+    if cols.dtype != rows.dtype or cols.numel() != rows.numel():
+        raise ValueError("rows and cols must have the same dtype and length")
+    nnz = rows.numel()
+    wt = 0
+    t_w = None
+    if weights is not None:
+        _check_dev("weights", weights, dev)
+        wt = _elem_code("weights", weights)
+        if weights.numel() != nnz:
+            raise ValueError("weights must have nnz entries")
+        t_w = torch.empty_like(weights)
+    t_rows = torch.empty_like(cols)
+    t_cols = torch.empty_like(rows)
+    need = transpose_workspace_bytes(nnz, rows.dtype, None if weights is None else weights.dtype)
+    if workspace is None:
+        workspace = torch.empty((max(need, 1),), dtype=torch.uint8, device=dev)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("workspace too small: need %d bytes" % need)
+    lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
+    if nnz > 0:
+        _lib.lib().cuembed_transpose(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt, _ptr(t_rows),
+                                     _ptr(t_cols), _ptr(t_w), _ptr(workspace), ctypes.byref(lwork),
+                                     _stream(rows))
+    return t_rows, t_cols, t_w
+
+
+def compressed_grad_workspace_bytes(nnz, index_dtype):
+    lwork = ctypes.c_size_t(0)
+    _lib.lib().cuembed_compute_compressed_grad_indices(None, nnz, _INDEX[index_dtype], None, None,
+                                                       ctypes.byref(lwork), None)
+    return lwork.value
+
+
+def compute_compressed_grad_indices(indices, workspace=None):
+    """[4,4,7,8,8,8,18] -> [0,0,1,2,2,2,3] for index-sorted lookups."""
+    _check_dev("indices", indices)
+    it = _index_code("indices", indices)
+    nnz = indices.numel()
+    out = torch.empty_like(indices)
+    need = compressed_grad_workspace_bytes(nnz, indices.dtype)
+    if workspace is None:
+        workspace = torch.empty((max(need, 1),), dtype=torch.uint8, device=indices.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("workspace too small: need %d bytes" % need)
+    lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
+    if nnz > 0:
+        _lib.lib().cuembed_compute_compressed_grad_indices(_ptr(indices), nnz, it, _ptr(out),
+                                                           _ptr(workspace), ctypes.byref(lwork),
+                                                           _stream(indices))
+    return out
+
+
+def extract_row_ids_from_fixed(batch_size, num_hots, dtype=torch.int32, device="cuda"):
+    out = torch.empty((batch_size * num_hots,), dtype=dtype, device=device)
+    _check_dev("row_ids", out)
+    _lib.lib().cuembed_extract_row_ids_from_fixed(batch_size, num_hots, _INDEX[dtype], _ptr(out), _stream(out))
+    return out
+
+
+def extract_row_ids_from_csr(offsets, nnz=None, dtype=None, batch_size=None):
+    """row_ids[i] = b for i in [offsets[b], offsets[b+1]).  nnz=None reads offsets[-1] (host sync)."""
+    _check_dev("offsets", offsets)
+    ot = _index_code("offsets", offsets)
+    if batch_size is None:
+        batch_size = offsets.numel() - 1
+    if nnz is None:
+        nnz = int(offsets[batch_size].item())
+    dtype = offsets.dtype if dtype is None else dtype
+    out = torch.empty((nnz,), dtype=dtype, device=offsets.device)
+    if batch_size > 0 and nnz > 0:
+        _lib.lib().cuembed_extract_row_ids_from_csr(_ptr(offsets), ot, batch_size, _INDEX[dtype],
+                                                    _ptr(out), _stream(offsets))
+    return out
+
+
+def extract_row_ids_for_concat(nnz, dtype=torch.int32, device="cuda"):
+    out = torch.empty((nnz,), dtype=dtype, device=device)
+    _check_dev("row_ids", out)
+    _lib.lib().cuembed_extract_row_ids_for_concat(nnz, _INDEX[dtype], _ptr(out), _stream(out))
+    return out
+
+
+# The reference's C++ names, for code that reads like the reference.
+EmbeddingForward = embedding_forward
+EmbeddingBackward = embedding_backward
+Transpose = transpose
+ComputeCompressedGradIndices = compute_compressed_grad_indices
+ExtractRowIdsFromFixed = extract_row_ids_from_fixed
+ExtractRowIdsFromCSR = extract_row_ids_from_csr
+ExtractRowIdsForConcat = extract_row_ids_for_concat

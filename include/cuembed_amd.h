@@ -1,0 +1,191 @@
+/* ============================================================================
+ * cuembed_amd.h -- C ABI of the MI355X-native embedding-lookup library.
+ *
+ * This is the drop-in boundary for foreign-function bindings (ctypes, cgo, JNI,
+ * a torch extension ...).  Every entry point is an explicit instantiation of one
+ * of the header-only C++ templates in cuembed_amd/csrc/cuembed/include/, which in
+ * turn mirror the reference's host API one to one:
+ *
+ *   cuembed_embedding_forward_*              cuembed::EmbeddingForward
+ *        reference: cuembed/include/embedding_lookup.cuh:245-308
+ *        (instantiation list: utils/src/embedding_gpu_forward.cu:69-76,
+ *         int64 offsets: examples/pytorch/cuembed_embedding.cu:39-49)
+ *   cuembed_embedding_backward_*             cuembed::EmbeddingBackward
+ *        reference: cuembed/include/embedding_lookup.cuh:423-483
+ *        (instantiations: utils/src/embedding_gpu_backward.cu:84-87)
+ *   cuembed_transpose_*                      cuembed::Transpose
+ *        reference: cuembed/include/index_transforms.cuh:224-250
+ *        (instantiations: utils/src/embedding_gpu_transpose.cu:95-98)
+ *   cuembed_compute_compressed_grad_indices_* cuembed::ComputeCompressedGradIndices
+ *        reference: cuembed/include/index_transforms.cuh:278-323
+ *   cuembed_extract_row_ids_from_fixed_*     cuembed::ExtractRowIdsFromFixed
+ *        reference: cuembed/include/index_transforms.cuh:45-55
+ *   cuembed_extract_row_ids_from_csr_*       cuembed::ExtractRowIdsFromCSR
+ *        reference: cuembed/include/index_transforms.cuh:66-74
+ *   cuembed_extract_row_ids_for_concat_*     cuembed::ExtractRowIdsForConcat
+ *        reference: cuembed/include/index_transforms.cuh:85-93
+ *
+ * Conventions (identical to the reference's):
+ *   - all data pointers are DEVICE pointers owned by the caller; the library
+ *     allocates nothing and keeps no state between calls;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) and returns immediately;
+ *   - functions return void; violating the argument contract prints
+ *     "Check failed: ..." on stderr and aborts the process;
+ *   - fp16 data is IEEE binary16 (`__half`), passed as void pointers here;
+ *   - Transpose / ComputeCompressedGradIndices are two-phase: call with
+ *     work == NULL to receive the scratch size in *lwork, then again with a
+ *     scratch buffer of at least that size.
+ *
+ * Suffix grammar:  _{f32|f16}  element type of table / gradient / weights
+ *                  _{i32|i64}  lookup-index and sample-id type
+ *                  _{o32|o64}  CSR offset type
+ * ==========================================================================*/
+#ifndef CUEMBED_AMD_H_
+#define CUEMBED_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CombineMode values (reference: embedding_lookup_types.cuh:29). */
+enum { CUEMBED_SUM = 0, CUEMBED_MEAN = 1, CUEMBED_CONCAT = 2 };
+/* type codes for the generic (runtime-dispatched) entry points */
+enum { CUEMBED_F32 = 0, CUEMBED_F16 = 1 };
+enum { CUEMBED_I32 = 0, CUEMBED_I64 = 1 };
+
+typedef void* cuembed_stream_t; /* hipStream_t */
+
+/* ---- forward ------------------------------------------------------------ */
+/* fixed hotness: offsets == NULL, num_hots > 0; CSR: offsets[batch_size + 1],
+ * num_hots == 0.  weights may be NULL.  ret: [batch x width] for sum/mean,
+ * [batch x num_hots x width] for concat (fixed hotness, unweighted only).
+ * fp16_math != 0 accumulates an fp16 table in fp16 (ignored for fp32). */
+#define CUEMBED_DECLARE_FORWARD(SUFFIX, ELEM, INDEX, OFFSET)                           \
+  void cuembed_embedding_forward_##SUFFIX(                                             \
+      const ELEM* params, int embed_width, const INDEX* indices, const OFFSET* offsets, \
+      const ELEM* weights, int batch_size, int num_hots, int mode, int fp16_math,      \
+      ELEM* ret, cuembed_stream_t stream);
+CUEMBED_DECLARE_FORWARD(f32_i32_o32, float, int32_t, int32_t)
+CUEMBED_DECLARE_FORWARD(f32_i32_o64, float, int32_t, int64_t)
+CUEMBED_DECLARE_FORWARD(f32_i64_o32, float, int64_t, int32_t)
+CUEMBED_DECLARE_FORWARD(f32_i64_o64, float, int64_t, int64_t)
+CUEMBED_DECLARE_FORWARD(f16_i32_o32, void, int32_t, int32_t)
+CUEMBED_DECLARE_FORWARD(f16_i32_o64, void, int32_t, int64_t)
+CUEMBED_DECLARE_FORWARD(f16_i64_o32, void, int64_t, int32_t)
+CUEMBED_DECLARE_FORWARD(f16_i64_o64, void, int64_t, int64_t)
+#undef CUEMBED_DECLARE_FORWARD
+
+/* ---- backward ----------------------------------------------------------- */
+/* COO lookups sorted by index (output of transpose).  Full gradient:
+ * transpose_remapped_indices == NULL, grad_embedding has num_grad_embedding_rows
+ * = table rows.  Compressed: remapped indices given, grad_embedding has
+ * num_unique rows and inverse_mapping[num_unique] is written.  The gradient
+ * buffer must be zero before the scatter: skip_grad_init != 0 means the caller
+ * already zeroed it, otherwise the call zeroes it first. */
+#define CUEMBED_DECLARE_BACKWARD(SUFFIX, ELEM, INDEX)                                     \
+  void cuembed_embedding_backward_##SUFFIX(                                               \
+      const ELEM* grad_y, int embed_width, int num_grad_embedding_rows, int nnz,          \
+      const INDEX* transpose_indices, const INDEX* transpose_sample_ids,                  \
+      const INDEX* transpose_remapped_indices, const ELEM* transpose_weights,             \
+      int skip_grad_init, ELEM* grad_embedding, INDEX* inverse_mapping,                   \
+      cuembed_stream_t stream);
+CUEMBED_DECLARE_BACKWARD(f32_i32, float, int32_t)
+CUEMBED_DECLARE_BACKWARD(f32_i64, float, int64_t)
+CUEMBED_DECLARE_BACKWARD(f16_i32, void, int32_t)
+CUEMBED_DECLARE_BACKWARD(f16_i64, void, int64_t)
+#undef CUEMBED_DECLARE_BACKWARD
+
+/* ---- transpose ---------------------------------------------------------- */
+/* Stable sort of (rows[i] [, weights[i]]) by key cols[i]; callers pass
+ * rows = sample ids, cols = lookup indices.  transpose_rows receives the sorted
+ * lookup indices, transpose_cols the sample ids, transpose_weights the weights
+ * (untouched when weights == NULL).  The suffix names the index type and the
+ * WEIGHT type. */
+#define CUEMBED_DECLARE_TRANSPOSE(SUFFIX, INDEX, WEIGHT)                                   \
+  void cuembed_transpose_##SUFFIX(const INDEX* rows, const INDEX* cols,                    \
+                                  const WEIGHT* weights, int nnz, INDEX* transpose_rows,   \
+                                  INDEX* transpose_cols, WEIGHT* transpose_weights,        \
+                                  char* work, size_t* lwork, cuembed_stream_t stream);
+CUEMBED_DECLARE_TRANSPOSE(i32_f32, int32_t, float)
+CUEMBED_DECLARE_TRANSPOSE(i64_f32, int64_t, float)
+CUEMBED_DECLARE_TRANSPOSE(i32_f16, int32_t, void)
+CUEMBED_DECLARE_TRANSPOSE(i64_f16, int64_t, void)
+#undef CUEMBED_DECLARE_TRANSPOSE
+
+/* ---- compressed-gradient remap ------------------------------------------ */
+#define CUEMBED_DECLARE_COMPRESS(SUFFIX, INDEX)                                           \
+  void cuembed_compute_compressed_grad_indices_##SUFFIX(                                  \
+      const INDEX* indices, int nnz, INDEX* remapped_indices, char* work, size_t* lwork,  \
+      cuembed_stream_t stream);
+CUEMBED_DECLARE_COMPRESS(i32, int32_t)
+CUEMBED_DECLARE_COMPRESS(i64, int64_t)
+#undef CUEMBED_DECLARE_COMPRESS
+
+/* ---- row-id extraction -------------------------------------------------- */
+#define CUEMBED_DECLARE_EXTRACT(SUFFIX, INDEX)                                            \
+  void cuembed_extract_row_ids_from_fixed_##SUFFIX(int batch_size, int num_hots,          \
+                                                   INDEX* row_ids, cuembed_stream_t stream); \
+  void cuembed_extract_row_ids_for_concat_##SUFFIX(int nnz, INDEX* row_ids,               \
+                                                   cuembed_stream_t stream);
+CUEMBED_DECLARE_EXTRACT(i32, int32_t)
+CUEMBED_DECLARE_EXTRACT(i64, int64_t)
+#undef CUEMBED_DECLARE_EXTRACT
+
+#define CUEMBED_DECLARE_EXTRACT_CSR(SUFFIX, INDEX, OFFSET)                                \
+  void cuembed_extract_row_ids_from_csr_##SUFFIX(const OFFSET* offsets, int batch_size,   \
+                                                 INDEX* row_ids, cuembed_stream_t stream);
+CUEMBED_DECLARE_EXTRACT_CSR(i32_o32, int32_t, int32_t)
+CUEMBED_DECLARE_EXTRACT_CSR(i32_o64, int32_t, int64_t)
+CUEMBED_DECLARE_EXTRACT_CSR(i64_o32, int64_t, int32_t)
+CUEMBED_DECLARE_EXTRACT_CSR(i64_o64, int64_t, int64_t)
+#undef CUEMBED_DECLARE_EXTRACT_CSR
+
+/* ---- generic entry points (runtime type codes; same semantics) ---------- */
+void cuembed_embedding_forward(const void* params, int elem_type, int embed_width,
+                               const void* indices, int index_type, const void* offsets,
+                               int offset_type, const void* weights, int batch_size,
+                               int num_hots, int mode, int fp16_math, void* ret,
+                               cuembed_stream_t stream);
+void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_width,
+                                int num_grad_embedding_rows, int nnz,
+                                const void* transpose_indices, const void* transpose_sample_ids,
+                                const void* transpose_remapped_indices, int index_type,
+                                const void* transpose_weights, int skip_grad_init,
+                                void* grad_embedding, void* inverse_mapping,
+                                cuembed_stream_t stream);
+void cuembed_transpose(const void* rows, const void* cols, const void* weights, int nnz,
+                       int index_type, int weight_type, void* transpose_rows,
+                       void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
+                       cuembed_stream_t stream);
+void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
+                                             void* remapped_indices, char* work, size_t* lwork,
+                                             cuembed_stream_t stream);
+void cuembed_extract_row_ids_from_fixed(int batch_size, int num_hots, int index_type,
+                                        void* row_ids, cuembed_stream_t stream);
+void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int batch_size,
+                                      int index_type, void* row_ids, cuembed_stream_t stream);
+void cuembed_extract_row_ids_for_concat(int nnz, int index_type, void* row_ids,
+                                        cuembed_stream_t stream);
+
+/* ---- introspection ------------------------------------------------------- */
+/* Launch shape the forward would use (no launch): out[0] = elements per lane,
+ * out[1] = lanes per row, out[2] = samples per workgroup, out[3] = grid size,
+ * out[4] = dynamic LDS bytes, out[5] = 1 if indices are staged in LDS. */
+void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width, int batch_size,
+                                  int num_hots, int is_csr, int is_weighted, int mode,
+                                  int* out);
+/* hipPeekAtLastError() as an int (0 = hipSuccess); launches themselves never
+ * report errors, exactly like the reference. */
+int cuembed_peek_last_error(void);
+/* "cuembed_amd <version> gfx950" */
+const char* cuembed_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CUEMBED_AMD_H_ */

@@ -1,0 +1,220 @@
+"""GPU parity: index transforms and EmbeddingBackward (HIP, through the C ABI) vs the CPU
+oracle -- bit-exact.  Shapes follow tests/test_embedding_transpose.cu, test_embedding_backward.cu
+and the test_embedding_against_cpu.cu sweep of the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ELEMS = [(np.float32, torch.float32), (np.float16, torch.float16)]
+IDXS = [(np.int32, torch.int32), (np.int64, torch.int64)]
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return None if t is None else t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ce():
+    import cuembed_amd
+    assert torch.cuda.is_available()
+    return cuembed_amd
+
+
+@pytest.fixture(scope="module")
+def kats(golden_dir):
+    with open(os.path.join(golden_dir, "reference_kats.json")) as f:
+        return json.load(f)
+
+
+# ---- row ids ------------------------------------------------------------------
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_extract_row_ids(ce, oracle, kats, idx):
+    r = kats["readme_examples"]
+    e = r["extract_fixed"]
+    assert host(ce.extract_row_ids_from_fixed(e["batch_size"], e["num_hots"], idx[1])).tolist() == e["row_ids"]
+    assert host(ce.extract_row_ids_for_concat(4, idx[1])).tolist() == r["extract_concat"]["row_ids"]
+    for off_t in (np.int32, np.int64):
+        off = np.array(r["extract_csr"]["offsets"], dtype=off_t)
+        assert host(ce.extract_row_ids_from_csr(dev(off), dtype=idx[1])).tolist() == r["extract_csr"]["row_ids"]
+    for B, H in [(1, 1), (3, 4), (1023, 26), (65536, 64), (5000, 1)]:
+        assert np.array_equal(host(ce.extract_row_ids_from_fixed(B, H, idx[1])),
+                              oracle.extract_row_ids_from_fixed(B, H, idx[0]))
+    assert np.array_equal(host(ce.extract_row_ids_for_concat(100003, idx[1])),
+                          oracle.extract_row_ids_for_concat(100003, idx[0]))
+    rng = np.random.default_rng(2)
+    for B, H in [(1, 5), (7, 0), (1023, 26), (1024, 3), (1025, 128), (70000, 9), (3000, 700)]:
+        lens = rng.integers(0, H + 1, B)
+        lens[rng.integers(0, B, max(1, B // 5))] = 0          # plenty of empty bags
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for off_t in (np.int32, np.int64):
+            got = host(ce.extract_row_ids_from_csr(dev(off.astype(off_t)), dtype=idx[1]))
+            assert np.array_equal(got, oracle.extract_row_ids_from_csr(off.astype(off_t), idx[0])), (B, H)
+
+
+# ---- transpose -----------------------------------------------------------------
+@pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_kat(ce, kats, elem, idx):
+    k = kats["transpose"]
+    for weighted in (False, True):
+        w = dev(np.array(k["weights"], dtype=elem[0])) if weighted else None
+        ti, ts, tw = ce.transpose(dev(np.array(k["sample_ids"], dtype=idx[0])),
+                                  dev(np.array(k["indices"], dtype=idx[0])), w)
+        assert host(ti).tolist() == k["transpose_indices"]
+        assert host(ts).tolist() == k["transpose_sample_ids"]
+        if weighted:
+            assert host(tw).tolist() == k["transpose_weights"]
+        else:
+            assert tw is None
+
+
+@pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_stable_with_repeats_and_remap(ce, oracle, elem, idx):
+    """Repeated indices inside a sample: the device contract is a STABLE sort (input order kept
+    inside a run), which is what a stable radix sort gives (index_transforms.cuh:95-137)."""
+    rng = np.random.default_rng(4)
+    for nnz, ncat in [(1, 5), (257, 3), (10007, 50), (300000, 1000), (300000, 3_000_000_000 if idx[0] == np.int64 else 2_000_000_000)]:
+        cols = rng.integers(0, ncat, nnz).astype(idx[0])
+        rows = rng.integers(0, 1000, nnz).astype(idx[0])
+        w = rng.uniform(0, 1, nnz).astype(elem[0])
+        for weights in (None, w):
+            ti, ts, tw = ce.transpose(dev(rows), dev(cols), dev(weights))
+            oi, os_, ow = oracle.transpose(rows, cols, weights, stable=True)
+            assert np.array_equal(host(ti), oi) and np.array_equal(host(ts), os_)
+            if weights is not None:
+                assert np.array_equal(host(tw).view(np.uint8), ow.view(np.uint8))
+        remap = ce.compute_compressed_grad_indices(ti)
+        assert np.array_equal(host(remap), oracle.compute_compressed_grad_indices(oi))
+
+
+def test_compressed_readme_example(ce, kats):
+    c = kats["readme_examples"]["compressed"]
+    for dt in (np.int32, np.int64):
+        got = host(ce.compute_compressed_grad_indices(dev(np.array(c["indices"], dtype=dt))))
+        assert got.tolist() == c["remapped"]
+
+
+def test_transpose_workspace_two_phase(ce):
+    """work == NULL returns the scratch size; an undersized buffer is refused by the host layer."""
+    n = 100000
+    need = ce.transpose_workspace_bytes(n, torch.int64, torch.float32)
+    assert need >= 2 * n * 4
+    rows = torch.arange(n, device="cuda")
+    with pytest.raises(ValueError):
+        ce.transpose(rows, rows, torch.ones(n, device="cuda"), workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+    big = torch.empty(need + 1024, dtype=torch.uint8, device="cuda")
+    ti, ts, tw = ce.transpose(rows, rows.flip(0).contiguous(), torch.ones(n, device="cuda"), workspace=big)
+    assert torch.equal(ti, rows) and torch.equal(ts, rows.flip(0))
+
+
+# ---- backward --------------------------------------------------------------------
+@pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+@pytest.mark.parametrize("compressed", [False, True], ids=["full", "compressed"])
+@pytest.mark.parametrize("skip_init", [False, True], ids=["init", "skipinit"])
+def test_backward_kat(ce, kats, elem, idx, compressed, skip_init):
+    k = kats["backward"]
+    W = k["embed_width"]
+    t_idx = dev(np.array(k["transpose_indices"], dtype=idx[0]))
+    remap = dev(np.array(k["transpose_remapped_indices"], dtype=idx[0])) if compressed else None
+    w = dev(np.array(k["transpose_weights"], dtype=elem[0]))
+    rows = k["num_unique"] if compressed else k["num_categories"]
+    pre = "compressed_grad_" if compressed else "grad_"
+    for mode in ("sum", "concat"):
+        sid = dev(np.array(k["transpose_sample_ids" + ("_concat" if mode == "concat" else "")], dtype=idx[0]))
+        gy = dev(np.array(k["grad_y_" + mode], dtype=elem[0]).reshape(-1, W))
+        for weighted in (False, True):
+            buf = torch.zeros((rows, W), dtype=elem[1], device="cuda") if skip_init else \
+                torch.full((rows, W), 77, dtype=elem[1], device="cuda")
+            grad, inv = ce.embedding_backward(gy, rows, t_idx, sid, remap, w if weighted else None,
+                                              skip_grad_init=skip_init, grad_embedding=buf)
+            assert host(grad).ravel().tolist() == k[pre + mode + ("_weighted" if weighted else "")]
+            if compressed:
+                assert host(inv).tolist() == k["inverse_mapping"]
+            else:
+                assert inv is None
+
+
+SWEEP_SHAPES = [(2, 3, 4), (4, 3, 4), (32, 1023, 26), (36, 1023, 26), (512, 3, 63), (512, 1023, 63),
+                (514, 1023, 63)]
+
+
+@pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+@pytest.mark.parametrize("shape", SWEEP_SHAPES, ids=lambda s: "w%d_b%d_h%d" % s)
+def test_pipeline_sweep_against_oracle(ce, oracle, elem, idx, shape):
+    """extract -> transpose -> (remap) -> backward, every stage bit-exact against the oracle on
+    the reference's synthetic inputs (integer grad_y in [-10,10], weights 0.5/0.25:
+    utils/src/embedding_allocation.cu:160-168, :234-237)."""
+    W, B, H = shape
+    if elem[0] == np.float16 and (W * 2) % 4:
+        pytest.skip("row bytes not a multiple of 4")
+    ncat = 20 * 1024
+    for mode, csr, weighted, compressed in [("sum", False, False, False), ("sum", True, False, False),
+                                             ("sum", False, True, False), ("sum", True, True, True),
+                                             ("sum", False, False, True), ("concat", False, False, False),
+                                             ("concat", False, False, True)]:
+        a = oracle.allocate_forward(ncat, W, B, H, alpha=0.0, is_csr=csr, elem=elem[0], index=idx[0])
+        indices, nnz = a["indices"], a["indices"].shape[0]
+        if mode == "concat":
+            o_sid = oracle.extract_row_ids_for_concat(nnz, idx[0])
+            d_sid = ce.extract_row_ids_for_concat(nnz, idx[1])
+        elif csr:
+            o_sid = oracle.extract_row_ids_from_csr(a["offsets"], idx[0])
+            d_sid = ce.extract_row_ids_from_csr(dev(a["offsets"]), nnz=nnz, dtype=idx[1])
+        else:
+            o_sid = oracle.extract_row_ids_from_fixed(B, H, idx[0])
+            d_sid = ce.extract_row_ids_from_fixed(B, H, idx[1])
+        assert np.array_equal(host(d_sid), o_sid)
+        w = a["weights"] if weighted else None
+        o_ti, o_ts, o_tw = oracle.transpose(o_sid, indices, w, stable=True)
+        d_ti, d_ts, d_tw = ce.transpose(d_sid, dev(indices), dev(w))
+        assert np.array_equal(host(d_ti), o_ti) and np.array_equal(host(d_ts), o_ts)
+        if weighted:
+            assert np.array_equal(host(d_tw), o_tw)
+        o_remap = d_remap = None
+        rows = ncat
+        if compressed:
+            o_remap = oracle.compute_compressed_grad_indices(o_ti)
+            d_remap = ce.compute_compressed_grad_indices(d_ti)
+            assert np.array_equal(host(d_remap), o_remap)
+            rows = int(o_remap[-1]) + 1 if nnz else 0
+        n_out = nnz if mode == "concat" else B
+        gy = oracle.allocate_grad_y(n_out * W, elem[0]).reshape(n_out, W)
+        o_grad, o_inv = oracle.embedding_backward(gy, W, rows, o_ti, o_ts, o_remap, o_tw)
+        d_grad, d_inv = ce.embedding_backward(dev(gy), rows, d_ti, d_ts, d_remap, d_tw)
+        assert np.array_equal(host(d_grad).view(np.uint8), o_grad.view(np.uint8)), (mode, csr, weighted, compressed)
+        if compressed:
+            assert np.array_equal(host(d_inv), o_inv)
+
+
+def test_backward_long_runs_power_law(ce, oracle):
+    """alpha = 1.15 over few categories: runs far longer than one nz-segment, so many segments
+    share a row and combine through atomics.  Data is chosen so that every partial sum is exactly
+    representable (fp32: integers/8 times 0.5|0.25; fp16: values in {-1,0,1}, runs < 2048), which
+    makes the result independent of the order in which segments arrive."""
+    W, B, H, ncat = 64, 2000, 16, 600
+    a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15)
+    sid = oracle.extract_row_ids_from_fixed(B, H)
+    ti, ts, tw = oracle.transpose(sid, a["indices"], a["weights"])
+    assert 1000 < np.bincount(ti).max() < 2048
+    ints = oracle.allocate_grad_y(B * W).reshape(B, W)
+    gy32 = (ints / 8).astype(np.float32)
+    for weights in (None, tw):
+        want, _ = oracle.embedding_backward(gy32, W, ncat, ti, ts, None, weights)
+        got, _ = ce.embedding_backward(dev(gy32), ncat, dev(ti), dev(ts), None, dev(weights))
+        assert np.array_equal(host(got), want)
+    gy16 = (np.mod(ints, 3) - 1).astype(np.float16)
+    want, _ = oracle.embedding_backward(gy16.astype(np.float32), W, ncat, ti, ts)
+    got, _ = ce.embedding_backward(dev(gy16), ncat, dev(ti), dev(ts))
+    assert np.array_equal(host(got).astype(np.float32), want)

@@ -1,0 +1,54 @@
+"""The product's synthetic-workload generator (cuembed_amd/csrc/utils) against the oracle, the
+reference-built generator and the golden vectors.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def harness():
+    from cuembed_amd import build, harness
+    build.build()
+    return harness
+
+
+def test_indices_match_golden_and_oracle(harness, oracle, golden_dir):
+    with open(os.path.join(golden_dir, "survey_digests.json")) as f:
+        d = json.load(f)
+    got = harness.generate_indices(1024, 1024, 8, alpha=1.15)
+    assert "%016x" % oracle.fnv1a64(got) == d["alpha_1.15"]["fnv_idx"]
+    got = harness.generate_indices(1024, 1024, 8, alpha=0.0)
+    assert "%016x" % oracle.fnv1a64(got) == d["alpha_0"]["fnv_idx"]
+    assert harness.generate_indices(10_000_000, 1, 64, alpha=1.15)[:8].tolist() == \
+        d["generator"]["psx_9999999_64_1.15_first8"]
+    for idx in (np.int32, np.int64):
+        for shuf in (False, True):
+            for perm in (False, True):
+                a = harness.generate_indices(5000, 300, 17, alpha=1.05, index=idx, shuffle=shuf, permute=perm)
+                b = oracle.generate_indices(5000, 300, 17, alpha=1.05, index=idx, shuffle=shuf, permute=perm)
+                assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("elem", [np.float32, np.float16])
+@pytest.mark.parametrize("csr", [False, True])
+def test_allocate_forward_matches_oracle(harness, oracle, golden_dir, elem, csr):
+    a = harness.allocate_forward(1024, 32, 1024, 8, alpha=1.15, is_csr=csr, elem=elem)
+    b = oracle.allocate_forward(1024, 32, 1024, 8, alpha=1.15, is_csr=csr, elem=elem)
+    for k in ("table", "offsets", "indices", "weights"):
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+    c = harness.allocate_forward(1024, 32, 1024, 8, alpha=1.15, is_csr=csr, elem=elem, with_table=False)
+    assert c["table"] is None
+    for k in ("offsets", "indices", "weights"):
+        assert np.array_equal(c[k].view(np.uint8), b[k].view(np.uint8)), k
+    if elem == np.float32 and not csr:
+        with open(os.path.join(golden_dir, "survey_digests.json")) as f:
+            d = json.load(f)
+        assert "%016x" % oracle.fnv1a64(a["table"]) == d["alpha_0"]["fnv_emb"]
+        assert "%016x" % oracle.fnv1a64(a["weights"]) == d["alpha_0"]["fnv_weights"]
+
+
+def test_grad_y_matches_oracle(harness, oracle):
+    for elem in (np.float32, np.float16):
+        assert np.array_equal(harness.allocate_grad_y(5000, elem), oracle.allocate_grad_y(5000, elem))
