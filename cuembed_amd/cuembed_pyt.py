@@ -1,0 +1,153 @@
+"""PyTorch op surface: the reference's `cuembed_pyt` torch library, rebuilt on PyTorch-ROCm.
+
+Same op names and schemas as examples/pytorch/cuembed_embedding.cu:169-183 (registered for the
+CUDA dispatch key, which is what HIP tensors use on ROCm) and the same Python entry point as
+examples/pytorch/cuembed_pyt.py:48-51:
+
+    from cuembed_amd.cuembed_pyt import cuemb_embedding
+    out = cuemb_embedding(weight, indices, offsets, per_sample_weights)   # like nn.EmbeddingBag(sum)
+
+The ops run the HIP kernels through the C ABI on torch's current stream.  Relative to the
+reference binding (fp32 / int64 / sum only, cuembed_embedding.cu:15-32) they also accept fp16
+tables, int32 indices/offsets and mode="mean" in the forward op.
+"""
+import torch
+
+from . import ops as _ops
+
+_lib = torch.library.Library("cuembed_pyt", "DEF")
+_lib.define("cuembed_extract_row_ids_from_csr(Tensor offsets, int nnz) ->Tensor")
+_lib.define("cuembed_transpose(Tensor rows, Tensor cols, Tensor weights) -> (Tensor, Tensor, Tensor)")
+_lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor offsets, Tensor weights,"
+            " str mode) -> Tensor")
+_lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
+            " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
+
+_FLOATS = (torch.float32, torch.float16)
+_INTS = (torch.int64, torch.int32)
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError("cuembed_pyt: " + msg)
+
+
+def _forward_impl(params, indices, offsets, weights, mode):
+    _require(params.is_cuda and indices.is_cuda and offsets.is_cuda, "tensors must be on the GPU")
+    _require(params.dtype in _FLOATS, "params must be float32 or float16")
+    _require(indices.dtype in _INTS and offsets.dtype in _INTS, "indices/offsets must be int64 or int32")
+    _require(mode in ("sum", "mean"), "mode must be 'sum' (or 'mean')")
+    if weights is not None:
+        _require(weights.dtype == params.dtype, "weights must have the dtype of params")
+        weights = weights.contiguous()
+    batch_size = offsets.numel() - 1
+    return _ops.embedding_forward(params.contiguous(), indices.contiguous(), offsets.contiguous(), weights,
+                                  batch_size=batch_size, num_hots=0, mode=mode)
+
+
+def _extract_impl(offsets, nnz):
+    _require(offsets.is_cuda, "offsets must be on the GPU")
+    _require(offsets.dtype in _INTS, "offsets must be int64 or int32")
+    # The reference passes `offsets[:-1]` and lets the kernel read one element past the slice
+    # (cuembed_pyt.py:23 / cuembed_embedding.cu:60).  Here the end of the last bag is made
+    # explicit from `nnz`, which is correct for the sliced AND the full offsets tensor.
+    closed = torch.cat([offsets.reshape(-1), torch.tensor([nnz], dtype=offsets.dtype, device=offsets.device)])
+    return _ops.extract_row_ids_from_csr(closed, nnz=nnz, dtype=offsets.dtype, batch_size=offsets.numel())
+
+
+def _transpose_impl(rows, cols, weights):
+    _require(rows.is_cuda and cols.is_cuda, "tensors must be on the GPU")
+    _require(rows.dtype in _INTS and cols.dtype == rows.dtype, "rows/cols must both be int64 or int32")
+    if weights is not None:
+        _require(weights.dtype in _FLOATS, "weights must be float32 or float16")
+        weights = weights.contiguous()
+    t_rows, t_cols, t_w = _ops.transpose(rows.contiguous(), cols.contiguous(), weights)
+    if t_w is None:  # the reference returns a 0-length float tensor (cuembed_embedding.cu:90-93)
+        t_w = torch.empty(0, dtype=torch.float32, device=rows.device)
+    return t_rows, t_cols, t_w
+
+
+def _backward_impl(y_grad, num_categories, transpose_indices, transpose_sample_ids, transpose_weights):
+    _require(y_grad.is_cuda and transpose_indices.is_cuda and transpose_sample_ids.is_cuda,
+             "tensors must be on the GPU")
+    _require(y_grad.dtype in _FLOATS, "y_grad must be float32 or float16")
+    _require(transpose_indices.dtype in _INTS and transpose_sample_ids.dtype == transpose_indices.dtype,
+             "transposed indices must be int64 or int32")
+    if transpose_weights is not None:
+        transpose_weights = transpose_weights.contiguous()
+    width = y_grad.size(1)
+    grad = torch.zeros((num_categories, width), dtype=y_grad.dtype, device=y_grad.device)
+    _ops.embedding_backward(y_grad.contiguous(), num_categories, transpose_indices.contiguous(),
+                            transpose_sample_ids.contiguous(), None, transpose_weights,
+                            skip_grad_init=True, grad_embedding=grad)
+    return grad
+
+
+_lib.impl("cuembed_embedding_forward", _forward_impl, "CUDA")
+_lib.impl("cuembed_extract_row_ids_from_csr", _extract_impl, "CUDA")
+_lib.impl("cuembed_transpose", _transpose_impl, "CUDA")
+_lib.impl("cuembed_embedding_backward", _backward_impl, "CUDA")
+
+cuembed_extract_row_ids_from_csr = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_csr
+cuembed_transpose = torch.ops.cuembed_pyt.cuembed_transpose
+cuembed_embedding_forward = torch.ops.cuembed_pyt.cuembed_embedding_forward
+cuembed_embedding_backward = torch.ops.cuembed_pyt.cuembed_embedding_backward
+
+
+def cuembed_forward(params, idx, offsets, weights):
+    return cuembed_embedding_forward(params, idx, offsets, weights, mode="sum")
+
+
+def cuembed_backward(ctx, out_grad):
+    idx, offsets, weights = ctx.saved_tensors
+    nnz = idx.size(0)
+    # equivalent of nn.EmbeddingBag(include_last_offset=True)
+    sample_ids = cuembed_extract_row_ids_from_csr(offsets[:-1], nnz)
+    transpose_indices, transpose_sample_ids, transpose_weights = cuembed_transpose(sample_ids, idx, weights)
+    if transpose_weights.numel() == 0:  # forward ran without weights
+        transpose_weights = None
+    grad_embedding = cuembed_embedding_backward(out_grad, ctx.num_categories, transpose_indices,
+                                                transpose_sample_ids, transpose_weights)
+    return grad_embedding, None, None, None  # no grad for indices, offsets or weights
+
+
+class _CuEmbEmbedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, idx, offsets, weights=None):
+        ctx.save_for_backward(idx, offsets, weights)
+        ctx.num_categories = params.size(0)
+        return cuembed_forward(params, idx, offsets, weights)
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        return cuembed_backward(ctx, out_grad)
+
+
+def cuemb_embedding(params, idx, offsets, weights=None):
+    """Sum-pooled embedding bag (offsets include the last offset).  Differentiable w.r.t. params."""
+    if not torch.is_grad_enabled() or not params.requires_grad:
+        return cuembed_forward(params, idx, offsets, weights)
+    return _CuEmbEmbedding.apply(params, idx, offsets, weights)
+
+
+# Shape functions so that torch.compile can trace through the ops without running them.
+@torch.library.register_fake("cuembed_pyt::cuembed_extract_row_ids_from_csr")
+def _(offsets, nnz):
+    return torch.empty((nnz,), device=offsets.device, dtype=offsets.dtype)
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_transpose")
+def _(rows, cols, weights=None):
+    n = 0 if weights is None else cols.shape[0]
+    return (torch.empty_like(cols), torch.empty_like(rows),
+            torch.empty((n,), device=rows.device, dtype=torch.float32 if weights is None else weights.dtype))
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_embedding_forward")
+def _(params, idx, offsets, weights=None, mode="sum"):
+    return torch.empty((offsets.shape[0] - 1, params.shape[1]), device=params.device, dtype=params.dtype)
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_embedding_backward")
+def _(y_grad, num_categories, transpose_indices, transpose_sample_ids, transpose_weights=None):
+    return torch.empty((num_categories, y_grad.shape[1]), device=y_grad.device, dtype=y_grad.dtype)

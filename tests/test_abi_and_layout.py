@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/cuembed_amd.h declares, the header compiles as plain C, the host-side argument contract
+raises before any launch, and the product never reaches into oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cuembed_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from cuembed_amd import build
+    return build.build()
+
+
+def declared_symbols():
+    pre = subprocess.run(["gcc", "-E", "-P", HEADER], check=True, stdout=subprocess.PIPE, text=True).stdout
+    names = set(re.findall(r"\b(cuembed_[a-z0-9_]+)\s*\(", pre))
+    names.discard("cuembed_stream_t")
+    return sorted(names)
+
+
+def test_header_is_plain_c():
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HEADER], check=True)
+
+
+def test_every_declared_symbol_is_exported(lib_path):
+    names = declared_symbols()
+    assert len(names) == 36
+    for must in ["cuembed_embedding_forward_f16_i32_o32", "cuembed_embedding_backward_f32_i64",
+                 "cuembed_transpose_i64_f32", "cuembed_compute_compressed_grad_indices_i32",
+                 "cuembed_extract_row_ids_from_csr_i64_o64", "cuembed_embedding_forward"]:
+        assert must in names
+    L = ctypes.CDLL(lib_path)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_launch_shapes_of_baseline_configs():
+    import torch
+    import cuembed_amd as ce
+    # C2: 512-byte fp16 rows -> 32 lanes x 16 B, two samples per wavefront, 8 per workgroup
+    s = ce.forward_launch_shape(torch.float16, torch.int32, 256, 65536, 64)
+    assert s == dict(elems_per_lane=8, lanes_per_row=32, samples_per_block=8, grid=8192,
+                     lds_bytes=8 * 64 * 4, staged=True)
+    # C1: 128-byte fp32 rows -> 8 lanes, 32 samples per workgroup
+    s = ce.forward_launch_shape(torch.float32, torch.int32, 32, 1024, 8)
+    assert (s["elems_per_lane"], s["lanes_per_row"], s["samples_per_block"], s["grid"]) == (4, 8, 32, 32)
+    # C3: CSR never stages
+    s = ce.forward_launch_shape(torch.float32, torch.int32, 128, 65536, 0, is_csr=True, is_weighted=True)
+    assert not s["staged"] and s["lds_bytes"] == 0 and s["lanes_per_row"] == 32
+    # odd widths fall back to 8- and 4-byte lanes
+    assert ce.forward_launch_shape(torch.float32, torch.int32, 514, 8, 4)["elems_per_lane"] == 2
+    assert ce.forward_launch_shape(torch.float16, torch.int32, 514, 8, 4)["elems_per_lane"] == 2
+    assert ce.forward_launch_shape(torch.float32, torch.int32, 3, 8, 4)["elems_per_lane"] == 1
+
+
+def test_host_layer_refuses_cpu_tensors_and_bad_contracts():
+    import torch
+    import cuembed_amd as ce
+    t = torch.zeros(4, 4)
+    i = torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ce.embedding_forward(t, i, num_hots=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ce.transpose(i, i)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ce.embedding_backward(t, 4, i, i)
+    with pytest.raises(ValueError):
+        ce.embedding_forward(t, i, num_hots=2, mode="max")
+
+
+def test_abort_on_contract_violation_in_c_abi(lib_path):
+    """The C ABI keeps the reference's behaviour (CUEMBED_ASSERT, embedding_lookup.cuh:151-158):
+    message on stderr + abort.  Checked in a child process; no GPU work is launched because the
+    argument check precedes everything."""
+    code = (
+        "import ctypes,sys\n"
+        "L=ctypes.CDLL(%r)\n"
+        "L.cuembed_embedding_forward(None,0,4,None,0,None,0,None,2,0,0,0,None,None)\n" % lib_path)
+    r = subprocess.run(["python3", "-c", code], stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0
+    assert "Check failed" in r.stderr and "num_hots" in r.stderr
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "cuembed_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "build" in dirpath or os.sep + "lib" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
+                with open(os.path.join(dirpath, f), errors="ignore") as fh:
+                    txt = fh.read()
+                if re.search(r"\boracle\b", txt):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
