@@ -1,0 +1,95 @@
+"""world_size-2 test of the batch-shard data-parallel path on CPU (gloo).  The HIP kernels need
+a GPU, so the per-rank compute is the CPU oracle here; what is under test is the sharding
+arithmetic and the collectives of cuembed_amd/distributed.py:
+  concat(shard forwards) == full forward;  all-reduce(shard backward grads) == full backward grad
+(dense and sparse exchange), for fixed-hotness and CSR batches."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, csr, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuembed_amd import distributed as D
+        from oracle import oracle as O
+        ncat, W, B, H = 300, 16, 101, 7          # B not divisible by world
+        a = O.allocate_forward(ncat, W, B, H, alpha=1.15, is_csr=csr)
+        table = a["table"]
+        idx_t = torch.from_numpy(a["indices"])
+        w_t = torch.from_numpy(a["weights"])
+        if csr:
+            off, idx, w, b_loc = D.shard_csr(torch.from_numpy(a["offsets"]), idx_t, w_t, rank, world)
+            out = O.embedding_forward(table, idx.numpy(), off.numpy(), w.numpy(), num_hots=0)
+            sid = O.extract_row_ids_from_csr(off.numpy())
+        else:
+            idx, w, b_loc = D.shard_fixed(idx_t, w_t, B, H, rank, world)
+            out = O.embedding_forward(table, idx.numpy(), None, w.numpy(), batch_size=b_loc, num_hots=H)
+            sid = O.extract_row_ids_from_fixed(b_loc, H)
+        lo, hi = D.shard_bounds(B, rank, world)
+        assert b_loc == hi - lo and out.shape[0] == b_loc
+        # forward: gather the shards (test-only) and compare with the unsharded result
+        gathered = [None] * world
+        dist.all_gather_object(gathered, out)
+        full_out = O.embedding_forward(table, a["indices"], a["offsets"] if csr else None, a["weights"],
+                                       batch_size=B, num_hots=0 if csr else H)
+        assert np.array_equal(np.concatenate(gathered), full_out)
+        # backward on the shard (integer grad_y -> exact in any summation order)
+        gy_full = O.allocate_grad_y(B * W).reshape(B, W)
+        gy = gy_full[lo:hi]
+        t_idx, t_sid, t_w = O.transpose(sid, idx.numpy(), w.numpy())
+        dense, _ = O.embedding_backward(gy, W, ncat, t_idx, t_sid, None, t_w)
+        dense_t = torch.from_numpy(dense.copy())
+        D.allreduce_dense_grad(dense_t)
+        full_sid = O.extract_row_ids_from_csr(a["offsets"]) if csr else O.extract_row_ids_from_fixed(B, H)
+        f_idx, f_sid, f_w = O.transpose(full_sid, a["indices"], a["weights"])
+        want, _ = O.embedding_backward(gy_full, W, ncat, f_idx, f_sid, None, f_w)
+        assert np.array_equal(dense_t.numpy(), want)
+        # sparse exchange of compressed gradients
+        remap = O.compute_compressed_grad_indices(t_idx)
+        nu = int(remap[-1]) + 1
+        comp, inv = O.embedding_backward(gy, W, nu, t_idx, t_sid, remap, t_w)
+        ids, rows = D.allreduce_sparse_grad(torch.from_numpy(comp), torch.from_numpy(inv), ncat)
+        rebuilt = np.zeros_like(want)
+        rebuilt[ids.numpy()] = rows.numpy()
+        assert np.array_equal(rebuilt, want)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("csr", [False, True], ids=["fixed", "csr"])
+def test_batch_shard_world2(oracle, csr):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), csr, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_shard_bounds_cover_batch():
+    from cuembed_amd import distributed as D
+    for B in (1, 7, 64, 65536, 524288 + 3):
+        for G in (1, 2, 3, 4, 8):
+            spans = [D.shard_bounds(B, r, G) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
