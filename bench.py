@@ -83,7 +83,7 @@ def make_batches(harness, np, cfg, alpha, n_batches, rank, world, index_dtype):
     # (step, rank) with a distinct batch prefix is not expressible, so take one long batch.
     a = harness.allocate_forward(cfg["rows"], cfg["width"], n_batches * world * B, H, alpha=alpha,
                                  is_csr=True, elem=np.float32 if cfg["elem"] == "f32" else np.float16,
-                                 index=index_dtype, with_table=False)
+                                 index=index_dtype, with_table=False, consume_table_draws=False)
     off = a["offsets"].astype(np.int64)
     for t in range(n_batches):
         s0 = (t * world + rank) * B

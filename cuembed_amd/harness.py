@@ -43,10 +43,13 @@ def generate_indices(num_categories, batch_size, hotness, alpha=0.0, index=np.in
 
 
 def allocate_forward(num_categories, embed_width, batch_size, hotness, alpha=0.0, is_csr=False,
-                     elem=np.float32, index=np.int32, shuffle=True, permute=True, with_table=True):
+                     elem=np.float32, index=np.int32, shuffle=True, permute=True, with_table=True,
+                     consume_table_draws=True):
     """The reference's forward workload (embedding_allocation.cu:96-169).  with_table=False skips
     the (slow, host-side) table fill but still consumes its draws so that offsets and weights
-    are the reference's; use it when the table is filled on the GPU."""
+    are the reference's; use it when the table is filled on the GPU.  consume_table_draws=False
+    additionally skips those draws (fast for 10M-row tables; offsets/weights then differ from the
+    reference stream but have the same distribution)."""
     table = np.empty((num_categories, embed_width), dtype=elem) if with_table else None
     offsets = np.empty((batch_size + 1,), dtype=np.int32)
     indices = np.empty((batch_size * hotness,), dtype=index)
@@ -56,7 +59,7 @@ def allocate_forward(num_categories, embed_width, batch_size, hotness, alpha=0.0
         ctypes.c_int(hotness), ctypes.c_double(alpha), ctypes.c_int(int(is_csr)),
         ctypes.c_int(int(shuffle)), ctypes.c_int(int(permute)),
         ctypes.c_int(1 if np.dtype(elem) == np.float16 else 0),
-        ctypes.c_int(1 if np.dtype(index) == np.int64 else 0), _p(table), ctypes.c_int(1),
+        ctypes.c_int(1 if np.dtype(index) == np.int64 else 0), _p(table), ctypes.c_int(1 if consume_table_draws else 0),
         _p(offsets), _p(indices), _p(weights))
     return dict(table=table, offsets=offsets, indices=indices[:n], weights=weights[:n])
 
