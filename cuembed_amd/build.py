@@ -38,61 +38,100 @@ def _hipcc():
     return exe
 
 
-def _source_digest():
+def _digest_files(paths, extra=""):
     h = hashlib.sha256()
-    h.update(" ".join(HIPCC_FLAGS).encode())
-    for base in (CSRC, os.path.join(ROOT, "include")):
-        for dirpath, _, files in sorted(os.walk(base)):
-            for f in sorted(files):
-                if f.endswith((".hpp", ".hip", ".h", ".cuh", ".cpp")):
-                    with open(os.path.join(dirpath, f), "rb") as fh:
-                        h.update(f.encode())
-                        h.update(fh.read())
+    h.update(extra.encode())
+    for p in sorted(set(paths)):
+        if os.path.exists(p):
+            with open(p, "rb") as fh:
+                h.update(os.path.relpath(p, ROOT).encode())
+                h.update(fh.read())
+        else:
+            h.update(("missing:" + os.path.relpath(p, ROOT)).encode())
     return h.hexdigest()
 
 
+def _deps_of(obj):
+    """Dependencies recorded by the last compile of `obj` (hipcc -MD), repo files only."""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep):
+        return None
+    with open(dep) as f:
+        txt = f.read().replace("\\\n", " ")
+    files = txt.split(":", 1)[1].split() if ":" in txt else []
+    out = []
+    for x in files:  # keep repo files only, re-rooted (the tree may have moved since the compile)
+        for marker in ("/cuembed_amd/csrc/", "/include/cuembed_amd.h"):
+            k = x.find(marker)
+            if k >= 0:
+                out.append(os.path.join(ROOT, x[k + 1:]))
+                break
+    return out
+
+
 def build(force=False, verbose=False):
-    """Compile if sources changed.  Returns the path of the shared library."""
+    """Compile what changed (per translation unit, by content hash of the unit and the repo
+    headers it includes).  Returns the path of the shared library."""
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
-    stamp = os.path.join(LIB_DIR, "libcuembed_amd.stamp")
-    digest = _source_digest()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(HARNESS_PATH) and \
-            os.path.exists(stamp):
-        with open(stamp) as f:
-            if f.read().strip() == digest:
-                return LIB_PATH
     hipcc = _hipcc()
+    flags_key = " ".join(HIPCC_FLAGS).replace(ROOT, "<root>")
+
+    def unit_state(unit):
+        obj = os.path.join(OBJ_DIR, unit.replace(".hip", ".o"))
+        stamp = obj[:-2] + ".stamp"
+        deps = _deps_of(obj)
+        fresh = False
+        if not force and deps is not None and os.path.exists(obj) and os.path.exists(stamp):
+            with open(stamp) as f:
+                fresh = f.read().strip() == _digest_files(deps, flags_key)
+        return obj, stamp, fresh
 
     def compile_one(unit):
-        obj = os.path.join(OBJ_DIR, unit.replace(".hip", ".o"))
-        cmd = [hipcc] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, unit), "-o", obj]
+        obj, stamp, fresh = unit_state(unit)
+        if fresh:
+            return obj, False
+        cmd = [hipcc] + HIPCC_FLAGS + ["-MD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, unit),
+                                       "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (unit, r.stdout))
-        return obj
+        with open(stamp, "w") as f:
+            f.write(_digest_files(_deps_of(obj) or [os.path.join(CSRC, unit)], flags_key))
+        return obj, True
+
+    harness_srcs = [os.path.join(CSRC, "utils", "synthetic_inputs.cpp"),
+                    os.path.join(CSRC, "utils", "datagen.hpp")]
+    harness_stamp = os.path.join(LIB_DIR, "libcuembed_harness.stamp")
 
     def compile_harness(_):
         # host-only synthetic-workload generator (libstdc++ <random>), plain g++
+        digest = _digest_files(harness_srcs)
+        if not force and os.path.exists(HARNESS_PATH) and os.path.exists(harness_stamp):
+            with open(harness_stamp) as f:
+                if f.read().strip() == digest:
+                    return None
         cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC,
-               os.path.join(CSRC, "utils", "synthetic_inputs.cpp"), "-o", HARNESS_PATH]
+               harness_srcs[0], "-o", HARNESS_PATH]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("g++ failed for the harness library:\n" + r.stdout)
+        with open(harness_stamp, "w") as f:
+            f.write(digest)
         return None
 
     with ThreadPoolExecutor(max_workers=len(UNITS) + 1) as ex:
         harness_job = ex.submit(compile_harness, None)
-        objs = list(ex.map(compile_one, UNITS))
+        results = list(ex.map(compile_one, UNITS))
         harness_job.result()
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + r.stdout)
-    with open(stamp, "w") as f:
-        f.write(digest)
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not os.path.exists(LIB_PATH):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout)
     return LIB_PATH
 
 

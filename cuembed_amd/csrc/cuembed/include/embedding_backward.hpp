@@ -11,6 +11,7 @@ namespace detail {
 
 constexpr int kMaxSegmentLen = 128;
 constexpr int kMinSegmentLen = 8;
+constexpr int kMaxScatterStageBytes = 32 * 1024;
 //! Lanes wanted in flight on the whole chip before segments are shortened:
 //! 256 CUs x 2048 lanes x 0.4 (the reference's 40 % target,
 //! embedding_lookup.cuh:312, :365-375, evaluated for MI355X without a device query).
@@ -26,17 +27,28 @@ template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream) {
-  const int segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
+  int segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
+  // Keep the staged COO triples of one workgroup within the LDS budget: shorten the
+  // segments first (down to 32 lookups), then put fewer segments in a workgroup.
+  while (ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len, weights != nullptr) >
+         static_cast<size_t>(kMaxScatterStageBytes)) {
+    if (segment_len > 32) segment_len /= 2;
+    else if (split.rows_per_block > 1) split.rows_per_block /= 2;
+    else if (segment_len > kMinSegmentLen) segment_len /= 2;
+    else break;
+  }
   const int64_t num_segments = (nnz + segment_len - 1) / segment_len;
   const dim3 block(split.lanes_per_row, split.rows_per_block, 1);
   const dim3 grid(static_cast<unsigned>((num_segments + split.rows_per_block - 1) /
                                         split.rows_per_block),
                   1, 1);
+  const size_t lds = ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len,
+                                                      weights != nullptr);
   if (weights != nullptr)
-    SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, 0, stream>>>(
+    SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, lds, stream>>>(
         grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);
   else
-    SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, 0, stream>>>(
+    SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, lds, stream>>>(
         grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);
 }
 

@@ -126,6 +126,9 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
   if (f.staged) {
     if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kLdsStaged);
     else CUEMBED_LAUNCH_GR(false, IndexSource::kLdsStaged);
+  } else if (64 % f.split.lanes_per_row == 0) {
+    if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kWaveShuffle);
+    else CUEMBED_LAUNCH_GR(false, IndexSource::kWaveShuffle);
   } else {
     if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kGlobal);
     else CUEMBED_LAUNCH_GR(false, IndexSource::kGlobal);

@@ -35,9 +35,18 @@ constexpr int kMaxBlockThreads = 1024;
 
 //! Where a lane finds the lookup indices of its sample.
 enum class IndexSource {
-  kLdsStaged,  //!< fixed hotness, indices of the whole workgroup staged in LDS
-  kGlobal      //!< CSR offsets (or fixed hotness too large to stage)
+  kLdsStaged,    //!< fixed hotness, indices of the whole workgroup staged in LDS
+  kWaveShuffle,  //!< CSR / large hotness, lanes_per_row divides 64: register-staged, cross-lane reads
+  kGlobal        //!< CSR / large hotness, any row split: per-lookup broadcast loads
 };
+
+__device__ __forceinline__ float ShuffleElem(float v, int src, int width) {
+  return __shfl(v, src, width);
+}
+__device__ __forceinline__ _Float16 ShuffleElem(_Float16 v, int src, int width) {
+  const int bits = __shfl(static_cast<int>(__builtin_bit_cast(unsigned short, v)), src, width);
+  return __builtin_bit_cast(_Float16, static_cast<unsigned short>(bits));
+}
 
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
@@ -48,6 +57,57 @@ template <typename ElemT, int N>
 __device__ __forceinline__ void StorePack(ElemT* p, const Pack<ElemT, N>& v) {
   *reinterpret_cast<Pack<ElemT, N>*>(p) = v;
 }
+
+//! Running state of one lane while it pools the rows of its sample.
+template <typename ElemT, typename AccT, int N, bool kWeighted>
+struct RowPool {
+  using A = Arith<AccT>;
+  AccT acc[N];
+  float weight_sum;
+
+  __device__ __forceinline__ RowPool() : weight_sum(0.f) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = static_cast<AccT>(0);
+  }
+
+  __device__ __forceinline__ void Add(const Pack<ElemT, N>& row, ElemT w) {
+    if constexpr (kWeighted) {
+      const AccT wa = A::widen(w);
+      weight_sum += static_cast<float>(w);
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(A::widen(row.v[e]), wa));
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::widen(row.v[e]));
+    }
+  }
+
+  //! Pools `count` lookups, kForwardUnroll row loads in flight at a time, in order.
+  //! index_at(j) / weight_at(j) give lookup j's row id and weight.
+  template <typename IndexFn, typename WeightFn>
+  __device__ __forceinline__ void Gather(const ElemT* lane_base, const int width, const int count,
+                                         IndexFn index_at, WeightFn weight_at) {
+    int j = 0;
+    for (; j + kForwardUnroll <= count; j += kForwardUnroll) {
+      Pack<ElemT, N> row[kForwardUnroll];
+      ElemT w[kForwardUnroll];
+#pragma unroll
+      for (int u = 0; u < kForwardUnroll; ++u) {
+        const int64_t r = index_at(j + u);
+        if constexpr (kWeighted) w[u] = weight_at(j + u);
+        row[u] = LoadPack<ElemT, N>(lane_base + r * width);
+      }
+#pragma unroll
+      for (int u = 0; u < kForwardUnroll; ++u) Add(row[u], w[u]);
+    }
+    for (; j < count; ++j) {
+      const int64_t r = index_at(j);
+      ElemT w = static_cast<ElemT>(0);
+      if constexpr (kWeighted) w = weight_at(j);
+      Add(LoadPack<ElemT, N>(lane_base + r * width), w);
+    }
+  }
+};
 
 // ---------------------------------------------------------------------------
 // Sum / mean.
@@ -77,16 +137,13 @@ GatherReduceKernel(const ElemT* __restrict__ table,
   const int slot = threadIdx.y;
   const int samples_per_block = blockDim.y;
   const int64_t sample = static_cast<int64_t>(blockIdx.x) * samples_per_block + slot;
-
-  // ---- locate this sample's indices -----------------------------------
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const IndexT* lds_idx = nullptr;
-  const ElemT* lds_w = nullptr;
-  const IndexT* g_idx = nullptr;
-  const ElemT* g_w = nullptr;
+  const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
+  RowPool<ElemT, AccT, N, kWeighted> pool;
   int hot = num_hots;
 
   if constexpr (kSource == IndexSource::kLdsStaged) {
+    // ---- fixed hotness: the workgroup's indices (+weights) go through LDS once ----
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     IndexT* stage_idx = reinterpret_cast<IndexT*>(lds_raw);
     ElemT* stage_w = reinterpret_cast<ElemT*>(stage_idx + samples_per_block * num_hots);
     const int64_t first = static_cast<int64_t>(blockIdx.x) * samples_per_block * num_hots;
@@ -103,8 +160,11 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     }
     __syncthreads();
     if (sample >= batch) return;
-    lds_idx = stage_idx + slot * num_hots;
-    lds_w = stage_w + slot * num_hots;
+    const IndexT* my_idx = stage_idx + slot * num_hots;
+    const ElemT* my_w = stage_w + slot * num_hots;
+    pool.Gather(lane_base, width, hot,
+                [&](int j) { return static_cast<int64_t>(my_idx[j]); },
+                [&](int j) { return my_w[j]; });
   } else {
     if (sample >= batch) return;
     int64_t begin;
@@ -114,61 +174,40 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     } else {
       begin = sample * num_hots;
     }
-    g_idx = indices + begin;
-    g_w = weights + begin;
-  }
-
-  auto index_at = [&](int j) -> int64_t {
-    if constexpr (kSource == IndexSource::kLdsStaged) return static_cast<int64_t>(lds_idx[j]);
-    else return static_cast<int64_t>(g_idx[j]);
-  };
-  auto weight_at = [&](int j) -> ElemT {
-    if constexpr (kSource == IndexSource::kLdsStaged) return lds_w[j];
-    else return g_w[j];
-  };
-
-  // ---- gather + reduce --------------------------------------------------
-  const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
-  AccT acc[N];
-#pragma unroll
-  for (int e = 0; e < N; ++e) acc[e] = static_cast<AccT>(0);
-  float weight_sum = 0.f;
-
-  int j = 0;
-  for (; j + kForwardUnroll <= hot; j += kForwardUnroll) {
-    Pack<ElemT, N> row[kForwardUnroll];
-    ElemT w[kForwardUnroll];
-#pragma unroll
-    for (int u = 0; u < kForwardUnroll; ++u) {
-      const int64_t r = index_at(j + u);
-      if constexpr (kWeighted) w[u] = weight_at(j + u);
-      row[u] = LoadPack<ElemT, N>(lane_base + r * width);
-    }
-#pragma unroll
-    for (int u = 0; u < kForwardUnroll; ++u) {
-      if constexpr (kWeighted) {
-        const AccT wa = A::widen(w[u]);
-        weight_sum += static_cast<float>(w[u]);
-#pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(A::widen(row[u].v[e]), wa));
-      } else {
-#pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::widen(row[u].v[e]));
+    const IndexT* my_idx = indices + begin;
+    const ElemT* my_w = weights + begin;
+    if constexpr (kSource == IndexSource::kWaveShuffle) {
+      // ---- lanes_per_row divides 64: the lanes of a sample are consecutive lanes of ONE
+      // wavefront.  They fetch lanes_per_row indices (+weights) with one coalesced load
+      // and hand them to each other with cross-lane reads (ds_bpermute: no LDS storage,
+      // no barrier); the next chunk is fetched while the current one is being pooled.
+      const int group = blockDim.x;
+      IndexT cur_i = static_cast<IndexT>(0);
+      ElemT cur_w = static_cast<ElemT>(0);
+      if (lane_x < hot) {
+        cur_i = my_idx[lane_x];
+        if constexpr (kWeighted) cur_w = my_w[lane_x];
       }
-    }
-  }
-  for (; j < hot; ++j) {
-    const int64_t r = index_at(j);
-    const Pack<ElemT, N> row = LoadPack<ElemT, N>(lane_base + r * width);
-    if constexpr (kWeighted) {
-      const ElemT w = weight_at(j);
-      const AccT wa = A::widen(w);
-      weight_sum += static_cast<float>(w);
-#pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(A::widen(row.v[e]), wa));
+      for (int c = 0; c < hot; c += group) {
+        IndexT next_i = static_cast<IndexT>(0);
+        ElemT next_w = static_cast<ElemT>(0);
+        if (c + group + lane_x < hot) {
+          next_i = my_idx[c + group + lane_x];
+          if constexpr (kWeighted) next_w = my_w[c + group + lane_x];
+        }
+        const int n = (hot - c < group) ? hot - c : group;
+        pool.Gather(lane_base, width, n,
+                    [&](int j) { return static_cast<int64_t>(__shfl(cur_i, j, group)); },
+                    [&](int j) { return ShuffleElem(cur_w, j, group); });
+        cur_i = next_i;
+        cur_w = next_w;
+      }
     } else {
-#pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::widen(row.v[e]));
+      // ---- any row split: every lane reads its sample's index straight from global
+      // memory (one address per sample: a broadcast load that mostly hits L1).
+      pool.Gather(lane_base, width, hot,
+                  [&](int j) { return static_cast<int64_t>(my_idx[j]); },
+                  [&](int j) { return my_w[j]; });
     }
   }
 
@@ -176,15 +215,16 @@ GatherReduceKernel(const ElemT* __restrict__ table,
   if (is_mean) {
     // Reference combiner (embedding_lookup_ops.cuh:273-285): scale by the
     // reciprocal of the accumulated weight; zeros when that is 0.
+    float weight_sum = pool.weight_sum;
     if constexpr (!kWeighted) weight_sum = static_cast<float>(hot);
     const float inv = (weight_sum == 0.f) ? 0.f : 1.0f / weight_sum;
     const AccT scale = static_cast<AccT>(inv);
 #pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = A::mul(acc[e], scale);
+    for (int e = 0; e < N; ++e) pool.acc[e] = A::mul(pool.acc[e], scale);
   }
   Pack<ElemT, N> result;
 #pragma unroll
-  for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(acc[e]);
+  for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
   StorePack<ElemT, N>(out + sample * width + static_cast<int64_t>(lane_x) * N, result);
 }
 

@@ -27,7 +27,6 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
-#include "cuembed/include/embedding_lookup.hpp"
 #include "cuembed/include/index_kernels.hpp"
 
 namespace cuembed {

@@ -54,7 +54,27 @@ __device__ __forceinline__ void FlushStore(GradT* dst, const float (&acc)[N]) {
   StorePack<GradT, N>(dst, p);
 }
 
+//! LDS needed by SegmentedScatterAddKernel for `segments_per_block` segments of
+//! `segment_len` lookups: row ids for [first - 1, last + 1] (two sentinels),
+//! sample ids, and weights when weighted.
+template <typename GradT, typename IndexT>
+__host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int segment_len,
+                                                    bool weighted) {
+  const size_t n = static_cast<size_t>(segments_per_block) * segment_len;
+  size_t bytes = (n + 2) * sizeof(IndexT) + n * sizeof(IndexT);
+  bytes = (bytes + 15) / 16 * 16;
+  if (weighted) bytes += n * sizeof(GradT);
+  return (bytes + 15) / 16 * 16;
+}
+
 //! block = (lanes_per_row, segments_per_block); grid = ceil(num_segments / segments_per_block)
+//! dynamic LDS = ScatterStageBytes(...).
+//!
+//! The workgroup's segments are consecutive, so their COO triples form ONE
+//! contiguous range of the sorted arrays: it is copied into LDS with coalesced
+//! loads once, and the walk then reads ids from LDS -- only the grad_y row
+//! gathers remain on the global-memory critical path (one latency per batch of
+//! kBackwardUnroll lookups instead of two).
 template <typename GradT, typename IndexT, int N, bool kWeighted>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
@@ -66,15 +86,45 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int segment_len,
                           GradT* __restrict__ grad_out) {
   using A = Arith<float>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane_x = threadIdx.x;
-  const int64_t segment = static_cast<int64_t>(blockIdx.x) * blockDim.y + threadIdx.y;
-  const int64_t begin = segment * segment_len;
+  const int segments_per_block = blockDim.y;
+  const int block_len = segments_per_block * segment_len;
+  const int64_t block_begin = static_cast<int64_t>(blockIdx.x) * block_len;
+
+  // ---- stage rows[block_begin-1 .. block_begin+block_len], sample ids, weights ----
+  IndexT* st_rows = reinterpret_cast<IndexT*>(lds_raw);            // [block_len + 2], index 0 = element before
+  IndexT* st_sids = st_rows + block_len + 2;                       // [block_len]
+  GradT* st_w = reinterpret_cast<GradT*>(
+      lds_raw + (((static_cast<size_t>(block_len) * 2 + 2) * sizeof(IndexT) + 15) / 16 * 16));
+  {
+    const int tid = threadIdx.y * blockDim.x + lane_x;
+    const int nthreads = blockDim.x * blockDim.y;
+    for (int k = tid; k < block_len + 2; k += nthreads) {
+      const int64_t g = block_begin - 1 + k;
+      st_rows[k] = (g >= 0 && g < nnz) ? rows[g] : static_cast<IndexT>(-1);
+    }
+    for (int k = tid; k < block_len; k += nthreads) {
+      const int64_t g = block_begin + k;
+      if (g < nnz) {
+        st_sids[k] = sample_ids[g];
+        if constexpr (kWeighted) st_w[k] = weights[g];
+      }
+    }
+  }
+  __syncthreads();
+
+  const int seg_off = threadIdx.y * segment_len;  // offset of this segment inside the block
+  const int64_t begin = block_begin + seg_off;
   if (begin >= nnz) return;
-  const int64_t end = (begin + segment_len < nnz) ? begin + segment_len : nnz;
+  const int count = static_cast<int>((begin + segment_len < nnz) ? segment_len : nnz - begin);
+  const IndexT* my_rows = st_rows + 1 + seg_off;   // my_rows[-1] = lookup before the segment
+  const IndexT* my_sids = st_sids + seg_off;
+  const GradT* my_w = st_w + seg_off;
 
   // A run is "shared" when it also has lookups in a neighbouring segment.
-  bool run_shared = begin > 0 && rows[begin - 1] == rows[begin];
-  const bool tail_shared = end < nnz && rows[end] == rows[end - 1];
+  bool run_shared = my_rows[-1] == my_rows[0];                    // sentinel -1 never matches
+  const bool tail_shared = my_rows[count] == my_rows[count - 1];  // sentinel past the end of nnz
 
   const GradT* lane_src = grad_y + static_cast<int64_t>(lane_x) * N;
   GradT* lane_dst = grad_out + static_cast<int64_t>(lane_x) * N;
@@ -92,18 +142,17 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     run_shared = false;
   };
 
-  int64_t i = begin;
-  int64_t row_cur = static_cast<int64_t>(rows[i]);
-  for (; i + kBackwardUnroll <= end; i += kBackwardUnroll) {
+  int i = 0;
+  int64_t row_cur = static_cast<int64_t>(my_rows[0]);
+  for (; i + kBackwardUnroll <= count; i += kBackwardUnroll) {
     Pack<GradT, N> g[kBackwardUnroll];
     GradT w[kBackwardUnroll];
     int64_t row_next[kBackwardUnroll];
 #pragma unroll
     for (int u = 0; u < kBackwardUnroll; ++u) {
-      const int64_t sid = static_cast<int64_t>(sample_ids[i + u]);
-      if constexpr (kWeighted) w[u] = weights[i + u];
-      // row id of the FOLLOWING lookup (clamped at the end of the array)
-      row_next[u] = (i + u + 1 < nnz) ? static_cast<int64_t>(rows[i + u + 1]) : -1;
+      const int64_t sid = static_cast<int64_t>(my_sids[i + u]);
+      if constexpr (kWeighted) w[u] = my_w[i + u];
+      row_next[u] = static_cast<int64_t>(my_rows[i + u + 1]);
       g[u] = LoadPack<GradT, N>(lane_src + sid * width);
     }
 #pragma unroll
@@ -117,24 +166,24 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 #pragma unroll
         for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g[u].v[e]));
       }
-      const bool last = (i + u + 1 == end);
+      const bool last = (i + u + 1 == count);
       if (last || row_next[u] != row_cur) end_of_run(row_cur, last);
       row_cur = row_next[u];
     }
   }
-  for (; i < end; ++i) {
-    const int64_t sid = static_cast<int64_t>(sample_ids[i]);
+  for (; i < count; ++i) {
+    const int64_t sid = static_cast<int64_t>(my_sids[i]);
     const Pack<GradT, N> g = LoadPack<GradT, N>(lane_src + sid * width);
-    const int64_t row_next = (i + 1 < nnz) ? static_cast<int64_t>(rows[i + 1]) : -1;
+    const int64_t row_next = static_cast<int64_t>(my_rows[i + 1]);
     if constexpr (kWeighted) {
-      const float wf = static_cast<float>(weights[i]);
+      const float wf = static_cast<float>(my_w[i]);
 #pragma unroll
       for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(g.v[e]), wf));
     } else {
 #pragma unroll
       for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g.v[e]));
     }
-    const bool last = (i + 1 == end);
+    const bool last = (i + 1 == count);
     if (last || row_next != row_cur) end_of_run(row_cur, last);
     row_cur = row_next;
   }
