@@ -11,7 +11,7 @@ namespace detail {
 
 constexpr int kMaxSegmentLen = 128;
 constexpr int kMinSegmentLen = 8;
-constexpr int kMaxScatterStageBytes = 32 * 1024;
+constexpr int kMaxScatterStageBytes = 48 * 1024;
 //! Lanes wanted in flight on the whole chip before segments are shortened:
 //! 256 CUs x 2048 lanes x 0.4 (the reference's 40 % target,
 //! embedding_lookup.cuh:312, :365-375, evaluated for MI355X without a device query).
@@ -19,6 +19,10 @@ constexpr int64_t kBackwardTargetLanes = static_cast<int64_t>(256) * 2048 * 4 / 
 
 inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
   int len = kMaxSegmentLen;
+  if (const char* env = std::getenv("CUEMBED_BWD_SEGMENT_LEN")) {  // tuning knob
+    const int v = std::atoi(env);
+    if (v >= kMinSegmentLen && v <= 4096) return v;
+  }
   while (len > kMinSegmentLen && (nnz / len) * lanes_per_row < kBackwardTargetLanes) len /= 2;
   return len;
 }
@@ -30,7 +34,8 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
   int segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
   // Keep the staged COO triples of one workgroup within the LDS budget: shorten the
   // segments first (down to 32 lookups), then put fewer segments in a workgroup.
-  while (ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len, weights != nullptr) >
+  while (ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len, split.lanes_per_row, N,
+                                          weights != nullptr) >
          static_cast<size_t>(kMaxScatterStageBytes)) {
     if (segment_len > 32) segment_len /= 2;
     else if (split.rows_per_block > 1) split.rows_per_block /= 2;
@@ -43,7 +48,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                                         split.rows_per_block),
                   1, 1);
   const size_t lds = ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len,
-                                                      weights != nullptr);
+                                                      split.lanes_per_row, N, weights != nullptr);
   if (weights != nullptr)
     SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, lds, stream>>>(
         grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);

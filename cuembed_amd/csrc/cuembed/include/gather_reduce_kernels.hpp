@@ -31,6 +31,7 @@ namespace cuembed {
 namespace detail {
 
 constexpr int kForwardUnroll = 8;
+constexpr bool kForwardPipelined = false;
 constexpr int kMaxBlockThreads = 1024;
 
 //! Where a lane finds the lookup indices of its sample.
@@ -82,23 +83,67 @@ struct RowPool {
     }
   }
 
-  //! Pools `count` lookups, kForwardUnroll row loads in flight at a time, in order.
-  //! index_at(j) / weight_at(j) give lookup j's row id and weight.
-  template <typename IndexFn, typename WeightFn>
+  //! Pools `count` lookups in order.  index_at(j) / weight_at(j) give lookup j's row id
+  //! and weight.  kUnroll row loads are issued back-to-back before the first is consumed;
+  //! with kPipelined the loads of batch k+1 are issued BEFORE batch k is consumed, so a
+  //! wave always has kUnroll..2*kUnroll loads in flight instead of draining to zero
+  //! between batches.  `sched_barrier` pins "all loads first, then the adds": without it
+  //! the compiler splits a batch (e.g. 5 + 3) to save registers.
+  template <int kUnroll, bool kPipelined, typename IndexFn, typename WeightFn>
   __device__ __forceinline__ void Gather(const ElemT* lane_base, const int width, const int count,
                                          IndexFn index_at, WeightFn weight_at) {
     int j = 0;
-    for (; j + kForwardUnroll <= count; j += kForwardUnroll) {
-      Pack<ElemT, N> row[kForwardUnroll];
-      ElemT w[kForwardUnroll];
+    if constexpr (kPipelined) {
+      if (count >= 2 * kUnroll) {
+        Pack<ElemT, N> a[kUnroll], b[kUnroll];
+        ElemT wa[kUnroll], wb[kUnroll];
+        auto issue = [&](Pack<ElemT, N>(&row)[kUnroll], ElemT(&w)[kUnroll], int base) {
 #pragma unroll
-      for (int u = 0; u < kForwardUnroll; ++u) {
+          for (int u = 0; u < kUnroll; ++u) {
+            const int64_t r = index_at(base + u);
+            if constexpr (kWeighted) w[u] = weight_at(base + u);
+            row[u] = LoadPack<ElemT, N>(lane_base + r * width);
+          }
+        };
+        auto consume = [&](Pack<ElemT, N>(&row)[kUnroll], ElemT(&w)[kUnroll]) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) Add(row[u], w[u]);
+        };
+        issue(a, wa, 0);
+        // invariant at loop top: batch [j, j+kUnroll) is in flight in `a`
+        for (; j + 3 * kUnroll <= count; j += 2 * kUnroll) {
+          issue(b, wb, j + kUnroll);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(a, wa);
+          issue(a, wa, j + 2 * kUnroll);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(b, wb);
+        }
+        // here j + kUnroll <= count and `a` holds [j, j+kUnroll)
+        if (j + 2 * kUnroll <= count) {
+          issue(b, wb, j + kUnroll);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(a, wa);
+          consume(b, wb);
+          j += 2 * kUnroll;
+        } else {
+          consume(a, wa);
+          j += kUnroll;
+        }
+      }
+    }
+    for (; j + kUnroll <= count; j += kUnroll) {
+      Pack<ElemT, N> row[kUnroll];
+      ElemT w[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
         const int64_t r = index_at(j + u);
         if constexpr (kWeighted) w[u] = weight_at(j + u);
         row[u] = LoadPack<ElemT, N>(lane_base + r * width);
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < kForwardUnroll; ++u) Add(row[u], w[u]);
+      for (int u = 0; u < kUnroll; ++u) Add(row[u], w[u]);
     }
     for (; j < count; ++j) {
       const int64_t r = index_at(j);
@@ -121,8 +166,11 @@ template <typename ElemT,    // table / output element: float or _Float16
           typename OffsetT,  // CSR offset type (unused for kLdsStaged)
           int N,             // elements per lane
           bool kWeighted,
-          IndexSource kSource>
-__global__ void __launch_bounds__(kMaxBlockThreads)
+          IndexSource kSource,
+          int kUnroll = kForwardUnroll,    // row loads issued back-to-back
+          bool kPipelined = kForwardPipelined,
+          int kBlockThreads = kMaxBlockThreads>
+__global__ void __launch_bounds__(kBlockThreads)
 GatherReduceKernel(const ElemT* __restrict__ table,
                    const int width,
                    const int batch,
@@ -162,7 +210,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     if (sample >= batch) return;
     const IndexT* my_idx = stage_idx + slot * num_hots;
     const ElemT* my_w = stage_w + slot * num_hots;
-    pool.Gather(lane_base, width, hot,
+    pool.template Gather<kUnroll, kPipelined>(lane_base, width, hot,
                 [&](int j) { return static_cast<int64_t>(my_idx[j]); },
                 [&](int j) { return my_w[j]; });
   } else {
@@ -196,7 +244,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
           if constexpr (kWeighted) next_w = my_w[c + group + lane_x];
         }
         const int n = (hot - c < group) ? hot - c : group;
-        pool.Gather(lane_base, width, n,
+        pool.template Gather<kUnroll, kPipelined>(lane_base, width, n,
                     [&](int j) { return static_cast<int64_t>(__shfl(cur_i, j, group)); },
                     [&](int j) { return ShuffleElem(cur_w, j, group); });
         cur_i = next_i;
@@ -205,7 +253,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     } else {
       // ---- any row split: every lane reads its sample's index straight from global
       // memory (one address per sample: a broadcast load that mostly hits L1).
-      pool.Gather(lane_base, width, hot,
+      pool.template Gather<kUnroll, kPipelined>(lane_base, width, hot,
                   [&](int j) { return static_cast<int64_t>(my_idx[j]); },
                   [&](int j) { return my_w[j]; });
     }

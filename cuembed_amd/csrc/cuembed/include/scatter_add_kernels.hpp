@@ -7,8 +7,10 @@
 // segment in nz order, gathering grad_y[sample_id] row slices with kBackwardUnroll
 // loads in flight and keeping the running sum in fp32 registers.  When a run ends:
 //   * the run lies entirely inside this segment  -> one plain vector store;
-//   * the run continues from / into a neighbour segment -> hardware float atomics
-//     (global_atomic_add_f32 / global_atomic_pk_add_f16) into the zeroed output.
+//   * the run continues from / into a neighbour segment -> the partial is combined with its
+//     neighbours inside the workgroup through LDS; only what crosses a WORKGROUP boundary
+//     goes out as hardware float atomics (global_atomic_add_f32 / global_atomic_pk_add_f16)
+//     into the zeroed output.
 // This is the reference's scheme (embedding_lookup_kernels.cuh:175-220,
 // embedding_lookup_ops.cuh:518-564, :647-662) with three differences: shared-run
 // detection looks at the real neighbours instead of treating every first/last
@@ -55,26 +57,42 @@ __device__ __forceinline__ void FlushStore(GradT* dst, const float (&acc)[N]) {
 }
 
 //! LDS needed by SegmentedScatterAddKernel for `segments_per_block` segments of
-//! `segment_len` lookups: row ids for [first - 1, last + 1] (two sentinels),
-//! sample ids, and weights when weighted.
+//! `segment_len` lookups handled by `lanes_per_row` lanes each:
+//!   row ids for [first - 1, last + 1] (two sentinels), sample ids, weights (if any),
+//!   two fp32 partial rows per segment (head run / tail run) and their bookkeeping.
 template <typename GradT, typename IndexT>
 __host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int segment_len,
+                                                    int lanes_per_row, int elems_per_lane,
                                                     bool weighted) {
   const size_t n = static_cast<size_t>(segments_per_block) * segment_len;
   size_t bytes = (n + 2) * sizeof(IndexT) + n * sizeof(IndexT);
   bytes = (bytes + 15) / 16 * 16;
   if (weighted) bytes += n * sizeof(GradT);
+  bytes = (bytes + 15) / 16 * 16;
+  bytes += static_cast<size_t>(segments_per_block) * 2 * lanes_per_row * elems_per_lane * sizeof(float);
+  bytes += static_cast<size_t>(segments_per_block) * (2 * sizeof(int64_t) + sizeof(int));
   return (bytes + 15) / 16 * 16;
 }
+
+enum : int { kPartHead = 1, kPartTail = 2, kPartWhole = 4 };
 
 //! block = (lanes_per_row, segments_per_block); grid = ceil(num_segments / segments_per_block)
 //! dynamic LDS = ScatterStageBytes(...).
 //!
-//! The workgroup's segments are consecutive, so their COO triples form ONE
-//! contiguous range of the sorted arrays: it is copied into LDS with coalesced
-//! loads once, and the walk then reads ids from LDS -- only the grad_y row
-//! gathers remain on the global-memory critical path (one latency per batch of
-//! kBackwardUnroll lookups instead of two).
+//! 1. The workgroup's segments are consecutive, so their COO triples form ONE contiguous
+//!    range of the sorted arrays: it is copied into LDS with coalesced loads once; the walk
+//!    reads ids from LDS and only the grad_y row gathers stay on the global-memory path.
+//! 2. Each segment is walked in nz order by `lanes_per_row` lanes (kBackwardUnroll gathers in
+//!    flight, fp32 partial sums).  A run that lies inside the segment ends in a plain vector
+//!    store.  The partial sums of the segment's FIRST run (when it continues from the previous
+//!    segment) and LAST run (when it continues into the next one) are parked in LDS instead.
+//! 3. After a barrier the parked partials of neighbouring segments that belong to the same
+//!    row are chained and summed in nz order by the segment that ends the chain.  A chain that
+//!    stays inside the workgroup is written with a plain store; only a chain that crosses the
+//!    workgroup boundary uses float atomics -- at most two atomic flushes per workgroup.
+//!    Device-scope atomics to one address serialise at roughly 0.5 us each on MI355X (the
+//!    XCD L2s are not coherent, so they execute memory-side); a row with a 65,528-lookup run
+//!    would otherwise be hit by 512 of them and alone take longer than the rest of the kernel.
 template <typename GradT, typename IndexT, int N, bool kWeighted>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
@@ -88,18 +106,28 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   using A = Arith<float>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane_x = threadIdx.x;
+  const int lanes = blockDim.x;
+  const int seg = threadIdx.y;
   const int segments_per_block = blockDim.y;
   const int block_len = segments_per_block * segment_len;
   const int64_t block_begin = static_cast<int64_t>(blockIdx.x) * block_len;
 
-  // ---- stage rows[block_begin-1 .. block_begin+block_len], sample ids, weights ----
-  IndexT* st_rows = reinterpret_cast<IndexT*>(lds_raw);            // [block_len + 2], index 0 = element before
+  // ---- LDS carve-up (must match ScatterStageBytes) ----
+  IndexT* st_rows = reinterpret_cast<IndexT*>(lds_raw);            // [block_len + 2], [0] = lookup before
   IndexT* st_sids = st_rows + block_len + 2;                       // [block_len]
-  GradT* st_w = reinterpret_cast<GradT*>(
-      lds_raw + (((static_cast<size_t>(block_len) * 2 + 2) * sizeof(IndexT) + 15) / 16 * 16));
+  size_t off = ((static_cast<size_t>(block_len) * 2 + 2) * sizeof(IndexT) + 15) / 16 * 16;
+  GradT* st_w = reinterpret_cast<GradT*>(lds_raw + off);
+  if (kWeighted) off += static_cast<size_t>(block_len) * sizeof(GradT);
+  off = (off + 15) / 16 * 16;
+  float* part = reinterpret_cast<float*>(lds_raw + off);          // [seg][2][N][lanes]
+  off += static_cast<size_t>(segments_per_block) * 2 * lanes * N * sizeof(float);
+  int64_t* part_row = reinterpret_cast<int64_t*>(lds_raw + off);   // [seg][2]
+  off += static_cast<size_t>(segments_per_block) * 2 * sizeof(int64_t);
+  int* part_flags = reinterpret_cast<int*>(lds_raw + off);         // [seg]
+
   {
-    const int tid = threadIdx.y * blockDim.x + lane_x;
-    const int nthreads = blockDim.x * blockDim.y;
+    const int tid = seg * lanes + lane_x;
+    const int nthreads = lanes * segments_per_block;
     for (int k = tid; k < block_len + 2; k += nthreads) {
       const int64_t g = block_begin - 1 + k;
       st_rows[k] = (g >= 0 && g < nnz) ? rows[g] : static_cast<IndexT>(-1);
@@ -111,81 +139,133 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
         if constexpr (kWeighted) st_w[k] = weights[g];
       }
     }
+    if (lane_x == 0) part_flags[seg] = 0;
   }
   __syncthreads();
 
-  const int seg_off = threadIdx.y * segment_len;  // offset of this segment inside the block
+  const int seg_off = seg * segment_len;  // offset of this segment inside the block
   const int64_t begin = block_begin + seg_off;
-  if (begin >= nnz) return;
-  const int count = static_cast<int>((begin + segment_len < nnz) ? segment_len : nnz - begin);
-  const IndexT* my_rows = st_rows + 1 + seg_off;   // my_rows[-1] = lookup before the segment
-  const IndexT* my_sids = st_sids + seg_off;
-  const GradT* my_w = st_w + seg_off;
-
-  // A run is "shared" when it also has lookups in a neighbouring segment.
-  bool run_shared = my_rows[-1] == my_rows[0];                    // sentinel -1 never matches
-  const bool tail_shared = my_rows[count] == my_rows[count - 1];  // sentinel past the end of nnz
-
+  const bool active = begin < nnz;
   const GradT* lane_src = grad_y + static_cast<int64_t>(lane_x) * N;
   GradT* lane_dst = grad_out + static_cast<int64_t>(lane_x) * N;
+  float* my_part = part + static_cast<size_t>(seg) * 2 * N * lanes;
 
-  float acc[N];
-#pragma unroll
-  for (int e = 0; e < N; ++e) acc[e] = 0.f;
+  if (active) {
+    const int count = static_cast<int>((begin + segment_len < nnz) ? segment_len : nnz - begin);
+    const IndexT* my_rows = st_rows + 1 + seg_off;   // my_rows[-1] = lookup before the segment
+    const IndexT* my_sids = st_sids + seg_off;
+    const GradT* my_w = st_w + seg_off;
 
-  auto end_of_run = [&](int64_t row, bool is_last_of_segment) {
-    GradT* dst = lane_dst + row * width;
-    if (run_shared || (is_last_of_segment && tail_shared)) FlushAtomic<N>(dst, acc);
-    else FlushStore<GradT, N>(dst, acc);
+    // A run is "shared" when it also has lookups in a neighbouring segment.
+    bool run_shared = my_rows[-1] == my_rows[0];                    // sentinel -1 never matches
+    const bool tail_shared = my_rows[count] == my_rows[count - 1];  // sentinel past the end of nnz
+
+    float acc[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) acc[e] = 0.f;
-    run_shared = false;
-  };
 
-  int i = 0;
-  int64_t row_cur = static_cast<int64_t>(my_rows[0]);
-  for (; i + kBackwardUnroll <= count; i += kBackwardUnroll) {
-    Pack<GradT, N> g[kBackwardUnroll];
-    GradT w[kBackwardUnroll];
-    int64_t row_next[kBackwardUnroll];
+    auto end_of_run = [&](int64_t row, bool is_last_of_segment) {
+      const bool continues = is_last_of_segment && tail_shared;
+      if (run_shared || continues) {
+        // park the partial: slot 0 = run that came in from the previous segment and ends here,
+        // slot 1 = run that goes on into the next segment (kPartWhole: it also came in).
+        const int slot = continues ? 1 : 0;
 #pragma unroll
-    for (int u = 0; u < kBackwardUnroll; ++u) {
-      const int64_t sid = static_cast<int64_t>(my_sids[i + u]);
-      if constexpr (kWeighted) w[u] = my_w[i + u];
-      row_next[u] = static_cast<int64_t>(my_rows[i + u + 1]);
-      g[u] = LoadPack<GradT, N>(lane_src + sid * width);
+        for (int e = 0; e < N; ++e) my_part[(slot * N + e) * lanes + lane_x] = acc[e];
+        if (lane_x == 0) {
+          part_row[seg * 2 + slot] = row;
+          part_flags[seg] |= continues ? (kPartTail | (run_shared ? kPartWhole : 0)) : kPartHead;
+        }
+      } else {
+        FlushStore<GradT, N>(lane_dst + row * width, acc);
+      }
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = 0.f;
+      run_shared = false;
+    };
+
+    int i = 0;
+    int64_t row_cur = static_cast<int64_t>(my_rows[0]);
+    for (; i + kBackwardUnroll <= count; i += kBackwardUnroll) {
+      Pack<GradT, N> g[kBackwardUnroll];
+      GradT w[kBackwardUnroll];
+      int64_t row_next[kBackwardUnroll];
+#pragma unroll
+      for (int u = 0; u < kBackwardUnroll; ++u) {
+        const int64_t sid = static_cast<int64_t>(my_sids[i + u]);
+        if constexpr (kWeighted) w[u] = my_w[i + u];
+        row_next[u] = static_cast<int64_t>(my_rows[i + u + 1]);
+        g[u] = LoadPack<GradT, N>(lane_src + sid * width);
+      }
+#pragma unroll
+      for (int u = 0; u < kBackwardUnroll; ++u) {
+        if constexpr (kWeighted) {
+          const float wf = static_cast<float>(w[u]);
+#pragma unroll
+          for (int e = 0; e < N; ++e)
+            acc[e] = A::add(acc[e], A::mul(static_cast<float>(g[u].v[e]), wf));
+        } else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g[u].v[e]));
+        }
+        const bool last = (i + u + 1 == count);
+        if (last || row_next[u] != row_cur) end_of_run(row_cur, last);
+        row_cur = row_next[u];
+      }
     }
-#pragma unroll
-    for (int u = 0; u < kBackwardUnroll; ++u) {
+    for (; i < count; ++i) {
+      const int64_t sid = static_cast<int64_t>(my_sids[i]);
+      const Pack<GradT, N> g = LoadPack<GradT, N>(lane_src + sid * width);
+      const int64_t row_next = static_cast<int64_t>(my_rows[i + 1]);
       if constexpr (kWeighted) {
-        const float wf = static_cast<float>(w[u]);
+        const float wf = static_cast<float>(my_w[i]);
 #pragma unroll
-        for (int e = 0; e < N; ++e)
-          acc[e] = A::add(acc[e], A::mul(static_cast<float>(g[u].v[e]), wf));
+        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(g.v[e]), wf));
       } else {
 #pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g[u].v[e]));
+        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g.v[e]));
       }
-      const bool last = (i + u + 1 == count);
-      if (last || row_next[u] != row_cur) end_of_run(row_cur, last);
-      row_cur = row_next[u];
+      const bool last = (i + 1 == count);
+      if (last || row_next != row_cur) end_of_run(row_cur, last);
+      row_cur = row_next;
     }
   }
-  for (; i < count; ++i) {
-    const int64_t sid = static_cast<int64_t>(my_sids[i]);
-    const Pack<GradT, N> g = LoadPack<GradT, N>(lane_src + sid * width);
-    const int64_t row_next = static_cast<int64_t>(my_rows[i + 1]);
-    if constexpr (kWeighted) {
-      const float wf = static_cast<float>(my_w[i]);
+  __syncthreads();
+  if (!active) return;
+
+  // ---- chain the parked partials (see 3. above) ----
+  const int flags = part_flags[seg];
+  const int64_t remaining = nnz - block_begin;
+  const int last_seg = static_cast<int>(
+      remaining >= block_len ? segments_per_block - 1 : (remaining + segment_len - 1) / segment_len - 1);
+  auto add_part = [&](float (&sum)[N], int s, int slot) {
+    const float* p = part + (static_cast<size_t>(s) * 2 + slot) * N * lanes;
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(g.v[e]), wf));
-    } else {
+    for (int e = 0; e < N; ++e) sum[e] = A::add(sum[e], p[e * lanes + lane_x]);
+  };
+  if (flags & kPartHead) {
+    // a run that came in from earlier segments ends in this one
+    float sum[N];
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g.v[e]));
-    }
-    const bool last = (i + 1 == count);
-    if (last || row_next != row_cur) end_of_run(row_cur, last);
-    row_cur = row_next;
+    for (int e = 0; e < N; ++e) sum[e] = 0.f;
+    int k = seg - 1;
+    while (k >= 0 && (part_flags[k] & kPartWhole)) --k;
+    const bool from_previous_block = k < 0;
+    for (int m = from_previous_block ? 0 : k; m < seg; ++m) add_part(sum, m, 1);
+    add_part(sum, seg, 0);
+    GradT* dst = lane_dst + part_row[seg * 2 + 0] * width;
+    if (from_previous_block) FlushAtomic<N>(dst, sum);
+    else FlushStore<GradT, N>(dst, sum);
+  }
+  if ((flags & kPartTail) && seg == last_seg) {
+    // the workgroup's last run goes on into the next workgroup
+    float sum[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) sum[e] = 0.f;
+    int k = seg;
+    while (k >= 0 && (part_flags[k] & kPartWhole)) --k;
+    for (int m = k < 0 ? 0 : k; m <= seg; ++m) add_part(sum, m, 1);
+    FlushAtomic<N>(lane_dst + part_row[seg * 2 + 1] * width, sum);
   }
 }
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Times the forward-kernel variants of tools/forward_variants.hip side by side (interleaved
+rounds in one process, median/min reported) on four regimes of the C2 shape:
+L2-resident table, Infinity-Cache-resident table, power-law alpha=1.15, uniform over 10M rows."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SO = os.path.join(ROOT, "tools", "forward_variants.so")
+
+
+def build():
+    src = os.path.join(ROOT, "tools", "forward_variants.hip")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-munsafe-fp-atomics", "-I" + os.path.join(ROOT, "cuembed_amd", "csrc"),
+                               "-I" + os.path.join(ROOT, "include"), src, "-o", SO])
+
+
+def main():
+    if "--build-only" in sys.argv:
+        build()
+        return
+    import numpy as np
+    import torch
+    from cuembed_amd import harness
+    L = ctypes.CDLL(SO)
+    L.variant_name.restype = ctypes.c_char_p
+    nv = L.variant_count()
+    dev = torch.device("cuda", 0)
+    B, H, W = 65536, 64, 256
+    out = torch.empty((B, W), dtype=torch.float16, device=dev)
+    ref = torch.empty((B, W), dtype=torch.float16, device=dev)
+    nbytes = 2 * B * (H + 1) * W
+    g = torch.Generator(device=dev).manual_seed(0)
+    big = torch.empty((10_000_000, W), dtype=torch.float16, device=dev).uniform_(-1, 1)
+    regimes = []
+    for name, rows in [("L2 (2 MiB table)", 4096), ("MALL (32 MiB table)", 65536)]:
+        regimes.append((name, big[:rows], [torch.randint(0, rows, (B * H,), device=dev, dtype=torch.int32, generator=g)
+                                            for _ in range(2)]))
+    for name, alpha in [("C2 alpha=1.15", 1.15), ("alpha=0 (HBM)", 0.0)]:
+        idx = harness.generate_indices(10_000_000, 2 * B, H, alpha=alpha).reshape(2, -1)
+        regimes.append((name, big, [torch.from_numpy(np.ascontiguousarray(idx[i])).to(dev) for i in range(2)]))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    spbs = [8] if "--spb" not in sys.argv else [int(x) for x in sys.argv[sys.argv.index("--spb") + 1].split(",")]
+
+    def launch(v, table, idx, spb, o):
+        L.variant_launch(v, ctypes.c_void_p(table.data_ptr()), W, B, ctypes.c_void_p(idx.data_ptr()), H,
+                         ctypes.c_void_p(o.data_ptr()), spb, stream)
+
+    for name, table, idxs in regimes:
+        print("== %s" % name)
+        launch(0, table, idxs[0], 8, ref)
+        results = {}
+        rounds, inner = 7, 10
+        for r in range(rounds):
+            for v in range(nv):
+                lb = int(L.variant_name(v).decode().split("lb")[1])
+                for spb in spbs:
+                    if spb * (W // 8) > lb:
+                        continue
+                    if r == 0:
+                        launch(v, table, idxs[0], spb, out)
+                        torch.cuda.synchronize()
+                        assert torch.equal(out, ref), (v, spb)
+                    a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for t in range(inner):
+                        launch(v, table, idxs[t % 2], spb, out)
+                    z.record()
+                    z.synchronize()
+                    results.setdefault((v, spb), []).append(a.elapsed_time(z) / inner)
+        for (v, spb), ms in sorted(results.items()):
+            ms = sorted(ms)
+            med = ms[len(ms) // 2]
+            print("  %-22s spb=%2d  median %.4f ms (%6.0f GB/s)  min %.4f ms" %
+                  (L.variant_name(v).decode(), spb, med, nbytes / med / 1e6, ms[0]))
+
+
+if __name__ == "__main__":
+    main()
