@@ -122,7 +122,7 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
 #define CUEMBED_LAUNCH_GR(W, SRC)                                                         \
   GatherReduceKernel<ElemT, AccT, IndexT, OffsetT, N, W, SRC>                             \
       <<<grid, block, f.stage_bytes, stream>>>(table, width, batch, indices, offsets,     \
-                                               num_hots, weights, is_mean, out)
+                                               num_hots, weights, is_mean, out, 1)
   if (f.staged) {
     if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kLdsStaged);
     else CUEMBED_LAUNCH_GR(false, IndexSource::kLdsStaged);

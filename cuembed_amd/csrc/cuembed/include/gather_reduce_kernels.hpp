@@ -49,6 +49,31 @@ __device__ __forceinline__ _Float16 ShuffleElem(_Float16 v, int src, int width) 
   return __builtin_bit_cast(_Float16, static_cast<unsigned short>(bits));
 }
 
+//! XCD-aware work placement.  MI355X has 8 XCDs with private 4 MiB L2s and dispatches
+//! workgroup b to XCD b % 8 (observed, not contractual: only speed depends on it).  With
+//! `slices` > 1 a row is cut into `slices` column slices and workgroup b works on slice
+//! (b % 8) % slices of its samples, so that every L2 only ever caches 1/slices of each
+//! table row: the set of hot rows that fits an L2 grows `slices`-fold and a row that is
+//! needed by samples on different XCDs is fetched from the fabric once per slice instead
+//! of once per XCD.  The 8 / slices XCDs that share a slice split the samples.
+struct ColumnSlice {
+  int slice;      //!< which column slice of the row this workgroup owns
+  int64_t block;  //!< index of the workgroup's group of samples
+  static __device__ __forceinline__ ColumnSlice Of(unsigned block_idx, int slices) {
+    ColumnSlice c;
+    if (slices <= 1) {
+      c.slice = 0;
+      c.block = block_idx;
+    } else {
+      const int xcd = block_idx & 7;
+      const int per_slice = 8 / slices;  // XCDs sharing one slice
+      c.slice = xcd % slices;
+      c.block = static_cast<int64_t>(block_idx >> 3) * per_slice + xcd / slices;
+    }
+    return c;
+  }
+};
+
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
   return *reinterpret_cast<const Pack<ElemT, N>*>(p);
@@ -179,13 +204,17 @@ GatherReduceKernel(const ElemT* __restrict__ table,
                    const int num_hots,
                    const ElemT* __restrict__ weights,
                    const bool is_mean,
-                   ElemT* __restrict__ out) {
+                   ElemT* __restrict__ out,
+                   const int column_slices) {  // 1, 2, 4 or 8 (see ColumnSlice)
   using A = Arith<AccT>;
   const int lane_x = threadIdx.x;
   const int slot = threadIdx.y;
   const int samples_per_block = blockDim.y;
-  const int64_t sample = static_cast<int64_t>(blockIdx.x) * samples_per_block + slot;
-  const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
+  const ColumnSlice cs = ColumnSlice::Of(blockIdx.x, column_slices);
+  const int64_t block_id = cs.block;
+  const int64_t sample = block_id * samples_per_block + slot;
+  const int64_t column0 = (static_cast<int64_t>(cs.slice) * blockDim.x + lane_x) * N;
+  const ElemT* lane_base = table + column0;
   RowPool<ElemT, AccT, N, kWeighted> pool;
   int hot = num_hots;
 
@@ -194,7 +223,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     IndexT* stage_idx = reinterpret_cast<IndexT*>(lds_raw);
     ElemT* stage_w = reinterpret_cast<ElemT*>(stage_idx + samples_per_block * num_hots);
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * samples_per_block * num_hots;
+    const int64_t first = block_id * samples_per_block * num_hots;
     const int64_t remaining = static_cast<int64_t>(batch) * num_hots - first;
     const int count = static_cast<int>(
         remaining < static_cast<int64_t>(samples_per_block) * num_hots
@@ -273,7 +302,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
   Pack<ElemT, N> result;
 #pragma unroll
   for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
-  StorePack<ElemT, N>(out + sample * width + static_cast<int64_t>(lane_x) * N, result);
+  StorePack<ElemT, N>(out + sample * width + column0, result);
 }
 
 // ---------------------------------------------------------------------------

@@ -45,6 +45,8 @@ def main():
         idx = harness.generate_indices(10_000_000, 2 * B, H, alpha=alpha).reshape(2, -1)
         regimes.append((name, big, [torch.from_numpy(np.ascontiguousarray(idx[i])).to(dev) for i in range(2)]))
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    only = None if "--variants" not in sys.argv else \
+        [int(x) for x in sys.argv[sys.argv.index("--variants") + 1].split(",")]
     spbs = [8] if "--spb" not in sys.argv else [int(x) for x in sys.argv[sys.argv.index("--spb") + 1].split(",")]
 
     def launch(v, table, idx, spb, o):
@@ -58,6 +60,8 @@ def main():
         rounds, inner = 7, 10
         for r in range(rounds):
             for v in range(nv):
+                if only is not None and v not in only:
+                    continue
                 lb = int(L.variant_name(v).decode().split("lb")[1])
                 for spb in spbs:
                     if spb * (W // 8) > lb:
