@@ -42,7 +42,12 @@ def parse():
 
 
 def main():
-    a = parse()
+    run(parse())
+
+
+def run(a, table_cache=None, quiet=False):
+    """Runs one benchmark point; returns [(name, total_ms, bw_l2, bw_dram), ...].
+    table_cache: optional dict reused across calls to keep (rows, width, dtype) tables alive."""
     import numpy as np
     import torch
     import cuembed_amd as ce
@@ -60,9 +65,16 @@ def main():
         dev_fill = (a.num_categories * W > (64 << 20)) and not a.check_result
     w = harness.allocate_forward(a.num_categories, W, B, H, alpha=a.alpha, is_csr=a.csr_input, elem=elem_np,
                                  index=idx_np, with_table=not dev_fill, consume_table_draws=not dev_fill)
-    if dev_fill:
+    key = (a.num_categories, W, elem_t)
+    if dev_fill and table_cache is not None and key in table_cache:
+        table = table_cache[key]
+    elif dev_fill:
         table = torch.empty((a.num_categories, W), dtype=elem_t, device=dev)
         table.uniform_(-1, 1)
+        if table_cache is not None:
+            for k in [k for k in table_cache if k != "flush"]:
+                del table_cache[k]
+            table_cache[key] = table
     else:
         table = torch.from_numpy(w["table"]).to(dev)
     indices = torch.from_numpy(w["indices"]).to(dev)
@@ -72,7 +84,14 @@ def main():
     hots = 0 if a.csr_input else H
     out = torch.empty((B, W), dtype=elem_t, device=dev)
 
-    flush = torch.ones(256_000_000, dtype=torch.int32, device=dev) if a.clear_caches else None
+    flush = None
+    if a.clear_caches:
+        if table_cache is not None and "flush" in table_cache:
+            flush = table_cache["flush"]
+        else:
+            flush = torch.ones(256_000_000, dtype=torch.int32, device=dev)
+            if table_cache is not None:
+                table_cache["flush"] = flush
     sink = torch.zeros((), dtype=torch.int32, device=dev)
 
     def clear():
@@ -101,8 +120,9 @@ def main():
     rows = []
 
     def report(name, ms, bw_l2, bw_dram, label):
-        print("%s. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , %s"
-              % (name, a.iterations, ms, ms / a.iterations, label), flush=True)
+        if not quiet:
+            print("%s. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , %s"
+                  % (name, a.iterations, ms, ms / a.iterations, label), flush=True)
         rows.append((name.lower().split()[-1], ms, bw_l2, bw_dram))
 
     # ---- forward ------------------------------------------------------------------
@@ -188,6 +208,7 @@ def main():
                 f.write("%d,%d,%d,%g,%d,kSum,%d,%d,%d,%d,%s,%d ,%.2f ,%.4f ,%.2f,%.2f\n"
                         % (a.num_categories, B, H, a.alpha, W, a.csr_input, a.weighted_sum, a.compressed_grad,
                            a.skip_grad_init, name, a.iterations, ms, ms / a.iterations, l2, dram))
+    return rows
 
 
 if __name__ == "__main__":

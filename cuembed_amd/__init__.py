@@ -12,7 +12,8 @@ from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBack
                   ExtractRowIdsFromFixed, Transpose, compressed_grad_workspace_bytes,
                   compute_compressed_grad_indices, embedding_backward, embedding_forward,
                   extract_row_ids_for_concat, extract_row_ids_from_csr,
-                  extract_row_ids_from_fixed, forward_launch_shape, transpose,
+                  extract_row_ids_from_fixed, forward_launch_shape, get_forward_reduction_order,
+                  set_forward_reduction_order, transpose,
                   transpose_workspace_bytes)
 
 __version__ = "0.1.0"

@@ -101,6 +101,14 @@ void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width
   out[5] = f.staged ? 1 : 0;
 }
 
+void cuembed_set_forward_reduction_order(int order) {
+  CUEMBED_ASSERT(order == 0 || order == 1);
+  cuembed::SetForwardReductionOrder(static_cast<cuembed::ReductionOrder>(order));
+}
+int cuembed_get_forward_reduction_order(void) {
+  return static_cast<int>(cuembed::GetForwardReductionOrder());
+}
+
 int cuembed_peek_last_error(void) { return static_cast<int>(hipPeekAtLastError()); }
 
 const char* cuembed_version(void) { return "cuembed_amd 0.1.0 gfx950"; }

@@ -306,6 +306,118 @@ GatherReduceKernel(const ElemT* __restrict__ table,
 }
 
 // ---------------------------------------------------------------------------
+// Sum / mean for SMALL batches: one sample per workgroup, the hotness dimension split
+// over the workgroup's waves.
+//   block = (lanes_per_row, slices) with lanes_per_row * slices = 256; grid = batch.
+//   static LDS: one partial pooled row per wave.
+// With few samples the sequential kernel above leaves most of the chip idle (1024
+// samples x 32 lanes = 512 wavefronts for 1024 SIMDs) and each wave walks its whole
+// bag alone.  Here slice k of a sample pools lookups [k*chunk, (k+1)*chunk) with the
+// same batched loads; slices that share a wavefront are folded with cross-lane reads
+// (DPP/ds_bpermute via __shfl_down), the per-wave partial rows are staged in LDS and
+// the first wave adds them in slice order.  The association order differs from the
+// sequential sum, so results agree with the reference to rounding (1e-3 / 1e-2
+// relative, fp32 / fp16), not bit-for-bit: the host API only selects this kernel
+// when ReductionOrder::kAllowSplit has been requested.
+// ---------------------------------------------------------------------------
+template <typename AccT>
+__device__ __forceinline__ AccT ShuffleDownAcc(AccT v, int delta) {
+  if constexpr (sizeof(AccT) == 2) {
+    const int bits = __shfl_down(static_cast<int>(__builtin_bit_cast(unsigned short, v)), delta);
+    return __builtin_bit_cast(AccT, static_cast<unsigned short>(bits));
+  } else {
+    return __shfl_down(v, delta);
+  }
+}
+
+constexpr int kSplitBlockThreads = 256;
+
+template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N, bool kWeighted>
+__global__ void __launch_bounds__(kSplitBlockThreads)
+GatherReduceSplitKernel(const ElemT* __restrict__ table,
+                        const int width,
+                        const int batch,
+                        const IndexT* __restrict__ indices,
+                        const OffsetT* __restrict__ offsets,  // null => fixed hotness
+                        const int num_hots,
+                        const ElemT* __restrict__ weights,
+                        const bool is_mean,
+                        ElemT* __restrict__ out) {
+  using A = Arith<AccT>;
+  constexpr int kWaves = kSplitBlockThreads / 64;
+  __shared__ AccT partial[kWaves][N][64];
+  __shared__ float partial_w[kWaves];
+  const int lane_x = threadIdx.x;
+  const int lanes = blockDim.x;
+  const int slice = threadIdx.y;
+  const int slices = blockDim.y;
+  const int64_t sample = blockIdx.x;
+
+  int64_t begin;
+  int hot = num_hots;
+  if (offsets != nullptr) {
+    begin = static_cast<int64_t>(offsets[sample]);
+    hot = static_cast<int>(static_cast<int64_t>(offsets[sample + 1]) - begin);
+  } else {
+    begin = sample * num_hots;
+  }
+  const int chunk = (hot + slices - 1) / slices;
+  const int j0 = slice * chunk < hot ? slice * chunk : hot;
+  const int j1 = j0 + chunk < hot ? j0 + chunk : hot;
+  const IndexT* my_idx = indices + begin + j0;
+  const ElemT* my_w = weights + begin + j0;
+
+  RowPool<ElemT, AccT, N, kWeighted> pool;
+  pool.template Gather<kForwardUnroll, false>(
+      table + static_cast<int64_t>(lane_x) * N, width, j1 - j0,
+      [&](int j) { return static_cast<int64_t>(my_idx[j]); }, [&](int j) { return my_w[j]; });
+
+  // ---- fold the slices that live in the same wavefront (lanes < 64 only) ----
+  const int tid = slice * lanes + lane_x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  if (lanes < 64) {
+    for (int delta = 32; delta >= lanes; delta >>= 1) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) pool.acc[e] = A::add(pool.acc[e], ShuffleDownAcc(pool.acc[e], delta));
+      pool.weight_sum += __shfl_down(pool.weight_sum, delta);
+    }
+  }
+  // ---- stage one partial pooled row per wave in LDS, add them in wave order ----
+  // (lanes >= 64: a row spans whole waves; wave w then holds columns of row part w % (lanes/64))
+  const int row_waves = lanes >= 64 ? lanes / 64 : 1;   // waves that make up one full row
+  if (lanes >= 64 || lane < lanes) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) partial[wave][e][lane] = pool.acc[e];
+    if (lane == 0) partial_w[wave] = pool.weight_sum;
+  }
+  __syncthreads();
+  if (wave >= row_waves) return;
+  if (lanes < 64 && lane >= lanes) return;
+  AccT sum[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) sum[e] = partial[wave][e][lane];
+  float weight_sum = partial_w[wave];
+  for (int w = wave + row_waves; w < kWaves; w += row_waves) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) sum[e] = A::add(sum[e], partial[w][e][lane]);
+    weight_sum += partial_w[w];
+  }
+  if (is_mean) {
+    if constexpr (!kWeighted) weight_sum = static_cast<float>(hot);
+    const float inv = (weight_sum == 0.f) ? 0.f : 1.0f / weight_sum;
+    const AccT scale = static_cast<AccT>(inv);
+#pragma unroll
+    for (int e = 0; e < N; ++e) sum[e] = A::mul(sum[e], scale);
+  }
+  Pack<ElemT, N> result;
+#pragma unroll
+  for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(sum[e]);
+  const int column_lane = lanes >= 64 ? wave * 64 + lane : lane;
+  StorePack<ElemT, N>(out + sample * width + static_cast<int64_t>(column_lane) * N, result);
+}
+
+// ---------------------------------------------------------------------------
 // Concat (fixed hotness only): out[s, j, :] = table[idx[s, j], :].
 // Same block/grid shape; indices always read from global (each is used once).
 // ---------------------------------------------------------------------------

@@ -54,6 +54,18 @@ def _index_code(name, t):
     return _INDEX[t.dtype]
 
 
+def set_forward_reduction_order(order):
+    """"sequential" (default, bit-identical to the reference for every batch size) or "split"
+    (small batches may split a sample's hotness loop over wavefronts; equal up to fp rounding)."""
+    if order not in ("sequential", "split"):
+        raise ValueError("order must be 'sequential' or 'split'")
+    _lib.lib().cuembed_set_forward_reduction_order(1 if order == "split" else 0)
+
+
+def get_forward_reduction_order():
+    return "split" if _lib.lib().cuembed_get_forward_reduction_order() else "sequential"
+
+
 def forward_launch_shape(elem_dtype, index_dtype, embed_width, batch_size, num_hots, is_csr=False,
                          is_weighted=False, mode="sum"):
     """Launch shape the forward kernel would use (pure host arithmetic)."""

@@ -171,6 +171,14 @@ void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int 
 void cuembed_extract_row_ids_for_concat(int nnz, int index_type, void* row_ids,
                                         cuembed_stream_t stream);
 
+/* ---- options ------------------------------------------------------------- */
+/* cuembed::SetForwardReductionOrder / GetForwardReductionOrder (this library's addition):
+ * 0 = sequential (default; bit-identical to the reference for every batch size),
+ * 1 = small batches may split a sample's hotness loop over several wavefronts and combine
+ *     partial rows through LDS (same result up to fp rounding, much faster for small batches). */
+void cuembed_set_forward_reduction_order(int order);
+int cuembed_get_forward_reduction_order(void);
+
 /* ---- introspection ------------------------------------------------------- */
 /* Launch shape the forward would use (no launch): out[0] = elements per lane,
  * out[1] = lanes per row, out[2] = samples per workgroup, out[3] = grid size,

@@ -180,3 +180,44 @@ def test_forward_full_size_c2_properties(ce, oracle):
     sub_idx = idx[:1024 * H]
     cat = ce.embedding_forward(table_i, sub_idx, num_hots=H, mode="concat")
     assert torch.equal(cat.float().sum(1).half(), out_i[:1024])
+
+
+@pytest.mark.parametrize("elem,fp16_math,rtol", [(ELEMS[0], False, 1e-3), (ELEMS[1], False, 1e-2),
+                                                  (ELEMS[1], True, 1e-2)], ids=["f32", "f16", "f16-fp16math"])
+@pytest.mark.parametrize("W", [8, 32, 128, 256, 512, 1024])
+def test_forward_split_hotness_small_batch(ce, oracle, elem, fp16_math, rtol, W):
+    """ReductionOrder kAllowSplit: small batches split a sample's hotness loop over wavefronts
+    (LDS partial rows + cross-lane folds).  Tolerance parity (north_star: 1e-3 fp32 / 1e-2 fp16
+    relative) against the oracle, EXACT on integer-valued tables, and the default order must be
+    unaffected afterwards."""
+    rng = np.random.default_rng(W)
+    B, H = 37, 61
+    table = rng.uniform(-1, 1, (2000, W)).astype(elem[0])
+    table_i = rng.integers(-3, 4, (2000, W)).astype(elem[0])
+    idx = rng.integers(0, 2000, (B, H)).astype(np.int32)
+    w = rng.choice([0.5, 0.25], (B, H)).astype(elem[0])
+    lens = rng.integers(0, H + 1, B)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx_csr = rng.integers(0, 2000, int(off[-1])).astype(np.int32)
+    assert ce.get_forward_reduction_order() == "sequential"
+    ce.set_forward_reduction_order("split")
+    try:
+        for mode, weights in [("sum", None), ("sum", w), ("mean", None), ("mean", w)]:
+            wf = None if weights is None else weights.ravel()
+            want = oracle.embedding_forward(table, idx.ravel(), None, wf, num_hots=H, mode=mode,
+                                            fp16_math=fp16_math).astype(np.float64)
+            got = ce.embedding_forward(dev(table), dev(idx.ravel()), None, dev(wf), num_hots=H, mode=mode,
+                                       fp16_math=fp16_math).cpu().numpy().astype(np.float64)
+            scale = np.abs(want).max()
+            assert np.abs(got - want).max() <= rtol * scale, (mode, weights is not None)
+            want_i = oracle.embedding_forward(table_i, idx.ravel(), None, wf, num_hots=H, mode="sum")
+            got_i = ce.embedding_forward(dev(table_i), dev(idx.ravel()), None, dev(wf), num_hots=H, mode="sum")
+            assert (bits(got_i.cpu().numpy()) == bits(want_i)).all()
+        want = oracle.embedding_forward(table_i, idx_csr, off, None, num_hots=0)      # ragged + empty bags
+        got = ce.embedding_forward(dev(table_i), dev(idx_csr), dev(off), None, num_hots=0)
+        assert (bits(got.cpu().numpy()) == bits(want)).all()
+    finally:
+        ce.set_forward_reduction_order("sequential")
+    want = oracle.embedding_forward(table, idx.ravel(), num_hots=H, fp16_math=fp16_math)
+    got = ce.embedding_forward(dev(table), dev(idx.ravel()), num_hots=H, fp16_math=fp16_math)
+    assert (bits(got.cpu().numpy()) == bits(want)).all()
