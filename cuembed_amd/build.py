@@ -135,5 +135,29 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_header_api_test(force=False):
+    """Compiles tests/cpp/header_api_kat.hip against the header-only API (the C++ side of the
+    drop-in boundary).  Returns the path of the executable."""
+    src = os.path.join(ROOT, "tests", "cpp", "header_api_kat.hip")
+    exe = os.path.join(ROOT, "tests", "cpp", "header_api_kat")
+    stamp = exe + ".stamp"
+    deps = [src]
+    for dirpath, _, files in os.walk(os.path.join(CSRC, "cuembed", "include")):
+        deps += [os.path.join(dirpath, f) for f in files]
+    digest = _digest_files(deps)
+    if not force and os.path.exists(exe) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return exe
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-munsafe-fp-atomics", "-I" + CSRC,
+           src, "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for the header-only API test:\n" + r.stdout)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
