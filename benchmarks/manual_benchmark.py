@@ -35,6 +35,8 @@ def parse():
                           ("fp16_math", False), ("compressed_grad", True), ("skip_grad_init", True),
                           ("forward_only", False), ("enable_csv", False), ("clear_caches", True)]:
         p.add_argument("--" + name, type=str2bool, nargs="?", const=True, default=default)
+    p.add_argument("--bounded_sort", type=str2bool, nargs="?", const=True, default=False,
+                   help="tell Transpose that indices < num_categories (this library's extension)")
     p.add_argument("--device_table_fill", type=str2bool, nargs="?", const=True, default=None,
                    help="fill the table on the GPU instead of with the reference's host RNG "
                         "(default: automatically for tables > 64M elements; not with --check_result)")
@@ -156,7 +158,8 @@ def run(a, table_cache=None, quiet=False):
                 sid = ce.extract_row_ids_from_csr(offsets, nnz=nnz, dtype=idx_t)
             else:
                 sid = ce.extract_row_ids_from_fixed(B, H, idx_t, dev)
-            t_idx, t_sid, t_w = ce.transpose(sid, indices, weights, workspace=work)
+            t_idx, t_sid, t_w = ce.transpose(sid, indices, weights, workspace=work,
+                                             num_categories=a.num_categories if a.bounded_sort else None)
             remap = ce.compute_compressed_grad_indices(t_idx, workspace=work) if a.compressed_grad else None
             state.update(t_idx=t_idx, t_sid=t_sid, t_w=t_w, remap=remap)
 

@@ -46,7 +46,7 @@ def main():
                 iterations=o.iterations, alpha=float(alpha), use_int64_indices=False, check_result=False,
                 half_embedding_type=False, csr_input=False, weighted_sum=False, fp16_math=False,
                 compressed_grad=True, skip_grad_init=True, forward_only=o.forward_only, enable_csv=False,
-                clear_caches=mb.str2bool(o.clear_caches), device_table_fill=True)
+                clear_caches=mb.str2bool(o.clear_caches), device_table_fill=True, bounded_sort=False)
             rows = mb.run(a, table_cache=cache, quiet=True)
             for name, ms, l2, dram in rows:
                 f.write("%d,%d,%d,%g,%d,%s,%s,%d,%.5f,%.2f,%.2f\n" % (cats, batch, hot, alpha, width, o.order,

@@ -64,11 +64,19 @@ void cuembed_transpose(const void* rows, const void* cols, const void* weights, 
                        int index_type, int weight_type, void* transpose_rows,
                        void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
                        cuembed_stream_t stream) {
+  cuembed_transpose_bounded(rows, cols, weights, nnz, index_type, weight_type, transpose_rows,
+                            transpose_cols, transpose_weights, work, lwork, 0, stream);
+}
+
+void cuembed_transpose_bounded(const void* rows, const void* cols, const void* weights, int nnz,
+                               int index_type, int weight_type, void* transpose_rows,
+                               void* transpose_cols, void* transpose_weights, char* work,
+                               size_t* lwork, int index_bits, cuembed_stream_t stream) {
 #define TR(I, W)                                                                              \
   cuembed::Transpose<I, W>(static_cast<const I*>(rows), static_cast<const I*>(cols),          \
                            static_cast<const W*>(weights), nnz, static_cast<I*>(transpose_rows), \
                            static_cast<I*>(transpose_cols), static_cast<W*>(transpose_weights), \
-                           work, lwork, Stream(stream))
+                           work, lwork, Stream(stream), index_bits)
   switch ((index_type << 1) | weight_type) {
     case 0: TR(int32_t, float); break;
     case 1: TR(int32_t, __half); break;

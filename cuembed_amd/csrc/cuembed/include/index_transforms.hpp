@@ -96,6 +96,11 @@ void ExtractRowIdsForConcat(const int nnz, IndexT* row_ids, const hipStream_t st
  *
  * Two-phase: call with work == nullptr to get *lwork, then with a buffer of at
  * least that many bytes.
+ *
+ * Extension over the reference: `index_bits` (default: all bits of IndexT, the reference's
+ * behaviour).  A caller that knows every lookup index is < 2^index_bits -- e.g.
+ * index_bits = ceil(log2(num_categories)) -- lets the radix sort skip the always-zero high
+ * digits: 3 passes instead of 8 for int64 ids of a 10M-row table.  Results are identical.
  */
 template <typename IndexT, typename WeightT>
 void Transpose(const IndexT* rows,
@@ -107,10 +112,14 @@ void Transpose(const IndexT* rows,
                WeightT* transpose_weights,
                char* work,
                size_t* lwork,
-               const hipStream_t stream = 0) {
+               const hipStream_t stream = 0,
+               const int index_bits = static_cast<int>(sizeof(IndexT) * 8)) {
   using KeyT = typename std::make_unsigned<IndexT>::type;  // ids are non-negative
   const unsigned int begin_bit = 0;
-  const unsigned int end_bit = sizeof(IndexT) * 8;
+  const unsigned int end_bit =
+      (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
+          ? static_cast<unsigned int>(index_bits)
+          : static_cast<unsigned int>(sizeof(IndexT) * 8);
   const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
   const KeyT* keys_in = reinterpret_cast<const KeyT*>(cols);
   KeyT* keys_out = reinterpret_cast<KeyT*>(transpose_rows);

@@ -18,6 +18,9 @@ from . import ops as _ops
 _lib = torch.library.Library("cuembed_pyt", "DEF")
 _lib.define("cuembed_extract_row_ids_from_csr(Tensor offsets, int nnz) ->Tensor")
 _lib.define("cuembed_transpose(Tensor rows, Tensor cols, Tensor weights) -> (Tensor, Tensor, Tensor)")
+# This library's extension: the same transpose when the caller knows indices < num_categories.
+_lib.define("cuembed_transpose_bounded(Tensor rows, Tensor cols, Tensor weights, int num_categories)"
+            " -> (Tensor, Tensor, Tensor)")
 _lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor offsets, Tensor weights,"
             " str mode) -> Tensor")
 _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
@@ -55,13 +58,18 @@ def _extract_impl(offsets, nnz):
     return _ops.extract_row_ids_from_csr(closed, nnz=nnz, dtype=offsets.dtype, batch_size=offsets.numel())
 
 
-def _transpose_impl(rows, cols, weights):
+def _transpose_bounded_impl(rows, cols, weights, num_categories):
+    return _transpose_impl(rows, cols, weights, num_categories)
+
+
+def _transpose_impl(rows, cols, weights, num_categories=None):
     _require(rows.is_cuda and cols.is_cuda, "tensors must be on the GPU")
     _require(rows.dtype in _INTS and cols.dtype == rows.dtype, "rows/cols must both be int64 or int32")
     if weights is not None:
         _require(weights.dtype in _FLOATS, "weights must be float32 or float16")
         weights = weights.contiguous()
-    t_rows, t_cols, t_w = _ops.transpose(rows.contiguous(), cols.contiguous(), weights)
+    t_rows, t_cols, t_w = _ops.transpose(rows.contiguous(), cols.contiguous(), weights,
+                                         num_categories=num_categories)
     if t_w is None:  # the reference returns a 0-length float tensor (cuembed_embedding.cu:90-93)
         t_w = torch.empty(0, dtype=torch.float32, device=rows.device)
     return t_rows, t_cols, t_w
@@ -86,10 +94,12 @@ def _backward_impl(y_grad, num_categories, transpose_indices, transpose_sample_i
 _lib.impl("cuembed_embedding_forward", _forward_impl, "CUDA")
 _lib.impl("cuembed_extract_row_ids_from_csr", _extract_impl, "CUDA")
 _lib.impl("cuembed_transpose", _transpose_impl, "CUDA")
+_lib.impl("cuembed_transpose_bounded", _transpose_bounded_impl, "CUDA")
 _lib.impl("cuembed_embedding_backward", _backward_impl, "CUDA")
 
 cuembed_extract_row_ids_from_csr = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_csr
 cuembed_transpose = torch.ops.cuembed_pyt.cuembed_transpose
+cuembed_transpose_bounded = torch.ops.cuembed_pyt.cuembed_transpose_bounded
 cuembed_embedding_forward = torch.ops.cuembed_pyt.cuembed_embedding_forward
 cuembed_embedding_backward = torch.ops.cuembed_pyt.cuembed_embedding_backward
 
@@ -103,7 +113,8 @@ def cuembed_backward(ctx, out_grad):
     nnz = idx.size(0)
     # equivalent of nn.EmbeddingBag(include_last_offset=True)
     sample_ids = cuembed_extract_row_ids_from_csr(offsets[:-1], nnz)
-    transpose_indices, transpose_sample_ids, transpose_weights = cuembed_transpose(sample_ids, idx, weights)
+    transpose_indices, transpose_sample_ids, transpose_weights = cuembed_transpose_bounded(
+        sample_ids, idx, weights, ctx.num_categories)
     if transpose_weights.numel() == 0:  # forward ran without weights
         transpose_weights = None
     grad_embedding = cuembed_embedding_backward(out_grad, ctx.num_categories, transpose_indices,
@@ -138,6 +149,13 @@ def _(offsets, nnz):
 
 @torch.library.register_fake("cuembed_pyt::cuembed_transpose")
 def _(rows, cols, weights=None):
+    n = 0 if weights is None else cols.shape[0]
+    return (torch.empty_like(cols), torch.empty_like(rows),
+            torch.empty((n,), device=rows.device, dtype=torch.float32 if weights is None else weights.dtype))
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_transpose_bounded")
+def _(rows, cols, weights=None, num_categories=0):
     n = 0 if weights is None else cols.shape[0]
     return (torch.empty_like(cols), torch.empty_like(rows),
             torch.empty((n,), device=rows.device, dtype=torch.float32 if weights is None else weights.dtype))

@@ -209,9 +209,11 @@ def transpose_workspace_bytes(nnz, index_dtype, weight_dtype=None):
     return lwork.value
 
 
-def transpose(rows, cols, weights=None, workspace=None):
+def transpose(rows, cols, weights=None, workspace=None, num_categories=None):
     """Stable sort of (rows[i][, weights[i]]) by key cols[i] (callers pass rows = sample ids,
-    cols = lookup indices).  Returns (sorted cols, rows carried along, weights carried along)."""
+    cols = lookup indices).  Returns (sorted cols, rows carried along, weights carried along).
+    num_categories (optional, this library's extension): an upper bound on the values in `cols`;
+    the sort then skips the key digits that are always zero (same result, fewer passes)."""
     _check_dev("rows", rows)
     dev = rows.device
     _check_dev("cols", cols, dev)
@@ -235,10 +237,11 @@ def transpose(rows, cols, weights=None, workspace=None):
     elif workspace.numel() * workspace.element_size() < need:
         raise ValueError("workspace too small: need %d bytes" % need)
     lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
+    bits = 0 if not num_categories else max(1, int(num_categories - 1).bit_length())
     if nnz > 0:
-        _lib.lib().cuembed_transpose(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt, _ptr(t_rows),
-                                     _ptr(t_cols), _ptr(t_w), _ptr(workspace), ctypes.byref(lwork),
-                                     _stream(rows))
+        _lib.lib().cuembed_transpose_bounded(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
+                                             _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(workspace),
+                                             ctypes.byref(lwork), bits, _stream(rows))
     return t_rows, t_cols, t_w
 
 

@@ -161,6 +161,13 @@ void cuembed_transpose(const void* rows, const void* cols, const void* weights, 
                        int index_type, int weight_type, void* transpose_rows,
                        void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
                        cuembed_stream_t stream);
+/* Extension: as cuembed_transpose, for callers that know all lookup indices are
+ * < 2^index_bits (e.g. ceil(log2(num_categories))): the radix sort then skips the
+ * always-zero high digits.  index_bits <= 0 means "all bits" (= cuembed_transpose). */
+void cuembed_transpose_bounded(const void* rows, const void* cols, const void* weights, int nnz,
+                               int index_type, int weight_type, void* transpose_rows,
+                               void* transpose_cols, void* transpose_weights, char* work,
+                               size_t* lwork, int index_bits, cuembed_stream_t stream);
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream);

@@ -218,3 +218,21 @@ def test_backward_long_runs_power_law(ce, oracle):
     want, _ = oracle.embedding_backward(gy16.astype(np.float32), W, ncat, ti, ts)
     got, _ = ce.embedding_backward(dev(gy16), ncat, dev(ti), dev(ts))
     assert np.array_equal(host(got).astype(np.float32), want)
+
+
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_bounded_keys_extension(ce, oracle, idx):
+    """num_categories bound (this library's extension): fewer radix passes, identical result."""
+    rng = np.random.default_rng(8)
+    for ncat in (2, 1000, 65536, 65537, 10_000_000):
+        nnz = 200003
+        cols = rng.integers(0, ncat, nnz).astype(idx[0])
+        cols[0] = ncat - 1                                     # the largest admissible key is present
+        rows = rng.integers(0, 5000, nnz).astype(idx[0])
+        w = rng.uniform(0, 1, nnz).astype(np.float32)
+        oi, os_, ow = oracle.transpose(rows, cols, w, stable=True)
+        for weights in (None, w):
+            ti, ts, tw = ce.transpose(dev(rows), dev(cols), dev(weights), num_categories=ncat)
+            assert np.array_equal(host(ti), oi) and np.array_equal(host(ts), os_), ncat
+            if weights is not None:
+                assert np.array_equal(host(tw), ow)
