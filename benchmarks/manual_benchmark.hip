@@ -1,0 +1,368 @@
+// manual_benchmark -- C++ benchmark harness on the header-only API.
+//
+// Counterpart of the reference's benchmarks/manual_benchmark.cu: same flag names and defaults
+// (:44-82), same synthetic workload recipe (utils/src/embedding_allocation.cu:96-247 via
+// cuembed_amd/csrc/utils), same protocol (one warm-up call; every iteration timed alone with
+// events after a 1.02 GB cache-flushing reduction, or the whole loop once with
+// --clear_caches=false; :199-248) and the same "Application BW" formulas (:250-261, :340-354,
+// :444-471).  RunForward / RunTranspose / RunBackward below are the launch wrappers of
+// utils/src/embedding_gpu_{forward,transpose,backward}.cu on raw device pointers.
+//
+// build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I cuembed_amd/csrc \
+//               benchmarks/manual_benchmark.hip cuembed_amd/csrc/utils/synthetic_inputs.cpp \
+//               -o benchmarks/manual_benchmark
+// run:    benchmarks/manual_benchmark --num_categories 10000000 --embed_width 256 \
+//               --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true --iterations 100
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "cuembed/include/embedding_lookup.hpp"
+#include "cuembed/include/index_transforms.hpp"
+
+// synthetic workload recipe (cuembed_amd/csrc/utils/synthetic_inputs.cpp)
+extern "C" int64_t cuembed_harness_allocate_forward(int64_t num_categories, int embed_width, int batch,
+                                                    int hotness, double alpha, int is_csr, int shuffle,
+                                                    int permute, int elem_is_half, int index_is_64,
+                                                    void* table, int consume_table_draws, int32_t* offsets,
+                                                    void* indices, void* weights);
+extern "C" void cuembed_harness_allocate_grad_y(int64_t count, int elem_is_half, void* grad_y);
+
+#define HIP_OK(x)                                                                  \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      std::exit(2);                                                                \
+    }                                                                              \
+  } while (0)
+
+namespace {
+
+constexpr double kHbmPeakGBps = 8000.0;
+
+struct Flags {
+  int num_categories = 1048576, embed_width = 128, batch_size = 1024, hotness = 1, iterations = 1;
+  float alpha = 0.f;
+  bool use_int64_indices = false, check_result = false, half_embedding_type = false, csr_input = false,
+       weighted_sum = false, fp16_math = false, compressed_grad = true, skip_grad_init = true,
+       forward_only = false, enable_csv = false, enable_stderr = true, clear_caches = true,
+       bounded_sort = false;
+};
+
+bool ParseBool(const std::string& v) { return v.empty() || v == "1" || v == "true" || v == "True" || v == "yes"; }
+
+Flags ParseFlags(int argc, char** argv) {
+  std::map<std::string, std::string> kv;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a.rfind("--", 0) != 0) {
+      std::fprintf(stderr, "unexpected argument %s\n", a.c_str());
+      std::exit(1);
+    }
+    a = a.substr(2);
+    const size_t eq = a.find('=');
+    if (eq != std::string::npos) kv[a.substr(0, eq)] = a.substr(eq + 1);
+    else if (i + 1 < argc && std::strncmp(argv[i + 1], "--", 2) != 0) kv[a] = argv[++i];
+    else kv[a] = "";
+  }
+  Flags f;
+  auto geti = [&](const char* n, int* dst) { if (kv.count(n)) { *dst = std::atoi(kv[n].c_str()); kv.erase(n); } };
+  auto getb = [&](const char* n, bool* dst) { if (kv.count(n)) { *dst = ParseBool(kv[n]); kv.erase(n); } };
+  geti("num_categories", &f.num_categories); geti("embed_width", &f.embed_width);
+  geti("batch_size", &f.batch_size); geti("hotness", &f.hotness); geti("iterations", &f.iterations);
+  if (kv.count("alpha")) { f.alpha = static_cast<float>(std::atof(kv["alpha"].c_str())); kv.erase("alpha"); }
+  getb("use_int64_indices", &f.use_int64_indices); getb("check_result", &f.check_result);
+  getb("half_embedding_type", &f.half_embedding_type); getb("csr_input", &f.csr_input);
+  getb("weighted_sum", &f.weighted_sum); getb("fp16_math", &f.fp16_math);
+  getb("compressed_grad", &f.compressed_grad); getb("skip_grad_init", &f.skip_grad_init);
+  getb("forward_only", &f.forward_only); getb("enable_csv", &f.enable_csv);
+  getb("enable_stderr", &f.enable_stderr); getb("clear_caches", &f.clear_caches);
+  getb("bounded_sort", &f.bounded_sort);
+  for (auto& e : kv) {
+    std::fprintf(stderr, "unknown flag --%s\n", e.first.c_str());
+    std::exit(1);
+  }
+  return f;
+}
+
+// ---- device helpers ----------------------------------------------------------------------
+template <typename T>
+struct DeviceBuffer {
+  T* ptr = nullptr;
+  size_t n = 0;
+  void Resize(size_t count) {
+    if (ptr) (void)hipFree(ptr);
+    n = count;
+    HIP_OK(hipMalloc(&ptr, (count ? count : 1) * sizeof(T)));
+  }
+  void Upload(const std::vector<T>& h) {
+    Resize(h.size());
+    if (n) HIP_OK(hipMemcpy(ptr, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+};
+
+// uniform(-1, 1) table fill on the device (values do not influence timing; the reference's
+// host RNG would need rows * width sequential draws)
+template <typename ElemT>
+__global__ void FillTableKernel(ElemT* table, int64_t count) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    uint64_t z = static_cast<uint64_t>(i) + 0x9e3779b97f4a7c15ull;  // splitmix64
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    const float u = static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
+    table[i] = static_cast<ElemT>(2.0f * u - 1.0f);
+  }
+}
+
+// cache flush: max-reduction over 256,000,000 ints (manual_benchmark.cu:136-144)
+__global__ void FlushKernel(const int* buf, int64_t count, int* sink) {
+  int m = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    m = buf[i] > m ? buf[i] : m;
+  if (m == 0x7fffffff) atomicMax(sink, m);
+}
+
+template <typename T> struct DevElem { using type = T; };
+template <> struct DevElem<__half> { using type = _Float16; };
+
+// ---- the reference's launch wrappers on raw pointers ---------------------------------------
+template <typename ElemT, typename IndexT, typename OffsetT>
+struct Workload {
+  Flags f;
+  int64_t nnz = 0;
+  DeviceBuffer<ElemT> table, weights, result, grad_y, grad_embedding, transpose_weights;
+  DeviceBuffer<IndexT> indices, sample_ids, transpose_indices, transpose_remapped_indices,
+      transpose_sample_ids, inverse_mapping;
+  DeviceBuffer<OffsetT> offsets;
+  DeviceBuffer<char> workspace;
+  size_t lwork = 0;
+};
+
+template <typename ElemT, typename IndexT, typename OffsetT, bool fp16_math>
+void RunForward(Workload<ElemT, IndexT, OffsetT>& w) {
+  const OffsetT* offsets = w.f.csr_input ? w.offsets.ptr : nullptr;
+  const int hotness = w.f.csr_input ? 0 : w.f.hotness;
+  const ElemT* weights = w.f.weighted_sum ? w.weights.ptr : nullptr;
+  cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, fp16_math>(
+      w.table.ptr, w.f.embed_width, w.indices.ptr, offsets, weights, w.f.batch_size, hotness,
+      cuembed::CombineMode::kSum, w.result.ptr);
+}
+
+template <typename ElemT, typename IndexT, typename OffsetT>
+void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
+  const int nnz = static_cast<int>(w.nnz);
+  if (w.f.csr_input)
+    cuembed::ExtractRowIdsFromCSR<IndexT, OffsetT>(w.offsets.ptr, w.f.batch_size, w.sample_ids.ptr);
+  else
+    cuembed::ExtractRowIdsFromFixed<IndexT>(w.f.batch_size, w.f.hotness, w.sample_ids.ptr);
+  const ElemT* weights = w.f.weighted_sum ? w.weights.ptr : nullptr;
+  ElemT* t_weights = w.f.weighted_sum ? w.transpose_weights.ptr : nullptr;
+  size_t lwork = w.lwork;
+  int bits = static_cast<int>(sizeof(IndexT) * 8);
+  if (w.f.bounded_sort) {
+    bits = 1;
+    while ((int64_t{1} << bits) < w.f.num_categories) ++bits;
+  }
+  cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, weights, nnz, w.transpose_indices.ptr,
+                                    w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits);
+  if (w.f.compressed_grad)
+    cuembed::ComputeCompressedGradIndices<IndexT>(w.transpose_indices.ptr, nnz,
+                                                  w.transpose_remapped_indices.ptr, w.workspace.ptr, &lwork);
+}
+
+template <typename ElemT, typename IndexT, typename OffsetT>
+void RunBackward(Workload<ElemT, IndexT, OffsetT>& w, int num_unique) {
+  cuembed::EmbeddingBackward<ElemT, IndexT>(
+      w.grad_y.ptr, w.f.embed_width, w.f.compressed_grad ? num_unique : w.f.num_categories,
+      static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
+      w.f.compressed_grad ? w.transpose_remapped_indices.ptr : nullptr,
+      w.f.weighted_sum ? w.transpose_weights.ptr : nullptr, w.f.skip_grad_init, w.grad_embedding.ptr,
+      w.f.compressed_grad ? w.inverse_mapping.ptr : nullptr);
+}
+
+struct Timer {
+  hipEvent_t start, stop;
+  DeviceBuffer<int> flush, sink;
+  bool clear;
+  explicit Timer(bool clear_caches) : clear(clear_caches) {
+    HIP_OK(hipEventCreate(&start));
+    HIP_OK(hipEventCreate(&stop));
+    sink.Resize(1);
+    HIP_OK(hipMemset(sink.ptr, 0, sizeof(int)));
+    if (clear) {
+      flush.Resize(256000000);
+      HIP_OK(hipMemset(flush.ptr, 1, flush.n * sizeof(int)));
+    }
+  }
+  void ClearCache() {
+    if (clear) FlushKernel<<<2048, 256>>>(flush.ptr, static_cast<int64_t>(flush.n), sink.ptr);
+  }
+  template <typename Fn>
+  float Run(int iterations, Fn fn) {
+    fn();  // warm-up
+    ClearCache();
+    float total = 0.f;
+    for (int it = 0; it < iterations; ++it) {
+      if (clear || it == 0) HIP_OK(hipEventRecord(start));
+      fn();
+      if (clear || it == iterations - 1) {
+        HIP_OK(hipEventRecord(stop));
+        HIP_OK(hipEventSynchronize(stop));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, start, stop));
+        total += ms;
+      }
+      ClearCache();
+    }
+    HIP_OK(hipDeviceSynchronize());
+    return total;
+  }
+};
+
+void CsvLine(const Flags& f, const char* name, double ms, double bw_l2, double bw_dram) {
+  if (!f.enable_csv) return;
+  const char* fname = "manual_benchmark_out.csv";
+  bool existed = std::ifstream(fname).good();
+  std::ofstream out(fname, std::ios::app);
+  if (!existed)
+    out << "num_categories,batch_size,hotness,alpha,embed_width,combine_mode,is_csr,is_weighted,"
+           "compressed_grad,skip_grad_init,name,iterations,elapsed_time_ms,avg_time_ms,algo_bw_l2,algo_bw_dram\n";
+  char buf[512];
+  std::snprintf(buf, sizeof buf, "%d,%d,%d,%g,%d,kSum,%d,%d,%d,%d,%s,%d ,%.2f ,%.4f ,%.2f,%.2f\n",
+                f.num_categories, f.batch_size, f.hotness, f.alpha, f.embed_width, f.csr_input, f.weighted_sum,
+                f.compressed_grad, f.skip_grad_init, name, f.iterations, ms, ms / f.iterations, bw_l2, bw_dram);
+  out << buf;
+}
+
+template <typename ElemT, typename IndexT, typename OffsetT, bool fp16_math>
+void EmbeddingLookupBenchmark(const Flags& f) {
+  using DevT = typename DevElem<ElemT>::type;
+  constexpr bool kHalf = sizeof(ElemT) == 2;
+  constexpr bool kIdx64 = sizeof(IndexT) == 8;
+  Workload<ElemT, IndexT, OffsetT> w;
+  w.f = f;
+  const int64_t cells = static_cast<int64_t>(f.num_categories) * f.embed_width;
+  const bool device_fill = cells > (int64_t{64} << 20);
+
+  // ---- host-side synthetic inputs (reference recipe), table on the device when it is large ----
+  const size_t cap = static_cast<size_t>(f.batch_size) * f.hotness;
+  std::vector<ElemT> h_table(device_fill ? 0 : cells), h_weights(cap);
+  std::vector<IndexT> h_indices(cap);
+  std::vector<int32_t> h_offsets(f.batch_size + 1);
+  w.nnz = cuembed_harness_allocate_forward(f.num_categories, f.embed_width, f.batch_size, f.hotness, f.alpha,
+                                           f.csr_input, 1, 1, kHalf, kIdx64, device_fill ? nullptr : h_table.data(),
+                                           device_fill ? 0 : 1, h_offsets.data(), h_indices.data(),
+                                           h_weights.data());
+  h_indices.resize(w.nnz);
+  h_weights.resize(w.nnz);
+  if (device_fill) {
+    w.table.Resize(cells);
+    FillTableKernel<DevT><<<4096, 256>>>(reinterpret_cast<DevT*>(w.table.ptr), cells);
+  } else {
+    w.table.Upload(h_table);
+  }
+  w.indices.Upload(h_indices);
+  w.weights.Upload(h_weights);
+  std::vector<OffsetT> h_off(h_offsets.begin(), h_offsets.end());
+  w.offsets.Upload(h_off);
+  w.result.Resize(static_cast<size_t>(f.batch_size) * f.embed_width);
+  HIP_OK(hipDeviceSynchronize());
+
+  Timer timer(f.clear_caches);
+  const double es = sizeof(ElemT), W = f.embed_width, B = f.batch_size, H = f.hotness, nnz = w.nnz;
+  const double it = f.iterations;
+
+  // ---- forward ----
+  float ms = timer.Run(f.iterations, [&] { RunForward<ElemT, IndexT, OffsetT, fp16_math>(w); });
+  double bytes = f.csr_input ? es * (nnz - 1 + B) * W : es * B * (H + 1) * W;
+  double bw = bytes * it / 1e6 / ms;
+  std::fprintf(stderr, "Embedding forward. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
+                       "Application BW [GB/s]: %.2f (%.1f%% of HBM peak)\n",
+               f.iterations, ms, ms / it, bw, 100.0 * bw / kHbmPeakGBps);
+  CsvLine(f, "forward", ms, bw, 0.0);
+  if (f.check_result)
+    std::fprintf(stderr, "check_result: results are checked against the CPU oracle by `pytest -m gpu` and "
+                         "benchmarks/manual_benchmark.py --check_result, not by this binary\n");
+  if (f.forward_only) return;
+
+  // ---- transpose (+ compressed remap) ----
+  w.sample_ids.Resize(w.nnz);
+  w.transpose_indices.Resize(w.nnz);
+  w.transpose_remapped_indices.Resize(w.nnz);
+  w.transpose_sample_ids.Resize(w.nnz);
+  w.transpose_weights.Resize(w.nnz);
+  size_t lw_t = 0, lw_c = 0;
+  cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, f.weighted_sum ? w.weights.ptr : nullptr,
+                                    static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
+                                    w.transpose_weights.ptr, nullptr, &lw_t);
+  cuembed::ComputeCompressedGradIndices<IndexT>(w.transpose_indices.ptr, static_cast<int>(w.nnz),
+                                                w.transpose_remapped_indices.ptr, nullptr, &lw_c);
+  w.lwork = lw_t > lw_c ? lw_t : lw_c;
+  w.workspace.Resize(w.lwork);
+  ms = timer.Run(f.iterations, [&] { RunTranspose<ElemT, IndexT, OffsetT>(w); });
+  double tb = nnz * sizeof(IndexT) + (f.csr_input ? nnz * sizeof(OffsetT) : 0) + (f.weighted_sum ? nnz * es : 0) +
+              (f.compressed_grad ? 3 : 2) * nnz * sizeof(IndexT) + (f.weighted_sum ? nnz * es : 0);
+  bw = tb * it / 1e6 / ms;
+  std::fprintf(stderr, "Transpose. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
+                       "Application BW [GB/s]: %.2f\n", f.iterations, ms, ms / it, bw);
+  CsvLine(f, "transpose", ms, 0.0, bw);
+
+  // ---- backward ----
+  int num_unique = 0;
+  if (f.compressed_grad) {
+    IndexT last = 0;
+    HIP_OK(hipMemcpy(&last, w.transpose_remapped_indices.ptr + (w.nnz - 1), sizeof(IndexT), hipMemcpyDeviceToHost));
+    num_unique = static_cast<int>(last) + 1;
+  }
+  const int64_t grad_rows = f.compressed_grad ? num_unique : f.num_categories;
+  std::vector<ElemT> h_gy(static_cast<size_t>(f.batch_size) * f.embed_width);
+  cuembed_harness_allocate_grad_y(static_cast<int64_t>(h_gy.size()), kHalf, h_gy.data());
+  w.grad_y.Upload(h_gy);
+  w.grad_embedding.Resize(static_cast<size_t>(grad_rows) * f.embed_width);
+  HIP_OK(hipMemset(w.grad_embedding.ptr, 0, w.grad_embedding.n * sizeof(ElemT)));
+  w.inverse_mapping.Resize(f.compressed_grad ? num_unique : 0);
+  ms = timer.Run(f.iterations, [&] { RunBackward<ElemT, IndexT, OffsetT>(w, num_unique); });
+  // unique rows actually touched (the reference counts them with thrust::unique_count)
+  std::vector<IndexT> h_t(w.nnz);
+  HIP_OK(hipMemcpy(h_t.data(), w.transpose_indices.ptr, w.nnz * sizeof(IndexT), hipMemcpyDeviceToHost));
+  int64_t uniq = w.nnz > 0 ? 1 : 0;
+  for (int64_t i = 1; i < w.nnz; ++i) uniq += h_t[i] != h_t[i - 1];
+  double dram = es * W * uniq + 2.0 * sizeof(IndexT) * nnz + (f.weighted_sum ? es * nnz : 0) + es * W * B;
+  double l2 = dram + es * W * nnz;
+  std::fprintf(stderr, "Backward. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
+                       "Application DRAM BW [GB/s]: %.2f , Application L2 BW [GB/s]: %.2f\n",
+               f.iterations, ms, ms / it, dram * it / 1e6 / ms, l2 * it / 1e6 / ms);
+  CsvLine(f, "backward", ms, l2 * it / 1e6 / ms, dram * it / 1e6 / ms);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  const Flags f = ParseFlags(argc, argv);
+  // type dispatch as in manual_benchmark.cu:563-659
+#define DISPATCH(ELEM, MATH)                                                            \
+  do {                                                                                  \
+    if (f.use_int64_indices) EmbeddingLookupBenchmark<ELEM, int64_t, int, MATH>(f);     \
+    else EmbeddingLookupBenchmark<ELEM, int32_t, int, MATH>(f);                         \
+  } while (0)
+  if (f.half_embedding_type) {
+    if (f.fp16_math) DISPATCH(__half, true);
+    else DISPATCH(__half, false);
+  } else {
+    DISPATCH(float, false);
+  }
+  return 0;
+}

@@ -159,5 +159,29 @@ def build_header_api_test(force=False):
     return exe
 
 
+def build_manual_benchmark(force=False):
+    """Compiles benchmarks/manual_benchmark.hip (C++ harness on the header-only API)."""
+    src = os.path.join(ROOT, "benchmarks", "manual_benchmark.hip")
+    gen = os.path.join(CSRC, "utils", "synthetic_inputs.cpp")
+    exe = os.path.join(ROOT, "benchmarks", "manual_benchmark")
+    stamp = exe + ".stamp"
+    deps = [src, gen, os.path.join(CSRC, "utils", "datagen.hpp")]
+    for dirpath, _, files in os.walk(os.path.join(CSRC, "cuembed", "include")):
+        deps += [os.path.join(dirpath, f) for f in files]
+    digest = _digest_files(deps)
+    if not force and os.path.exists(exe) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return exe
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I" + CSRC,
+           src, gen, "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for benchmarks/manual_benchmark.hip:\n" + r.stdout)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
