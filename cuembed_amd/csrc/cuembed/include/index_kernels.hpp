@@ -12,8 +12,10 @@ namespace cuembed {
 namespace detail {
 
 constexpr int kSequenceItemsPerThread = 4;
-//! Samples whose offsets one workgroup stages in LDS for ExpandCsrKernel.
-constexpr int kCsrSamplesPerBlock = 1024;
+//! Samples whose offsets one workgroup stages in LDS for ExpandCsrKernel.  Small enough that
+//! a 65,536-sample batch already gives 512 workgroups (2 per CU); large enough that the
+//! workgroup's slice of row_ids (~samples x hotness entries) amortises the staging.
+constexpr int kCsrSamplesPerBlock = 128;
 
 //! out[t] = t / divisor.  Grid-free of tails: each workgroup covers
 //! blockDim.x * kSequenceItemsPerThread consecutive items, lane-interleaved so
@@ -60,22 +62,37 @@ ExpandCsrKernel(const OffsetT* __restrict__ offsets, const int batch, IndexT* __
   }
 }
 
-//! out_rows[i] = rows[pos[i]], out_weights[i] = weights[pos[i]]
-//! (second half of the weighted transpose; the reference moves a
-//! (sample id, weight) struct through the sort instead,
-//! index_transforms_kernels.cuh:50-81).
+//! (sample id, weight) travelling together as the VALUE of the radix sort of a weighted
+//! transpose (the reference's WeightTuple, index_transforms_kernels.cuh:50-54).
 template <typename IndexT, typename WeightT>
-__global__ void GatherByPositionKernel(const uint32_t* __restrict__ pos,
-                                       const IndexT* __restrict__ rows,
-                                       const WeightT* __restrict__ weights,
-                                       const int64_t count,
-                                       IndexT* __restrict__ out_rows,
-                                       WeightT* __restrict__ out_weights) {
+struct alignas(sizeof(IndexT) >= 8 ? 8 : 4) IdWeight {
+  IndexT id;
+  WeightT weight;
+};
+
+template <typename IndexT, typename WeightT>
+__global__ void PackIdWeightKernel(const IndexT* __restrict__ ids,
+                                   const WeightT* __restrict__ weights,
+                                   const int64_t count,
+                                   IdWeight<IndexT, WeightT>* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const uint32_t p = pos[i];
-  out_rows[i] = rows[p];
-  out_weights[i] = weights[p];
+  IdWeight<IndexT, WeightT> t;
+  t.id = ids[i];
+  t.weight = weights[i];
+  out[i] = t;
+}
+
+template <typename IndexT, typename WeightT>
+__global__ void UnpackIdWeightKernel(const IdWeight<IndexT, WeightT>* __restrict__ in,
+                                     const int64_t count,
+                                     IndexT* __restrict__ ids,
+                                     WeightT* __restrict__ weights) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const IdWeight<IndexT, WeightT> t = in[i];
+  ids[i] = t.id;
+  weights[i] = t.weight;
 }
 
 //! flag(i) = 1 when lookup i starts a new run of equal indices, 0 for i == 0

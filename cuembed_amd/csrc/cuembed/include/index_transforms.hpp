@@ -140,34 +140,35 @@ void Transpose(const IndexT* rows,
     return;
   }
 
-  // Weighted: sort (key, original position) and gather sample id + weight
-  // through the sorted positions -- the payload that rides through every radix
-  // pass stays 4 bytes instead of a (sample id, weight) struct.
-  const size_t pos_bytes = detail::AlignUp(n * sizeof(uint32_t), 256);
+  // Weighted: (sample id, weight) ride through the sort as one packed value, like the
+  // reference's WeightTuple (index_transforms.cuh:139-200): pack -> sort -> unpack, all
+  // streaming.  (Sorting positions and gathering through them was measured 3x slower: the
+  // 4-byte random gathers waste most of every cache line.)
+  using ValueT = detail::IdWeight<IndexT, WeightT>;
+  const size_t val_bytes = detail::AlignUp(n * sizeof(ValueT), 256);
   size_t sort_bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_in, keys_out,
-                                  static_cast<const uint32_t*>(nullptr),
-                                  static_cast<uint32_t*>(nullptr), n, begin_bit, end_bit, stream);
-  const size_t required = 2 * pos_bytes + sort_bytes;
+                                  static_cast<const ValueT*>(nullptr), static_cast<ValueT*>(nullptr),
+                                  n, begin_bit, end_bit, stream);
+  const size_t required = 2 * val_bytes + sort_bytes;
   if (work == nullptr) {
     *lwork = required;
     return;
   }
   assert(*lwork >= required);
   if (n == 0) return;
-  uint32_t* pos_in = reinterpret_cast<uint32_t*>(work);
-  uint32_t* pos_out = reinterpret_cast<uint32_t*>(work + pos_bytes);
-  void* sort_work = work + 2 * pos_bytes;
+  ValueT* vals_in = reinterpret_cast<ValueT*>(work);
+  ValueT* vals_out = reinterpret_cast<ValueT*>(work + val_bytes);
+  void* sort_work = work + 2 * val_bytes;
 
   const int threads = detail::kIndexBlockThreads;
-  const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
-  const unsigned blocks = static_cast<unsigned>((nnz + per_block - 1) / per_block);
-  detail::FillQuotientKernel<uint32_t><<<blocks, threads, 0, stream>>>(nnz, 1, pos_in);
-  (void)rocprim::radix_sort_pairs(sort_work, sort_bytes, keys_in, keys_out, pos_in, pos_out, n,
+  const unsigned blocks = static_cast<unsigned>((nnz + threads - 1) / threads);
+  detail::PackIdWeightKernel<IndexT, WeightT>
+      <<<blocks, threads, 0, stream>>>(rows, weights, nnz, vals_in);
+  (void)rocprim::radix_sort_pairs(sort_work, sort_bytes, keys_in, keys_out, vals_in, vals_out, n,
                                   begin_bit, end_bit, stream);
-  detail::GatherByPositionKernel<IndexT, WeightT>
-      <<<(nnz + threads - 1) / threads, threads, 0, stream>>>(pos_out, rows, weights, nnz,
-                                                               transpose_cols, transpose_weights);
+  detail::UnpackIdWeightKernel<IndexT, WeightT>
+      <<<blocks, threads, 0, stream>>>(vals_out, nnz, transpose_cols, transpose_weights);
 }
 
 /**
