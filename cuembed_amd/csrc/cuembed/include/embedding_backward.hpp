@@ -27,34 +27,51 @@ inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
   return len;
 }
 
+//! Column slices for the backward gather (see SegmentedScatterAddKernel 2b): slices of at
+//! least 128 bytes (one L2 line), at most 4.  CUEMBED_BWD_SLICES overrides (tuning knob).
+inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row) {
+  int slices = 1;
+  while (slices < 4 && row_bytes / (slices * 2) >= 128 && lanes_per_row % (slices * 2) == 0) slices *= 2;
+  if (const char* env = std::getenv("CUEMBED_BWD_SLICES")) {
+    const int v = std::atoi(env);
+    if ((v == 1 || v == 2 || v == 4 || v == 8) && lanes_per_row % v == 0) slices = v;
+  }
+  return slices;
+}
+
 template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream) {
+  const int slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row);
+  const int lanes = split.lanes_per_row / slices;  // lanes of one column slice
+  int segments_per_block = lanes >= kDefaultBlockThreads ? 1 : kDefaultBlockThreads / lanes;
   int segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
   // Keep the staged COO triples of one workgroup within the LDS budget: shorten the
   // segments first (down to 32 lookups), then put fewer segments in a workgroup.
-  while (ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len, split.lanes_per_row, N,
-                                          weights != nullptr) >
+  while (ScatterStageBytes<GradT, IndexT>(segments_per_block, segment_len, lanes, N, weights != nullptr) >
          static_cast<size_t>(kMaxScatterStageBytes)) {
     if (segment_len > 32) segment_len /= 2;
-    else if (split.rows_per_block > 1) split.rows_per_block /= 2;
+    else if (segments_per_block > 1) segments_per_block /= 2;
     else if (segment_len > kMinSegmentLen) segment_len /= 2;
     else break;
   }
   const int64_t num_segments = (nnz + segment_len - 1) / segment_len;
-  const dim3 block(split.lanes_per_row, split.rows_per_block, 1);
-  const dim3 grid(static_cast<unsigned>((num_segments + split.rows_per_block - 1) /
-                                        split.rows_per_block),
-                  1, 1);
-  const size_t lds = ScatterStageBytes<GradT, IndexT>(split.rows_per_block, segment_len,
-                                                      split.lanes_per_row, N, weights != nullptr);
+  const int64_t nz_blocks = (num_segments + segments_per_block - 1) / segments_per_block;
+  // one workgroup per (nz block, slice); with slices > 1 the 8 / slices XCDs that share a
+  // slice split the nz blocks, so the grid is a whole number of rounds of 8 workgroups
+  const int per_slice = slices > 1 ? 8 / slices : 1;
+  const int64_t grid_blocks = slices > 1 ? (nz_blocks + per_slice - 1) / per_slice * 8 : nz_blocks;
+  const dim3 block(lanes, segments_per_block, 1);
+  const dim3 grid(static_cast<unsigned>(grid_blocks), 1, 1);
+  const size_t lds =
+      ScatterStageBytes<GradT, IndexT>(segments_per_block, segment_len, lanes, N, weights != nullptr);
   if (weights != nullptr)
     SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);
+        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out, slices);
   else
     SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out);
+        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out, slices);
 }
 
 }  // namespace detail

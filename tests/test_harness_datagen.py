@@ -52,3 +52,23 @@ def test_allocate_forward_matches_oracle(harness, oracle, golden_dir, elem, csr)
 def test_grad_y_matches_oracle(harness, oracle):
     for elem in (np.float32, np.float16):
         assert np.array_equal(harness.allocate_grad_y(5000, elem), oracle.allocate_grad_y(5000, elem))
+
+
+def test_one_hot_power_law_matches_analytical_distribution(harness):
+    """tests/test_datagen.cpp:109-139: one-hot Psx generator, 9 categories, alpha 1.15, 4M draws:
+    empirical frequencies within 1e-3 of the normalised integral of x^-alpha over [i, i+1)."""
+    n_cat, alpha, draws = 9, 1.15, 4_000_000
+    idx = harness.generate_indices(n_cat + 1, draws, 1, alpha=alpha, shuffle=False, permute=False)
+    assert idx.min() >= 1 and idx.max() <= n_cat
+    i = np.arange(1, n_cat + 1, dtype=np.float64)
+    p = (-alpha) * i ** (1 - alpha) - (-alpha) * (i + 1) ** (1 - alpha)
+    p /= p.sum()
+    freq = np.bincount(idx, minlength=n_cat + 1)[1:] / draws
+    assert np.abs(freq - p).max() < 1e-3
+
+
+def test_multi_hot_no_repeats_in_range(harness):
+    """tests/test_datagen.cpp:143-160."""
+    idx = harness.generate_indices(1001, 40000, 64, alpha=1.15, shuffle=False, permute=False).reshape(40000, 64)
+    assert idx.min() >= 1 and idx.max() <= 1000
+    assert (np.diff(np.sort(idx, axis=1), axis=1) > 0).all()
