@@ -29,9 +29,13 @@ inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
 
 //! Column slices for the backward gather (see SegmentedScatterAddKernel 2b): slices of at
 //! least 128 bytes (one L2 line), at most 4.  CUEMBED_BWD_SLICES overrides (tuning knob).
-inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row) {
+//! Only for >= 1M lookups: EmbeddingBackward is not told the batch size, and with few lookups
+//! grad_y fits the L2s anyway (measured: 0.340 -> 0.290 ms at C4, but 25 -> 28 us at nnz = 262k).
+inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row, const int64_t nnz) {
   int slices = 1;
-  while (slices < 4 && row_bytes / (slices * 2) >= 128 && lanes_per_row % (slices * 2) == 0) slices *= 2;
+  while (nnz >= (int64_t{1} << 20) && slices < 4 && row_bytes / (slices * 2) >= 128 &&
+         lanes_per_row % (slices * 2) == 0)
+    slices *= 2;
   if (const char* env = std::getenv("CUEMBED_BWD_SLICES")) {
     const int v = std::atoi(env);
     if ((v == 1 || v == 2 || v == 4 || v == 8) && lanes_per_row % v == 0) slices = v;
@@ -43,7 +47,7 @@ template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream) {
-  const int slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row);
+  const int slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row, nnz);
   const int lanes = split.lanes_per_row / slices;  // lanes of one column slice
   int segments_per_block = lanes >= kDefaultBlockThreads ? 1 : kDefaultBlockThreads / lanes;
   int segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
