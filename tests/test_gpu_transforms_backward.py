@@ -236,3 +236,40 @@ def test_transpose_bounded_keys_extension(ce, oracle, idx):
             assert np.array_equal(host(ti), oi) and np.array_equal(host(ts), os_), ncat
             if weights is not None:
                 assert np.array_equal(host(tw), ow)
+
+
+@pytest.mark.parametrize("slices", ["2", "4"])
+def test_backward_column_slices_small_shapes(ce, oracle, slices, monkeypatch):
+    """Forces the XCD column-slice mapping (normally only used for >= 1M lookups) on small, odd
+    shapes: partial grids of 8-workgroup rounds, segments shorter than the unroll, long runs."""
+    monkeypatch.setenv("CUEMBED_BWD_SLICES", slices)
+    for (W, B, H, ncat, alpha) in [(128, 1023, 26, 20480, 0.0), (256, 300, 63, 500, 1.15), (64, 5, 3, 50, 0.0),
+                                   (512, 2000, 16, 600, 1.15)]:
+        for elem in ELEMS:
+            a = oracle.allocate_forward(ncat, W, B, H, alpha=alpha, elem=elem[0])
+            sid = oracle.extract_row_ids_from_fixed(B, H)
+            ti, ts, tw = oracle.transpose(sid, a["indices"], a["weights"])
+            ints = oracle.allocate_grad_y(B * W).reshape(B, W)
+            gy = (np.mod(ints, 3) - 1).astype(elem[0])          # {-1,0,1}: exact for any run length here
+            remap = oracle.compute_compressed_grad_indices(ti)
+            nu = int(remap[-1]) + 1
+            for weights in (None, tw):
+                if weights is not None and elem[0] == np.float16 and alpha > 0:
+                    continue                                     # 0.25-steps x long runs exceed fp16's 11 bits
+                want, winv = oracle.embedding_backward(gy.astype(np.float32), W, nu, ti, ts, remap,
+                                                       None if weights is None else weights.astype(np.float32))
+                got, ginv = ce.embedding_backward(dev(gy), nu, dev(ti), dev(ts), dev(remap), dev(weights))
+                assert np.array_equal(host(got).astype(np.float32), want), (W, B, H, elem[0], weights is not None)
+                assert np.array_equal(host(ginv), winv)
+
+
+def test_backward_million_lookups_default_heuristics(ce, oracle):
+    """nnz >= 2^20 takes the column-sliced path by default (fp32, W=128: four 128-byte slices)."""
+    W, B, H, ncat = 128, 16384, 64, 100_000
+    a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15)
+    sid = oracle.extract_row_ids_from_fixed(B, H)
+    ti, ts, _ = oracle.transpose(sid, a["indices"])
+    gy = oracle.allocate_grad_y(B * W).reshape(B, W)
+    want, _ = oracle.embedding_backward(gy, W, ncat, ti, ts)
+    got, _ = ce.embedding_backward(dev(gy), ncat, dev(ti), dev(ts))
+    assert np.array_equal(host(got), want)
