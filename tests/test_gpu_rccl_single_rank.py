@@ -1,0 +1,54 @@
+"""BASELINE config 5 path (fwd + bwd with the gradient combined over RCCL) on ONE rank: the
+collective code of cuembed_amd/distributed.py runs through the real RCCL backend ("nccl") on
+HIP tensors, with the HIP kernels doing the compute.  The world-size-2 arithmetic is covered on
+CPU/gloo in tests/test_distributed_gloo.py; multi-GPU boxes are not available to the test suite."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_fwd_bwd_allreduce_world1(oracle):
+    import torch.distributed as dist
+    import cuembed_amd as ce
+    from cuembed_amd import distributed as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ncat, W, B, H = 4000, 128, 1000, 12
+        a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15, elem=np.float16)
+        table = torch.from_numpy(a["table"]).cuda()
+        idx_all = torch.from_numpy(a["indices"]).cuda()
+        idx, _, b_loc = D.shard_fixed(idx_all, None, B, H, dist.get_rank(), dist.get_world_size())
+        out = ce.embedding_forward(table, idx.contiguous(), batch_size=b_loc, num_hots=H)
+        want = oracle.embedding_forward(a["table"], a["indices"], num_hots=H)
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
+        gy_np = oracle.allocate_grad_y(B * W, np.float16).reshape(B, W)
+        gy = torch.from_numpy(gy_np).cuda()
+        sid = ce.extract_row_ids_from_fixed(b_loc, H, torch.int32, "cuda")
+        t_idx, t_sid, _ = ce.transpose(sid, idx.contiguous(), num_categories=ncat)
+        dense, _ = ce.embedding_backward(gy, ncat, t_idx, t_sid)
+        D.allreduce_dense_grad(dense)                                   # RCCL all-reduce
+        o_ti, o_ts, _ = oracle.transpose(oracle.extract_row_ids_from_fixed(B, H), a["indices"])
+        o_grad, _ = oracle.embedding_backward(gy_np, W, ncat, o_ti, o_ts)
+        assert np.array_equal(dense.cpu().numpy().view(np.uint16), o_grad.view(np.uint16))
+        remap = ce.compute_compressed_grad_indices(t_idx)
+        nu = int(remap[-1].item()) + 1
+        rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
+        ids, summed = D.allreduce_sparse_grad(rows, inv, ncat)          # RCCL all-gather based
+        rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device="cuda")
+        rebuilt[ids] = summed
+        assert np.array_equal(rebuilt.cpu().numpy().view(np.uint16), o_grad.view(np.uint16))
+    finally:
+        dist.destroy_process_group()

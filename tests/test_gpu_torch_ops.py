@@ -163,3 +163,32 @@ def test_op_schemas_and_dtypes(pyt):
         pyt.cuembed_embedding_forward(table.double(), idx, off, None, "sum")
     with pytest.raises(RuntimeError):
         pyt.cuembed_embedding_forward(table, idx, off, None, "max")
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_sparse_gradient_extension(pyt, weighted):
+    """sparse_grad=True returns the compressed gradient as a coalesced sparse COO tensor that
+    densifies to the dense-path gradient (and to nn.EmbeddingBag's)."""
+    k, d, B = 20000, 64, 2048
+    bag = make_bag(k, d)
+    lens = torch.randint(1, 20, (B,), device="cuda")
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens.cumsum(0)])
+    n = int(offsets[-1])
+    indices = torch.randint(0, k, (n,), device="cuda")
+    w = torch.rand(n, device="cuda") if weighted else None
+    up = torch.randn(B, d, device="cuda")
+    weight = bag.weight
+    weight.grad = None
+    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=True) * up).sum().backward()
+    g_sparse = weight.grad
+    assert g_sparse.is_sparse
+    assert g_sparse._nnz() == torch.unique(indices).numel()        # one entry per looked-up row
+    ids = g_sparse._indices()[0]
+    assert (ids[1:] > ids[:-1]).all()                                # ascending, no duplicates
+    weight.grad = None
+    (pyt.cuemb_embedding(weight, indices, offsets, w) * up).sum().backward()
+    g_dense = weight.grad.clone()
+    assert torch.allclose(g_sparse.to_dense(), g_dense, rtol=1e-5, atol=1e-5)
+    weight.grad = None
+    (bag(indices, offsets, w) * up).sum().backward()
+    assert torch.allclose(g_sparse.to_dense(), weight.grad, rtol=1e-4, atol=1e-4)
