@@ -36,6 +36,8 @@ CUEMBED_DEFINE_BACKWARD(f32_i32, float, float, int32_t)
 CUEMBED_DEFINE_BACKWARD(f32_i64, float, float, int64_t)
 CUEMBED_DEFINE_BACKWARD(f16_i32, void, __half, int32_t)
 CUEMBED_DEFINE_BACKWARD(f16_i64, void, __half, int64_t)
+CUEMBED_DEFINE_BACKWARD(bf16_i32, void, __hip_bfloat16, int32_t)
+CUEMBED_DEFINE_BACKWARD(bf16_i64, void, __hip_bfloat16, int64_t)
 #undef CUEMBED_DEFINE_BACKWARD
 
 void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_width,
@@ -56,6 +58,8 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
     case 1: BWD(float, int64_t); break;
     case 2: BWD(__half, int32_t); break;
     case 3: BWD(__half, int64_t); break;
+    case 4: BWD(__hip_bfloat16, int32_t); break;
+    case 5: BWD(__hip_bfloat16, int64_t); break;
     default: CUEMBED_C_API_BAD_TYPE();
   }
 #undef BWD

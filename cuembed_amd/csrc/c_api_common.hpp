@@ -2,6 +2,7 @@
 #ifndef CUEMBED_AMD_C_API_COMMON_HPP_
 #define CUEMBED_AMD_C_API_COMMON_HPP_
 
+#include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 

@@ -47,6 +47,10 @@ CUEMBED_DEFINE_FORWARD(f16_i32_o32, void, __half, int32_t, int32_t)
 CUEMBED_DEFINE_FORWARD(f16_i32_o64, void, __half, int32_t, int64_t)
 CUEMBED_DEFINE_FORWARD(f16_i64_o32, void, __half, int64_t, int32_t)
 CUEMBED_DEFINE_FORWARD(f16_i64_o64, void, __half, int64_t, int64_t)
+CUEMBED_DEFINE_FORWARD(bf16_i32_o32, void, __hip_bfloat16, int32_t, int32_t)
+CUEMBED_DEFINE_FORWARD(bf16_i32_o64, void, __hip_bfloat16, int32_t, int64_t)
+CUEMBED_DEFINE_FORWARD(bf16_i64_o32, void, __hip_bfloat16, int64_t, int32_t)
+CUEMBED_DEFINE_FORWARD(bf16_i64_o64, void, __hip_bfloat16, int64_t, int64_t)
 #undef CUEMBED_DEFINE_FORWARD
 
 void cuembed_embedding_forward(const void* params, int elem_type, int embed_width,
@@ -68,6 +72,10 @@ void cuembed_embedding_forward(const void* params, int elem_type, int embed_widt
     case 5: FWD(__half, int32_t, int64_t); break;
     case 6: FWD(__half, int64_t, int32_t); break;
     case 7: FWD(__half, int64_t, int64_t); break;
+    case 8: FWD(__hip_bfloat16, int32_t, int32_t); break;
+    case 9: FWD(__hip_bfloat16, int32_t, int64_t); break;
+    case 10: FWD(__hip_bfloat16, int64_t, int32_t); break;
+    case 11: FWD(__hip_bfloat16, int64_t, int64_t); break;
     default: CUEMBED_C_API_BAD_TYPE();
   }
 #undef FWD
@@ -84,7 +92,7 @@ void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width
                                                            num_hots, is_csr, is_weighted, concat)
             : cuembed::detail::PlanForward<float, int64_t>(embed_width, nullptr, nullptr, batch_size,
                                                            num_hots, is_csr, is_weighted, concat);
-  } else {
+  } else {  // 2-byte elements (fp16 and bf16 plan identically)
     f = index_type == CUEMBED_I32
             ? cuembed::detail::PlanForward<_Float16, int32_t>(embed_width, nullptr, nullptr,
                                                               batch_size, num_hots, is_csr,

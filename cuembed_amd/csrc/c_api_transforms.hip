@@ -22,6 +22,8 @@ CUEMBED_DEFINE_TRANSPOSE(i32_f32, int32_t, float, float)
 CUEMBED_DEFINE_TRANSPOSE(i64_f32, int64_t, float, float)
 CUEMBED_DEFINE_TRANSPOSE(i32_f16, int32_t, void, __half)
 CUEMBED_DEFINE_TRANSPOSE(i64_f16, int64_t, void, __half)
+CUEMBED_DEFINE_TRANSPOSE(i32_bf16, int32_t, void, __hip_bfloat16)
+CUEMBED_DEFINE_TRANSPOSE(i64_bf16, int64_t, void, __hip_bfloat16)
 #undef CUEMBED_DEFINE_TRANSPOSE
 
 #define CUEMBED_DEFINE_COMPRESS(SUFFIX, INDEX)                                                \
@@ -77,7 +79,8 @@ void cuembed_transpose_bounded(const void* rows, const void* cols, const void* w
                            static_cast<const W*>(weights), nnz, static_cast<I*>(transpose_rows), \
                            static_cast<I*>(transpose_cols), static_cast<W*>(transpose_weights), \
                            work, lwork, Stream(stream), index_bits)
-  switch ((index_type << 1) | weight_type) {
+  // weights are only moved, never computed on: fp16 and bf16 share the 2-byte instantiation
+  switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {
     case 0: TR(int32_t, float); break;
     case 1: TR(int32_t, __half); break;
     case 2: TR(int64_t, float); break;

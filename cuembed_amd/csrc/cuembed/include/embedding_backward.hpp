@@ -103,8 +103,9 @@ void EmbeddingBackward(const GradT* grad_y,
                        GradT* grad_embedding,
                        IndexT* inverse_mapping,
                        const hipStream_t stream = 0) {
-  static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value,
-                "EmbeddingBackward: gradients must be float or __half");
+  static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value ||
+                    std::is_same<GradT, __hip_bfloat16>::value,
+                "EmbeddingBackward: gradients must be float, __half or __hip_bfloat16");
   using ElemT = detail::DeviceElemT<GradT>;
 
   const IndexT* rows =

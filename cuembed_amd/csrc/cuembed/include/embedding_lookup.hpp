@@ -236,8 +236,9 @@ void EmbeddingForward(const InputT* params,
   static_assert(std::is_same<InputT, OutputT>::value,
                 "EmbeddingForward: OutputT must equal InputT");
   using HostElemT = GetElemT<InputT>;
-  static_assert(std::is_same<HostElemT, float>::value || std::is_same<HostElemT, __half>::value,
-                "EmbeddingForward: table elements must be float or __half");
+  static_assert(std::is_same<HostElemT, float>::value || std::is_same<HostElemT, __half>::value ||
+                    std::is_same<HostElemT, __hip_bfloat16>::value,
+                "EmbeddingForward: table elements must be float, __half or __hip_bfloat16");
   using ElemT = detail::DeviceElemT<HostElemT>;
   using AccT = typename std::conditional<fp16_math && detail::IsHalf<ElemT>::value, ElemT,
                                          float>::type;

@@ -10,6 +10,7 @@
 #ifndef CUEMBED_INCLUDE_EMBEDDING_TYPES_HPP_
 #define CUEMBED_INCLUDE_EMBEDDING_TYPES_HPP_
 
+#include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -42,6 +43,13 @@ struct DeviceElem {
 template <>
 struct DeviceElem<__half> {
   using type = _Float16;
+};
+// bf16 tables (an extension: the reference lists bf16 as future work, README.md:111).
+// `__bf16` converts to/from float with round-to-nearest-even in hardware on gfx950
+// (v_cvt_pk_bf16_f32); accumulation is always fp32.
+template <>
+struct DeviceElem<__hip_bfloat16> {
+  using type = __bf16;
 };
 template <typename T>
 using DeviceElemT = typename DeviceElem<T>::type;

@@ -74,6 +74,11 @@ struct ColumnSlice {
   }
 };
 
+__device__ __forceinline__ __bf16 ShuffleElem(__bf16 v, int src, int width) {
+  const int bits = __shfl(static_cast<int>(__builtin_bit_cast(unsigned short, v)), src, width);
+  return __builtin_bit_cast(__bf16, static_cast<unsigned short>(bits));
+}
+
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
   return *reinterpret_cast<const Pack<ElemT, N>*>(p);

@@ -48,6 +48,20 @@ __device__ __forceinline__ void FlushAtomic(_Float16* dst, const float (&acc)[N]
   }
 }
 
+template <int N>
+__device__ __forceinline__ void FlushAtomic(__bf16* dst, const float (&acc)[N]) {
+  static_assert(N % 2 == 0, "bf16 rows are split in multiples of 4 bytes");
+  typedef __bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+#pragma unroll
+  for (int e = 0; e < N; e += 2) {
+    bf16x2_t v;
+    v.x = static_cast<__bf16>(acc[e]);
+    v.y = static_cast<__bf16>(acc[e + 1]);
+    __builtin_amdgcn_global_atomic_fadd_v2bf16(
+        (__attribute__((address_space(1))) bf16x2_t*)(dst + e), v);  // generic -> global pointer
+  }
+}
+
 template <typename GradT, int N>
 __device__ __forceinline__ void FlushStore(GradT* dst, const float (&acc)[N]) {
   Pack<GradT, N> p;

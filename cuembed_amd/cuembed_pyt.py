@@ -32,7 +32,7 @@ _lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor off
 _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
             " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
 
-_FLOATS = (torch.float32, torch.float16)
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16)
 _INTS = (torch.int64, torch.int32)
 
 

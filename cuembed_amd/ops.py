@@ -19,7 +19,7 @@ from . import _lib
 
 SUM, MEAN, CONCAT = 0, 1, 2
 _MODES = {"sum": SUM, "mean": MEAN, "concat": CONCAT, SUM: SUM, MEAN: MEAN, CONCAT: CONCAT}
-_ELEM = {torch.float32: 0, torch.float16: 1}
+_ELEM = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _INDEX = {torch.int32: 0, torch.int64: 1}
 
 
@@ -44,7 +44,7 @@ def _check_dev(name, t, device=None):
 
 def _elem_code(name, t):
     if t.dtype not in _ELEM:
-        raise TypeError("%s must be float32 or float16, got %s" % (name, t.dtype))
+        raise TypeError("%s must be float32, float16 or bfloat16, got %s" % (name, t.dtype))
     return _ELEM[t.dtype]
 
 

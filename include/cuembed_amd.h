@@ -32,12 +32,13 @@
  *     NULL = the default stream) and returns immediately;
  *   - functions return void; violating the argument contract prints
  *     "Check failed: ..." on stderr and aborts the process;
- *   - fp16 data is IEEE binary16 (`__half`), passed as void pointers here;
+ *   - fp16 data is IEEE binary16 (`__half`), bf16 data is bfloat16 (`__hip_bfloat16`), both
+ *     passed as void pointers here;
  *   - Transpose / ComputeCompressedGradIndices are two-phase: call with
  *     work == NULL to receive the scratch size in *lwork, then again with a
  *     scratch buffer of at least that size.
  *
- * Suffix grammar:  _{f32|f16}  element type of table / gradient / weights
+ * Suffix grammar:  _{f32|f16|bf16}  element type of table / gradient / weights
  *                  _{i32|i64}  lookup-index and sample-id type
  *                  _{o32|o64}  CSR offset type
  * ==========================================================================*/
@@ -54,7 +55,7 @@ extern "C" {
 /* CombineMode values (reference: embedding_lookup_types.cuh:29). */
 enum { CUEMBED_SUM = 0, CUEMBED_MEAN = 1, CUEMBED_CONCAT = 2 };
 /* type codes for the generic (runtime-dispatched) entry points */
-enum { CUEMBED_F32 = 0, CUEMBED_F16 = 1 };
+enum { CUEMBED_F32 = 0, CUEMBED_F16 = 1, CUEMBED_BF16 = 2 /* extension */ };
 enum { CUEMBED_I32 = 0, CUEMBED_I64 = 1 };
 
 typedef void* cuembed_stream_t; /* hipStream_t */
@@ -77,6 +78,11 @@ CUEMBED_DECLARE_FORWARD(f16_i32_o32, void, int32_t, int32_t)
 CUEMBED_DECLARE_FORWARD(f16_i32_o64, void, int32_t, int64_t)
 CUEMBED_DECLARE_FORWARD(f16_i64_o32, void, int64_t, int32_t)
 CUEMBED_DECLARE_FORWARD(f16_i64_o64, void, int64_t, int64_t)
+/* bf16 tables (extension; fp32 accumulation, fp16_math ignored) */
+CUEMBED_DECLARE_FORWARD(bf16_i32_o32, void, int32_t, int32_t)
+CUEMBED_DECLARE_FORWARD(bf16_i32_o64, void, int32_t, int64_t)
+CUEMBED_DECLARE_FORWARD(bf16_i64_o32, void, int64_t, int32_t)
+CUEMBED_DECLARE_FORWARD(bf16_i64_o64, void, int64_t, int64_t)
 #undef CUEMBED_DECLARE_FORWARD
 
 /* ---- backward ----------------------------------------------------------- */
@@ -97,6 +103,8 @@ CUEMBED_DECLARE_BACKWARD(f32_i32, float, int32_t)
 CUEMBED_DECLARE_BACKWARD(f32_i64, float, int64_t)
 CUEMBED_DECLARE_BACKWARD(f16_i32, void, int32_t)
 CUEMBED_DECLARE_BACKWARD(f16_i64, void, int64_t)
+CUEMBED_DECLARE_BACKWARD(bf16_i32, void, int32_t)
+CUEMBED_DECLARE_BACKWARD(bf16_i64, void, int64_t)
 #undef CUEMBED_DECLARE_BACKWARD
 
 /* ---- transpose ---------------------------------------------------------- */
@@ -114,6 +122,8 @@ CUEMBED_DECLARE_TRANSPOSE(i32_f32, int32_t, float)
 CUEMBED_DECLARE_TRANSPOSE(i64_f32, int64_t, float)
 CUEMBED_DECLARE_TRANSPOSE(i32_f16, int32_t, void)
 CUEMBED_DECLARE_TRANSPOSE(i64_f16, int64_t, void)
+CUEMBED_DECLARE_TRANSPOSE(i32_bf16, int32_t, void)
+CUEMBED_DECLARE_TRANSPOSE(i64_bf16, int64_t, void)
 #undef CUEMBED_DECLARE_TRANSPOSE
 
 /* ---- compressed-gradient remap ------------------------------------------ */

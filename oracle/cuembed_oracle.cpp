@@ -32,6 +32,7 @@
 #include <numeric>
 #include <random>
 #include <set>
+#include <type_traits>
 #include <vector>
 
 #ifdef _OPENMP
@@ -112,10 +113,38 @@ inline h16 f2h(float f) {
 inline h16 hadd(h16 a, h16 b) { return f2h(h2f(a) + h2f(b)); }
 inline h16 hmul(h16 a, h16 b) { return f2h(h2f(a) * h2f(b)); }
 
+// bfloat16 storage (an extension of this library; the reference has no bf16): the upper 16
+// bits of a binary32, converted with round-to-nearest-even (what v_cvt_pk_bf16_f32 does).
+struct b16 {
+  uint16_t bits;
+};
+inline float b2f(b16 v) {
+  const uint32_t x = (uint32_t)v.bits << 16;
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+inline b16 f2b(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  b16 r;
+  if ((x & 0x7fffffffu) > 0x7f800000u) {  // NaN: keep it a NaN
+    r.bits = (uint16_t)((x >> 16) | 0x0040u);
+    return r;
+  }
+  x += 0x7fffu + ((x >> 16) & 1u);  // round to nearest, ties to even
+  r.bits = (uint16_t)(x >> 16);
+  return r;
+}
+
 // ---------------------------------------------------------------------------
-// Element traits: T is `float` or `h16` (storage type).
+// Element traits: T is `float`, `h16` or `b16` (storage type).
 // ---------------------------------------------------------------------------
 template <typename T> struct El;
+template <> struct El<b16> {
+  static float to_f(b16 v) { return b2f(v); }
+  static b16 from_f(float v) { return f2b(v); }
+};
 template <> struct El<float> {
   static float to_f(float v) { return v; }
   static float from_f(float v) { return v; }
@@ -150,7 +179,7 @@ void forward_impl(const T* params, int W, int B, int H, const IndexT* indices,
         }
         continue;
       }
-      if (kFp16Math && sizeof(T) == 2) {
+      if (kFp16Math && std::is_same<T, h16>::value) {
         // SumT = half (:59): every product and every partial sum is rounded
         // to fp16 (embedding_lookup_types.cuh:140-150, :269-291).
         h16 sum = 0;
@@ -211,7 +240,7 @@ void forward_dispatch(const void* params, int W, int B, int H,
   const OffsetT* off = (const OffsetT*)offsets;
   const T* w = (const T*)weights;
   T* r = (T*)ret;
-  const bool f16m = fp16_math && sizeof(T) == 2;
+  const bool f16m = fp16_math && std::is_same<T, h16>::value;
   if (threads <= 1) {
     if (f16m) forward_impl<T, IndexT, OffsetT, true>(p, W, B, H, idx, off, w, r, mode, 0, B);
     else forward_impl<T, IndexT, OffsetT, false>(p, W, B, H, idx, off, w, r, mode, 0, B);
@@ -252,24 +281,12 @@ void backward_impl(const T* grad_y, int W, int64_t num_rows, int64_t nnz,
     const int64_t row = t_remap ? (int64_t)t_remap[nz] : (int64_t)t_idx[nz];
     const int64_t sid = (int64_t)t_sid[nz];
     for (int e = 0; e < W; ++e) {
+      // product and sum are both rounded to GradT, like `grad += result_grad * weight`
+      // in GradT arithmetic (embedding_lookup_cpu.hpp:139-142)
       T& dst = grad[e + row * W];
-      const T g = grad_y[e + sid * W];
-      if (sizeof(T) == 2) {
-        h16 gv, dv, wv = 0x3c00;  // 1.0h
-        std::memcpy(&gv, &g, 2);
-        std::memcpy(&dv, &dst, 2);
-        if (t_w) std::memcpy(&wv, &t_w[nz], 2);
-        dv = hadd(dv, hmul(gv, wv));
-        std::memcpy(&dst, &dv, 2);
-      } else {
-        float gv, dv, wv = 1.0f;
-        std::memcpy(&gv, &g, 4);
-        std::memcpy(&dv, &dst, 4);
-        if (t_w) std::memcpy(&wv, &t_w[nz], 4);
-        const float p = gv * wv;
-        dv = dv + p;
-        std::memcpy(&dst, &dv, 4);
-      }
+      float p = El<T>::to_f(grad_y[e + sid * W]);
+      if (t_w) p = El<T>::to_f(El<T>::from_f(p * El<T>::to_f(t_w[nz])));
+      dst = El<T>::from_f(El<T>::to_f(dst) + p);
     }
   }
 }
@@ -403,7 +420,7 @@ int64_t gen_indices_impl(int64_t num_categories, int B, int H, double alpha,
 }  // namespace
 
 // ===========================================================================
-// C interface (ctypes).  type codes: elem 0 = f32, 1 = f16;
+// C interface (ctypes).  type codes: elem 0 = f32, 1 = f16, 2 = bf16 (bits in uint16);
 // index/offset 0 = int32, 1 = int64.  Return 0 on success, -1 on a contract
 // violation (the reference CHECK-fails / aborts in those cases).
 // ===========================================================================
@@ -432,6 +449,10 @@ int oracle_embedding_forward(const void* params, int elem_type, int embed_width,
     case 5: FWD(h16, int32_t, int64_t); break;
     case 6: FWD(h16, int64_t, int32_t); break;
     case 7: FWD(h16, int64_t, int64_t); break;
+    case 8: FWD(b16, int32_t, int32_t); break;
+    case 9: FWD(b16, int32_t, int64_t); break;
+    case 10: FWD(b16, int64_t, int32_t); break;
+    case 11: FWD(b16, int64_t, int64_t); break;
     default: return -1;
   }
 #undef FWD
@@ -455,6 +476,8 @@ int oracle_embedding_backward(const void* grad_y, int elem_type,
     case 1: BWD(float, int64_t); break;
     case 2: BWD(h16, int32_t); break;
     case 3: BWD(h16, int64_t); break;
+    case 4: BWD(b16, int32_t); break;
+    case 5: BWD(b16, int64_t); break;
     default: return -1;
   }
 #undef BWD
@@ -469,7 +492,7 @@ int oracle_transpose(const void* rows, const void* cols, const void* weights,
 #define TR(I, W)                                                           \
   transpose_impl<I, W>((const I*)rows, (const I*)cols, (const W*)weights,  \
                        nnz, (I*)t_rows, (I*)t_cols, (W*)t_weights, !stable)
-  switch (index_type * 2 + weight_type) {
+  switch (index_type * 2 + (weight_type != 0 ? 1 : 0)) {  // 2-byte weights are only moved
     case 0: TR(int32_t, float); break;
     case 1: TR(int32_t, h16); break;
     case 2: TR(int64_t, float); break;
@@ -645,6 +668,7 @@ int oracle_allocate_grad_y(int64_t count, int elem_type, void* grad_y) {
 }
 
 // conversions exposed for tests (checked against numpy.float16)
+uint16_t oracle_f2b(float f) { return f2b(f).bits; }
 uint16_t oracle_f2h(float f) { return f2h(f); }
 float oracle_h2f(uint16_t h) { return h2f(h); }
 

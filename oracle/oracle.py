@@ -64,7 +64,20 @@ def _etype(a):
         return 0
     if a.dtype == np.float16:
         return 1
-    raise TypeError("element type must be float32 or float16, got %s" % a.dtype)
+    if a.dtype == np.uint16:      # bfloat16 bit patterns (numpy has no bf16 dtype)
+        return 2
+    raise TypeError("element type must be float32, float16 or uint16 (bf16 bits), got %s" % a.dtype)
+
+
+def to_bf16_bits(a):
+    """float32 array -> bfloat16 bit patterns (uint16), round-to-nearest-even."""
+    x = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((x + 0x7fff + ((x >> 16) & 1)) >> 16).astype(np.uint16)
+    return r.reshape(np.shape(a))
+
+
+def from_bf16_bits(b):
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(b))
 
 
 def _itype(a):
