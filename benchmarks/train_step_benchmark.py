@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: fp16 forward + backward on a batch sharded over the GPUs of one node, table
+replicated, gradient combined over RCCL (xGMI).  One process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port 29500 benchmarks/train_step_benchmark.py --exchange sparse
+
+One step on every rank = EmbeddingForward on its 65,536-sample shard, row-id extraction, Transpose
+(index_bits from the table size), ComputeCompressedGradIndices, EmbeddingBackward into a compressed
+gradient, then the exchange:
+  sparse : all-gather of the compressed rows + local merge (~293 MB per rank at this shape)
+  dense  : scatter into the dense table gradient + RCCL all-reduce (5.12 GB per rank)
+  none   : no exchange (upper bound / single GPU)
+Rank 0 prints one JSON line with the step time (max over ranks) and its breakdown."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=10_000_000)
+    p.add_argument("--width", type=int, default=256)
+    p.add_argument("--batch", type=int, default=65536, help="samples per GPU")
+    p.add_argument("--hotness", type=int, default=64)
+    p.add_argument("--alpha", type=float, default=1.15)
+    p.add_argument("--exchange", default="sparse", choices=["sparse", "dense", "none"])
+    a = p.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cuembed_amd as ce
+    from cuembed_amd import distributed as D
+    from cuembed_amd import harness
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 or "MASTER_ADDR" in os.environ:
+        dist.init_process_group("nccl", device_id=dev)
+    use_dist = dist.is_initialized()
+    B, H, W = a.batch, a.hotness, a.width
+    table = torch.empty((a.rows, W), dtype=torch.float16, device=dev).uniform_(-1, 1)
+    idx_all = harness.generate_indices(a.rows, world * B, H, alpha=a.alpha)
+    idx = torch.from_numpy(np.ascontiguousarray(idx_all.reshape(world, B * H)[rank])).to(dev)
+    gy = torch.from_numpy(harness.allocate_grad_y(B * W, np.float16).reshape(B, W)).to(dev)
+    out = torch.empty((B, W), dtype=torch.float16, device=dev)
+    nnz = B * H
+    work = torch.empty(max(ce.transpose_workspace_bytes(nnz, torch.int32), 1), dtype=torch.uint8, device=dev)
+    dense = torch.zeros((a.rows, W), dtype=torch.float16, device=dev) if a.exchange == "dense" else None
+    names = ["forward", "transpose", "backward", "exchange"]
+
+    def step(ev):
+        ev[0].record()
+        ce.embedding_forward(table, idx, num_hots=H, out=out)
+        ev[1].record()
+        sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, dev)
+        t_idx, t_sid, _ = ce.transpose(sid, idx, workspace=work, num_categories=a.rows)
+        remap = ce.compute_compressed_grad_indices(t_idx)
+        nu = int(remap[-1].item()) + 1          # host read-back, as in the reference's benchmark
+        ev[2].record()
+        if a.exchange == "dense":
+            ce.embedding_backward(gy, a.rows, t_idx, t_sid, skip_grad_init=False, grad_embedding=dense)
+            ev[3].record()
+            if use_dist:
+                D.allreduce_dense_grad(dense)
+        else:
+            rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
+            ev[3].record()
+            if a.exchange == "sparse" and use_dist:
+                D.allreduce_sparse_grad(rows, inv, a.rows)
+        ev[4].record()
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step([torch.cuda.Event(enable_timing=True) for _ in range(5)])
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        step(events[s])
+    sync()
+    wall = time.perf_counter() - t0
+    parts = {n: sum(e[i].elapsed_time(e[i + 1]) for e in events) / a.steps for i, n in enumerate(names)}
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ms = float(t.item()) / a.steps * 1e3
+        print(json.dumps({"workload": "fp16 fwd+bwd, %dx%d table, batch %d per GPU x %d GPUs, hotness %d, alpha %g"
+                                      % (a.rows, W, B, world, H, a.alpha),
+                          "exchange": a.exchange, "n_gpus": world, "ms_per_step": round(ms, 4),
+                          "samples_per_s": round(world * B / (ms * 1e-3)),
+                          "breakdown_ms": {k: round(v, 4) for k, v in parts.items()}}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
