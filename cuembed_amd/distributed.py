@@ -47,6 +47,21 @@ def allreduce_dense_grad(grad_embedding, group=None, async_op=False):
     return dist.all_reduce(grad_embedding, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def _merge_on_gpu(ids, vals, num_categories):
+    """Sum rows that carry the same id with the library's own kernels: the merge of the gathered
+    (id, row) pairs IS an embedding backward -- Transpose sorts the ids (carrying the position of
+    each row), ComputeCompressedGradIndices numbers the distinct ids, and EmbeddingBackward adds
+    the rows of each run (fp32 partial sums) into the compressed result."""
+    from . import ops
+    m = ids.numel()
+    pos = ops.extract_row_ids_for_concat(m, torch.int64, ids.device)
+    t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories)
+    remap = ops.compute_compressed_grad_indices(t_ids)
+    num_unique = int(remap[-1].item()) + 1
+    merged, uniq = ops.embedding_backward(vals.contiguous(), num_unique, t_ids, t_pos, remap)
+    return uniq, merged
+
+
 def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None):
     """Sum compressed gradients across ranks without materialising the dense table gradient.
 
@@ -74,6 +89,8 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None):
     dist.all_gather(all_ids, pad_ids, group=group)
     ids = torch.cat([all_ids[r][: counts[r]] for r in range(world)])
     vals = torch.cat([all_rows[r][: counts[r]] for r in range(world)])
+    if vals.is_cuda:
+        return _merge_on_gpu(ids, vals, num_categories)
     uniq, inverse = torch.unique(ids, sorted=True, return_inverse=True)
     summed = torch.zeros((uniq.numel(), width), dtype=torch.float32, device=rows.device)
     summed.index_add_(0, inverse, vals.float())
