@@ -221,3 +221,25 @@ def test_forward_split_hotness_small_batch(ce, oracle, elem, fp16_math, rtol, W)
     want = oracle.embedding_forward(table, idx.ravel(), num_hots=H, fp16_math=fp16_math)
     got = ce.embedding_forward(dev(table), dev(idx.ravel()), num_hots=H, fp16_math=fp16_math)
     assert (bits(got.cpu().numpy()) == bits(want)).all()
+
+
+@pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
+@pytest.mark.parametrize("W,B", [(128, 40003), (32, 140000)], ids=["w128", "w32"])
+def test_forward_csr_length_balanced_large_batch(ce, oracle, elem, W, B):
+    """Large CSR batches take the length-balanced kernel (workgroups walk their samples in
+    bag-length order); every sample is still pooled in lookup order -> bit-exact.  Bag lengths
+    are deliberately skewed (many empty, a few long) and the batch is not a multiple of the
+    workgroup's chunk."""
+    rng = np.random.default_rng(B)
+    lens = rng.integers(0, 33, B)
+    lens[rng.integers(0, B, B // 7)] = 0
+    lens[rng.integers(0, B, 50)] = rng.integers(100, 400, 50)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(off[-1])
+    table = rng.uniform(-1, 1, (3000, W)).astype(elem[0])
+    idx = rng.integers(0, 3000, nnz).astype(np.int32)
+    w = rng.uniform(0, 1, nnz).astype(elem[0])
+    for mode, weights in [("sum", None), ("sum", w), ("mean", None), ("mean", w)]:
+        want = oracle.embedding_forward(table, idx, off, weights, num_hots=0, mode=mode, threads=8)
+        got = ce.embedding_forward(dev(table), dev(idx), dev(off), dev(weights), num_hots=0, mode=mode)
+        assert (bits(got.cpu().numpy()) == bits(want)).all(), mode
