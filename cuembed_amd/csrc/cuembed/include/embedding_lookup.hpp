@@ -165,20 +165,6 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
     return;
   }
   const dim3 block(f.split.lanes_per_row, f.split.rows_per_block, 1);
-  // CSR with whole sample groups inside a wavefront and enough samples to keep the chip busy
-  // with 8x fewer workgroups: walk each workgroup's samples in bag-length order.
-  if (offsets != nullptr && 64 % lanes == 0 && f.split.rows_per_block * kCsrRounds <= kCsrMaxChunk &&
-      static_cast<int64_t>(batch) >= static_cast<int64_t>(f.split.rows_per_block) * kCsrRounds * 512) {
-    const int chunk = f.split.rows_per_block * kCsrRounds;
-    const dim3 bgrid((batch + chunk - 1) / chunk, 1, 1);
-    if (weighted)
-      GatherReduceCsrBalancedKernel<ElemT, AccT, IndexT, OffsetT, N, true><<<bgrid, block, 0, stream>>>(
-          table, width, batch, indices, offsets, weights, is_mean, out);
-    else
-      GatherReduceCsrBalancedKernel<ElemT, AccT, IndexT, OffsetT, N, false><<<bgrid, block, 0, stream>>>(
-          table, width, batch, indices, offsets, weights, is_mean, out);
-    return;
-  }
   const dim3 grid(f.grid, 1, 1);
 #define CUEMBED_LAUNCH_GR(W, SRC)                                                         \
   GatherReduceKernel<ElemT, AccT, IndexT, OffsetT, N, W, SRC>                             \

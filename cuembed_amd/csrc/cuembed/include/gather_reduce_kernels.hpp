@@ -175,11 +175,27 @@ struct RowPool {
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) Add(row[u], w[u]);
     }
-    for (; j < count; ++j) {
-      const int64_t r = index_at(j);
-      ElemT w = static_cast<ElemT>(0);
-      if constexpr (kWeighted) w = weight_at(j);
-      Add(LoadPack<ElemT, N>(lane_base + r * width), w);
+    // Tail (< kUnroll lookups): still ONE batch -- all remaining loads are issued together
+    // under a predicate instead of one exposed memory latency per leftover row (bags whose
+    // length is not a multiple of kUnroll, i.e. almost every CSR bag, would otherwise spend a
+    // third of their time there).
+    const int rem = count - j;
+    if (rem > 0) {
+      Pack<ElemT, N> row[kUnroll];
+      ElemT w[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll - 1; ++u) {
+        if (u < rem) {
+          const int64_t r = index_at(j + u);
+          if constexpr (kWeighted) w[u] = weight_at(j + u);
+          row[u] = LoadPack<ElemT, N>(lane_base + r * width);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kUnroll - 1; ++u) {
+        if (u < rem) Add(row[u], w[u]);
+      }
     }
   }
 };
@@ -308,106 +324,6 @@ GatherReduceKernel(const ElemT* __restrict__ table,
 #pragma unroll
   for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
   StorePack<ElemT, N>(out + sample * width + column0, result);
-}
-
-// ---------------------------------------------------------------------------
-// Sum / mean for CSR batches, length-balanced.
-//   block = (lanes_per_row, samples_per_block) with lanes_per_row | 64;
-//   grid = ceil(batch / (samples_per_block * kCsrRounds)).
-// Two samples share a 64-lane wavefront, so the wave runs as long as the LONGER of its two
-// bags: with hotness uniform on [0, 128] that alone costs a third of the throughput
-// (E[max] = 85 vs mean 64).  Here a workgroup owns samples_per_block * kCsrRounds consecutive
-// samples, ranks them by bag length in LDS (a 64-element counting rank, a few dozen
-// instructions) and walks them in that order: the two halves of every wave, and all waves of a
-// round, then pool bags of neighbouring length.  Each sample is still pooled by the same
-// lanes in lookup order, so results stay bit-identical.
-// ---------------------------------------------------------------------------
-constexpr int kCsrRounds = 8;
-constexpr int kCsrMaxChunk = 1024;  // samples_per_block (<= 64 here) * kCsrRounds
-
-template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N, bool kWeighted>
-__global__ void __launch_bounds__(kMaxBlockThreads)
-GatherReduceCsrBalancedKernel(const ElemT* __restrict__ table,
-                              const int width,
-                              const int batch,
-                              const IndexT* __restrict__ indices,
-                              const OffsetT* __restrict__ offsets,
-                              const ElemT* __restrict__ weights,
-                              const bool is_mean,
-                              ElemT* __restrict__ out) {
-  using A = Arith<AccT>;
-  __shared__ int bag_len[kCsrMaxChunk];
-  __shared__ unsigned short order[kCsrMaxChunk];
-  const int lane_x = threadIdx.x;
-  const int slot = threadIdx.y;
-  const int group = blockDim.x;
-  const int samples_per_block = blockDim.y;
-  const int chunk = samples_per_block * kCsrRounds;
-  const int64_t first = static_cast<int64_t>(blockIdx.x) * chunk;
-  const int count = static_cast<int>(batch - first < chunk ? batch - first : chunk);
-  const int tid = slot * group + lane_x;
-  const int nthreads = group * samples_per_block;
-
-  for (int s = tid; s < count; s += nthreads)
-    bag_len[s] = static_cast<int>(static_cast<int64_t>(offsets[first + s + 1]) -
-                                  static_cast<int64_t>(offsets[first + s]));
-  __syncthreads();
-  // rank by (length descending, position ascending): long bags first, so the tail of the
-  // workgroup's life is filled with short ones
-  for (int s = tid; s < count; s += nthreads) {
-    const int mine = bag_len[s];
-    int rank = 0;
-    for (int t = 0; t < count; ++t) {
-      const int other = bag_len[t];
-      rank += (other > mine) || (other == mine && t < s);
-    }
-    order[rank] = static_cast<unsigned short>(s);
-  }
-  __syncthreads();
-
-  const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
-  for (int round = 0; round < kCsrRounds; ++round) {
-    const int r = round * samples_per_block + slot;
-    if (r >= count) break;
-    const int64_t sample = first + order[r];
-    const int64_t begin = static_cast<int64_t>(offsets[sample]);
-    const int hot = bag_len[order[r]];
-    const IndexT* my_idx = indices + begin;
-    const ElemT* my_w = weights + begin;
-    RowPool<ElemT, AccT, N, kWeighted> pool;
-    IndexT cur_i = static_cast<IndexT>(0);
-    ElemT cur_w = static_cast<ElemT>(0);
-    if (lane_x < hot) {
-      cur_i = my_idx[lane_x];
-      if constexpr (kWeighted) cur_w = my_w[lane_x];
-    }
-    for (int c = 0; c < hot; c += group) {
-      IndexT next_i = static_cast<IndexT>(0);
-      ElemT next_w = static_cast<ElemT>(0);
-      if (c + group + lane_x < hot) {
-        next_i = my_idx[c + group + lane_x];
-        if constexpr (kWeighted) next_w = my_w[c + group + lane_x];
-      }
-      const int n = (hot - c < group) ? hot - c : group;
-      pool.template Gather<kForwardUnroll, false>(
-          lane_base, width, n, [&](int j) { return static_cast<int64_t>(__shfl(cur_i, j, group)); },
-          [&](int j) { return ShuffleElem(cur_w, j, group); });
-      cur_i = next_i;
-      cur_w = next_w;
-    }
-    if (is_mean) {
-      float weight_sum = pool.weight_sum;
-      if constexpr (!kWeighted) weight_sum = static_cast<float>(hot);
-      const float inv = (weight_sum == 0.f) ? 0.f : 1.0f / weight_sum;
-      const AccT scale = static_cast<AccT>(inv);
-#pragma unroll
-      for (int e = 0; e < N; ++e) pool.acc[e] = A::mul(pool.acc[e], scale);
-    }
-    Pack<ElemT, N> result;
-#pragma unroll
-    for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
-    StorePack<ElemT, N>(out + sample * width + static_cast<int64_t>(lane_x) * N, result);
-  }
 }
 
 // ---------------------------------------------------------------------------

@@ -225,11 +225,9 @@ def test_forward_split_hotness_small_batch(ce, oracle, elem, fp16_math, rtol, W)
 
 @pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
 @pytest.mark.parametrize("W,B", [(128, 40003), (32, 140000)], ids=["w128", "w32"])
-def test_forward_csr_length_balanced_large_batch(ce, oracle, elem, W, B):
-    """Large CSR batches take the length-balanced kernel (workgroups walk their samples in
-    bag-length order); every sample is still pooled in lookup order -> bit-exact.  Bag lengths
-    are deliberately skewed (many empty, a few long) and the batch is not a multiple of the
-    workgroup's chunk."""
+def test_forward_csr_skewed_bags_large_batch(ce, oracle, elem, W, B):
+    """Large CSR batches with deliberately skewed bag lengths (many empty, a few of several
+    hundred lookups, lengths that are not multiples of the load batch): bit-exact."""
     rng = np.random.default_rng(B)
     lens = rng.integers(0, 33, B)
     lens[rng.integers(0, B, B // 7)] = 0
