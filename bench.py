@@ -48,7 +48,9 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     p.add_argument("--alpha", type=float, default=None, help="override the workload's alpha")
-    p.add_argument("--index-batches", type=int, default=4, help="distinct index batches cycled through")
+    p.add_argument("--index-batches", type=int, default=0,
+                   help="distinct index batches cycled through (default: 4, or 2 with more than 2 GPUs "
+                        "because every rank walks the whole generator stream)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the cold-cache and alpha=0 companions")
     p.add_argument("--cold-iters", type=int, default=20)
@@ -133,7 +135,7 @@ def main():
 
     ce._lib.lib()  # fail loudly if the HIP library is absent
     table = fill_table(torch, cfg["rows"], W, tdtype, device, seed=1234 + rank)
-    nb = max(1, args.index_batches)
+    nb = args.index_batches if args.index_batches > 0 else (4 if world <= 2 else 2)
     host_batches = make_batches(harness, np, cfg, alpha, nb, rank, world, np.int32)
     dev_batches = []
     for hb in host_batches:

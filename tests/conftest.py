@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """A fresh checkout has no binaries (they are git-ignored): build the HIP library and the
+    harness library once per session (a no-op taking ~2 s when they are up to date).  hipcc
+    cross-compiles for gfx950 without a GPU."""
+    import shutil
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        from cuembed_amd import build
+        build.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
