@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <iostream>
 
 #include "cuembed_amd.h"
 

@@ -62,50 +62,6 @@ ExpandCsrKernel(const OffsetT* __restrict__ offsets, const int batch, IndexT* __
   }
 }
 
-//! (sample id, weight) travelling together as the VALUE of the radix sort of a weighted
-//! transpose (the reference's WeightTuple, index_transforms_kernels.cuh:50-54).
-template <typename IndexT, typename WeightT>
-struct alignas(sizeof(IndexT) >= 8 ? 8 : 4) IdWeight {
-  IndexT id;
-  WeightT weight;
-};
-
-template <typename IndexT, typename WeightT>
-__global__ void PackIdWeightKernel(const IndexT* __restrict__ ids,
-                                   const WeightT* __restrict__ weights,
-                                   const int64_t count,
-                                   IdWeight<IndexT, WeightT>* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  IdWeight<IndexT, WeightT> t;
-  t.id = ids[i];
-  t.weight = weights[i];
-  out[i] = t;
-}
-
-template <typename IndexT, typename WeightT>
-__global__ void UnpackIdWeightKernel(const IdWeight<IndexT, WeightT>* __restrict__ in,
-                                     const int64_t count,
-                                     IndexT* __restrict__ ids,
-                                     WeightT* __restrict__ weights) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const IdWeight<IndexT, WeightT> t = in[i];
-  ids[i] = t.id;
-  weights[i] = t.weight;
-}
-
-//! flag(i) = 1 when lookup i starts a new run of equal indices, 0 for i == 0
-//! (reference: FlagNonzero + the memset of element 0, index_transforms.cuh
-//! :252-257, :307-315).  Used as a transform iterator feeding the scan.
-template <typename IndexT>
-struct RunHeadFlag {
-  const IndexT* indices;
-  __host__ __device__ __forceinline__ IndexT operator()(size_t i) const {
-    return (i > 0 && indices[i] != indices[i - 1]) ? IndexT(1) : IndexT(0);
-  }
-};
-
 }  // namespace detail
 }  // namespace cuembed
 

@@ -21,13 +21,8 @@
 #include <cstring>
 #include <type_traits>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/functional.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
 #include "cuembed/include/index_kernels.hpp"
+#include "cuembed/include/radix_sort_kernels.hpp"
 
 namespace cuembed {
 
@@ -115,67 +110,45 @@ void Transpose(const IndexT* rows,
                const hipStream_t stream = 0,
                const int index_bits = static_cast<int>(sizeof(IndexT) * 8)) {
   using KeyT = typename std::make_unsigned<IndexT>::type;  // ids are non-negative
-  const unsigned int begin_bit = 0;
-  const unsigned int end_bit =
-      (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
-          ? static_cast<unsigned int>(index_bits)
-          : static_cast<unsigned int>(sizeof(IndexT) * 8);
+  const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
+                           ? index_bits
+                           : static_cast<int>(sizeof(IndexT) * 8);
   const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
   const KeyT* keys_in = reinterpret_cast<const KeyT*>(cols);
   KeyT* keys_out = reinterpret_cast<KeyT*>(transpose_rows);
 
   if (weights == nullptr) {
-    // keys = lookup index, values = sample id: one radix sort does it all.
-    size_t sort_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_in, keys_out, rows, transpose_cols,
-                                    n, begin_bit, end_bit, stream);
+    // keys = lookup index, payload = sample id
+    const detail::RadixSortPlan<KeyT, IndexT, detail::NoPayload> plan(n, key_bits);
     if (work == nullptr) {
-      *lwork = sort_bytes;
+      *lwork = plan.total;
       return;
     }
-    assert(*lwork >= sort_bytes);
-    if (n == 0) return;
-    (void)rocprim::radix_sort_pairs(work, sort_bytes, keys_in, keys_out, rows, transpose_cols, n,
-                                    begin_bit, end_bit, stream);
+    assert(*lwork >= plan.total);
+    detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
+        keys_in, keys_out, rows, transpose_cols, nullptr, nullptr, n, key_bits, work, stream);
     return;
   }
-
-  // Weighted: (sample id, weight) ride through the sort as one packed value, like the
-  // reference's WeightTuple (index_transforms.cuh:139-200): pack -> sort -> unpack, all
-  // streaming.  (Sorting positions and gathering through them was measured 3x slower: the
-  // 4-byte random gathers waste most of every cache line.)
-  using ValueT = detail::IdWeight<IndexT, WeightT>;
-  const size_t val_bytes = detail::AlignUp(n * sizeof(ValueT), 256);
-  size_t sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_in, keys_out,
-                                  static_cast<const ValueT*>(nullptr), static_cast<ValueT*>(nullptr),
-                                  n, begin_bit, end_bit, stream);
-  const size_t required = 2 * val_bytes + sort_bytes;
+  // weighted: sample id AND weight move with the key as two payload arrays (the reference
+  // packs them into a struct before the sort and unpacks it afterwards,
+  // index_transforms.cuh:139-200)
+  const detail::RadixSortPlan<KeyT, IndexT, WeightT> plan(n, key_bits);
   if (work == nullptr) {
-    *lwork = required;
+    *lwork = plan.total;
     return;
   }
-  assert(*lwork >= required);
-  if (n == 0) return;
-  ValueT* vals_in = reinterpret_cast<ValueT*>(work);
-  ValueT* vals_out = reinterpret_cast<ValueT*>(work + val_bytes);
-  void* sort_work = work + 2 * val_bytes;
-
-  const int threads = detail::kIndexBlockThreads;
-  const unsigned blocks = static_cast<unsigned>((nnz + threads - 1) / threads);
-  detail::PackIdWeightKernel<IndexT, WeightT>
-      <<<blocks, threads, 0, stream>>>(rows, weights, nnz, vals_in);
-  (void)rocprim::radix_sort_pairs(sort_work, sort_bytes, keys_in, keys_out, vals_in, vals_out, n,
-                                  begin_bit, end_bit, stream);
-  detail::UnpackIdWeightKernel<IndexT, WeightT>
-      <<<blocks, threads, 0, stream>>>(vals_out, nnz, transpose_cols, transpose_weights);
+  assert(*lwork >= plan.total);
+  detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, rows, transpose_cols, weights,
+                                                transpose_weights, n, key_bits, work, stream);
 }
 
 /**
  * @brief Map sorted lookup indices to dense ids 0..num_unique-1:
  * indices = [4, 4, 7, 8, 8, 8, 18] -> remapped_indices = [0, 0, 1, 2, 2, 2, 3].
  * (num_unique = remapped_indices[nnz - 1] + 1, read back by the caller.)
- * One fused pass: an inclusive scan over run-head flags generated on the fly.
+ * Run-head flags are generated on the fly and scanned over 4096-element tiles (count, scan
+ * of the tile counts, scan inside the tiles); the reference runs cub adjacent-difference, a
+ * memset and an inclusive scan (index_transforms.cuh:285-322).
  * Two-phase workspace query as for Transpose().
  */
 template <typename IndexT>
@@ -186,19 +159,13 @@ void ComputeCompressedGradIndices(const IndexT* indices,
                                   size_t* lwork,
                                   const hipStream_t stream = 0) {
   const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
-  auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0),
-                                                detail::RunHeadFlag<IndexT>{indices});
-  size_t scan_bytes = 0;
-  (void)rocprim::inclusive_scan(nullptr, scan_bytes, flags, remapped_indices, n,
-                                rocprim::plus<IndexT>(), stream);
+  const size_t need = detail::RunHeadScanWorkBytes(n);
   if (work == nullptr) {
-    *lwork = scan_bytes;
+    *lwork = need;
     return;
   }
-  assert(*lwork >= scan_bytes);
-  if (n == 0) return;
-  (void)rocprim::inclusive_scan(work, scan_bytes, flags, remapped_indices, n,
-                                rocprim::plus<IndexT>(), stream);
+  assert(*lwork >= need);
+  detail::RunHeadScan<IndexT>(indices, n, remapped_indices, work, stream);
 }
 
 }  // namespace cuembed
