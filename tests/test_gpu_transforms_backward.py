@@ -273,3 +273,26 @@ def test_backward_million_lookups_default_heuristics(ce, oracle):
     want, _ = oracle.embedding_backward(gy, W, ncat, ti, ts)
     got, _ = ce.embedding_backward(dev(gy), ncat, dev(ti), dev(ts))
     assert np.array_equal(host(got), want)
+
+
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_tile_boundaries_and_degenerate_keys(ce, oracle, idx):
+    """The hand-written radix sort works on 4096-key tiles with 64-key wave rounds: sizes around
+    those boundaries, all-equal keys (every key of a tile in one bin), already sorted and reverse
+    sorted keys, the largest representable key, and remap on the results."""
+    rng = np.random.default_rng(1)
+    big = np.iinfo(idx[0]).max
+    for nnz in (1, 63, 64, 65, 4095, 4096, 4097, 8191, 8192 + 17, 3 * 4096):
+        for name, cols in [("equal", np.full(nnz, 7)), ("sorted", np.arange(nnz)),
+                           ("reverse", np.arange(nnz)[::-1].copy()), ("two", rng.integers(0, 2, nnz)),
+                           ("huge", rng.integers(big - 5, big, nnz, endpoint=True)),
+                           ("random", rng.integers(0, 1 << 20, nnz))]:
+            cols = cols.astype(idx[0])
+            rows = rng.integers(0, 100, nnz).astype(idx[0])
+            w = rng.uniform(0, 1, nnz).astype(np.float16)
+            oi, os_, ow = oracle.transpose(rows, cols, w, stable=True)
+            ti, ts, tw = ce.transpose(dev(rows), dev(cols), dev(w))
+            assert np.array_equal(host(ti), oi) and np.array_equal(host(ts), os_), (nnz, name)
+            assert np.array_equal(host(tw).view(np.uint16), ow.view(np.uint16)), (nnz, name)
+            assert np.array_equal(host(ce.compute_compressed_grad_indices(ti)),
+                                  oracle.compute_compressed_grad_indices(oi)), (nnz, name)
