@@ -121,12 +121,21 @@ def main():
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One GPU per rank (RCCL).  If there are fewer GPUs than ranks -- only ever the case when the
+    # multi-rank code path is being smoke-tested on a single-GPU box -- ranks share GPUs and the
+    # tiny timing reductions go over gloo instead (RCCL refuses two ranks on one device).
+    ngpu = torch.cuda.device_count()
+    shared_gpus = world > ngpu
+    device = torch.device("cuda", local_rank % ngpu)
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if shared_gpus:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
+    reduce_device = torch.device("cpu") if shared_gpus else device
 
     cfg = dict(WORKLOADS[args.workload])
     alpha = cfg["alpha"] if args.alpha is None else args.alpha
@@ -171,8 +180,8 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
     step_bytes = sum(bytes_per_step[t % nb] for t in range(args.steps))
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=device)
-    bytes_t = torch.tensor([float(step_bytes)], dtype=torch.float64, device=device)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=reduce_device)
+    bytes_t = torch.tensor([float(step_bytes)], dtype=torch.float64, device=reduce_device)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(bytes_t, op=dist.ReduceOp.SUM)
@@ -197,6 +206,7 @@ def main():
         "config": {"workload": cfg["desc"], "name": args.workload, "alpha": alpha,
                    "global_batch": world * B, "per_gpu_batch": B, "index_dtype": "int32",
                    "index_batches_cycled": nb, "parallelism": "batch-shard x%d, table replicated" % world,
+                   "ranks_share_gpus": shared_gpus,
                    "algorithmic_bytes_per_step_per_gpu": bytes_per_step[0]},
         "pct_of_hbm_peak": round(100.0 * total_bytes / wall_max / 1e9 / (HBM_PEAK_GBPS * world), 2),
         "roofline": {"bound": "hbm", "kernel": "GatherReduceKernel", "achieved": round(achieved, 2),
