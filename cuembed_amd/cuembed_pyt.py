@@ -27,6 +27,10 @@ _lib.define("cuembed_compute_compressed_grad_indices(Tensor transpose_indices) -
 _lib.define("cuembed_embedding_backward_compressed(Tensor y_grad, int num_unique, Tensor transpose_indices,"
             " Tensor transpose_sample_ids, Tensor transpose_remapped_indices, Tensor transpose_weights)"
             " -> (Tensor, Tensor)")
+# Fixed-hotness (2-D index tensor) forward with every combine mode of the C++ API
+# (the reference binding only exposes CSR + sum, cuembed_embedding.cu:29-32).
+_lib.define("cuembed_embedding_forward_fixed(Tensor params, Tensor indices, Tensor weights, str mode)"
+            " -> Tensor")
 _lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor offsets, Tensor weights,"
             " str mode) -> Tensor")
 _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
@@ -97,6 +101,20 @@ def _backward_impl(y_grad, num_categories, transpose_indices, transpose_sample_i
     return grad
 
 
+def _forward_fixed_impl(params, indices, weights, mode):
+    _require(params.is_cuda and indices.is_cuda, "tensors must be on the GPU")
+    _require(params.dtype in _FLOATS and indices.dtype in _INTS, "unsupported dtypes")
+    _require(indices.dim() == 2, "indices must be [batch, hotness]")
+    _require(mode in ("sum", "mean", "concat"), "mode must be 'sum', 'mean' or 'concat'")
+    batch, hot = indices.shape
+    if weights is not None:
+        _require(weights.dtype == params.dtype and weights.shape == indices.shape,
+                 "weights must match indices in shape and params in dtype")
+        weights = weights.contiguous().view(-1)
+    return _ops.embedding_forward(params.contiguous(), indices.contiguous().view(-1), None, weights,
+                                  batch_size=batch, num_hots=hot, mode=mode)
+
+
 def _compress_impl(transpose_indices):
     _require(transpose_indices.is_cuda and transpose_indices.dtype in _INTS, "indices must be int tensors on the GPU")
     return _ops.compute_compressed_grad_indices(transpose_indices.contiguous())
@@ -114,6 +132,7 @@ def _backward_compressed_impl(y_grad, num_unique, transpose_indices, transpose_s
     return grad, inv
 
 
+_lib.impl("cuembed_embedding_forward_fixed", _forward_fixed_impl, "CUDA")
 _lib.impl("cuembed_compute_compressed_grad_indices", _compress_impl, "CUDA")
 _lib.impl("cuembed_embedding_backward_compressed", _backward_compressed_impl, "CUDA")
 _lib.impl("cuembed_embedding_forward", _forward_impl, "CUDA")
@@ -193,7 +212,53 @@ def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False):
     return _CuEmbEmbedding.apply(params, idx, offsets, weights, sparse_grad)
 
 
+class _CuEmbFixed(torch.autograd.Function):
+    """Fixed-hotness lookup: indices [B, H]; mode sum / mean -> [B, W], concat -> [B, H, W]."""
+
+    @staticmethod
+    def forward(ctx, params, idx, weights, mode):
+        ctx.save_for_backward(idx, weights)
+        ctx.num_categories = params.size(0)
+        ctx.mode = mode
+        return torch.ops.cuembed_pyt.cuembed_embedding_forward_fixed(params, idx, weights, mode)
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        idx, weights = ctx.saved_tensors
+        batch, hot = idx.shape
+        flat = idx.contiguous().view(-1)
+        if ctx.mode == "concat":   # every lookup has its own gradient row
+            y = out_grad.reshape(batch * hot, -1)
+            sample_ids = _ops.extract_row_ids_for_concat(batch * hot, flat.dtype, flat.device)
+        else:
+            y = out_grad if ctx.mode == "sum" else out_grad * (1.0 / hot)
+            sample_ids = _ops.extract_row_ids_from_fixed(batch, hot, flat.dtype, flat.device)
+        w = None if weights is None else weights.contiguous().view(-1)
+        if ctx.mode == "mean" and w is not None:      # out = sum(w x) / sum(w)
+            y = out_grad / weights.sum(1, keepdim=True).to(out_grad.dtype)
+        t_idx, t_sid, t_w = cuembed_transpose_bounded(sample_ids, flat, w, ctx.num_categories)
+        if t_w.numel() == 0:
+            t_w = None
+        grad = cuembed_embedding_backward(y.contiguous(), ctx.num_categories, t_idx, t_sid, t_w)
+        return grad, None, None, None
+
+
+def cuemb_embedding_fixed(params, idx, weights=None, mode="sum"):
+    """Fixed-hotness lookup (this library's extension of the reference's Python surface):
+    idx is [batch, hotness]; weights (optional, sum/mean only) has the same shape."""
+    if not torch.is_grad_enabled() or not params.requires_grad:
+        return torch.ops.cuembed_pyt.cuembed_embedding_forward_fixed(params, idx, weights, mode)
+    return _CuEmbFixed.apply(params, idx, weights, mode)
+
+
 # Shape functions so that torch.compile can trace through the ops without running them.
+@torch.library.register_fake("cuembed_pyt::cuembed_embedding_forward_fixed")
+def _(params, indices, weights=None, mode="sum"):
+    b, h = indices.shape
+    shape = (b, h, params.shape[1]) if mode == "concat" else (b, params.shape[1])
+    return torch.empty(shape, device=params.device, dtype=params.dtype)
+
+
 @torch.library.register_fake("cuembed_pyt::cuembed_extract_row_ids_from_csr")
 def _(offsets, nnz):
     return torch.empty((nnz,), device=offsets.device, dtype=offsets.dtype)

@@ -192,3 +192,31 @@ def test_sparse_gradient_extension(pyt, weighted):
     weight.grad = None
     (bag(indices, offsets, w) * up).sum().backward()
     assert torch.allclose(g_sparse.to_dense(), weight.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "concat"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fixed_hotness_2d_indices_all_modes(pyt, mode, weighted):
+    """cuemb_embedding_fixed: [B, H] index tensors with sum / mean / concat, forward and backward
+    against plain torch indexing."""
+    if mode == "concat" and weighted:
+        pytest.skip("concat takes no weights (embedding_lookup.cuh:261)")
+    k, d, B, H = 4000, 48, 700, 9
+    torch.manual_seed(1)
+    table = torch.randn(k, d, device="cuda", requires_grad=True)
+    ref_table = table.detach().clone().requires_grad_(True)
+    idx = torch.randint(0, k, (B, H), device="cuda")
+    w = torch.rand(B, H, device="cuda") + 0.1 if weighted else None
+    out = pyt.cuemb_embedding_fixed(table, idx, w, mode)
+    rows = ref_table[idx]                                   # [B, H, d]
+    if mode == "concat":
+        ref = rows
+    else:
+        ref = (rows * w[..., None]).sum(1) if weighted else rows.sum(1)
+        if mode == "mean":
+            ref = ref / (w.sum(1, keepdim=True) if weighted else H)
+    assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    up = torch.randn_like(ref)
+    (out * up).sum().backward()
+    (ref * up).sum().backward()
+    assert torch.allclose(table.grad, ref_table.grad, rtol=1e-4, atol=1e-4)
