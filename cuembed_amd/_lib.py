@@ -41,6 +41,8 @@ def _declare(L):
     L.cuembed_extract_row_ids_for_concat.argtypes = [_I, _I, _VP, _VP]
     L.cuembed_forward_launch_shape.restype = None
     L.cuembed_forward_launch_shape.argtypes = [_I, _I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]
+    L.cuembed_embedding_weight_grad.restype = None
+    L.cuembed_embedding_weight_grad.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _VP]
     L.cuembed_set_forward_reduction_order.restype = None
     L.cuembed_set_forward_reduction_order.argtypes = [_I]
     L.cuembed_get_forward_reduction_order.restype = _I

@@ -109,6 +109,35 @@ void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width
   out[5] = f.staged ? 1 : 0;
 }
 
+void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_width,
+                                   const void* indices, int index_type, const void* offsets,
+                                   int offset_type, const void* grad_y, int batch_size, int num_hots,
+                                   void* grad_weights, cuembed_stream_t stream) {
+#define WG(E, I, O)                                                                              \
+  cuembed::EmbeddingWeightGrad<E, I, O>(static_cast<const E*>(params), embed_width,              \
+                                        static_cast<const I*>(indices),                          \
+                                        static_cast<const O*>(offsets),                          \
+                                        static_cast<const E*>(grad_y), batch_size, num_hots,     \
+                                        static_cast<E*>(grad_weights), Stream(stream))
+  const int key = (elem_type << 2) | (index_type << 1) | (offsets ? offset_type : 0);
+  switch (key) {
+    case 0: WG(float, int32_t, int32_t); break;
+    case 1: WG(float, int32_t, int64_t); break;
+    case 2: WG(float, int64_t, int32_t); break;
+    case 3: WG(float, int64_t, int64_t); break;
+    case 4: WG(__half, int32_t, int32_t); break;
+    case 5: WG(__half, int32_t, int64_t); break;
+    case 6: WG(__half, int64_t, int32_t); break;
+    case 7: WG(__half, int64_t, int64_t); break;
+    case 8: WG(__hip_bfloat16, int32_t, int32_t); break;
+    case 9: WG(__hip_bfloat16, int32_t, int64_t); break;
+    case 10: WG(__hip_bfloat16, int64_t, int32_t); break;
+    case 11: WG(__hip_bfloat16, int64_t, int64_t); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef WG
+}
+
 void cuembed_set_forward_reduction_order(int order) {
   CUEMBED_ASSERT(order == 0 || order == 1);
   cuembed::SetForwardReductionOrder(static_cast<cuembed::ReductionOrder>(order));

@@ -282,6 +282,44 @@ void EmbeddingForward(const InputT* params,
         table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
 }
 
+/**
+ * @brief Gradient of a weighted sum-forward with respect to the per-lookup weights (extension;
+ * nn.EmbeddingBag's per_sample_weights gradient):
+ * grad_weights[s, j] = dot(params[indices[s, j], :], grad_y[s, :]).  Same index layouts as
+ * EmbeddingForward (fixed hotness or CSR); grad_weights has one entry per lookup.
+ */
+template <typename InputT, typename IndexT, typename OffsetT>
+void EmbeddingWeightGrad(const InputT* params,
+                         const int embed_width,
+                         const IndexT* indices,
+                         const OffsetT* offsets,
+                         const InputT* grad_y,
+                         const int batch_size,
+                         const int num_hots,
+                         InputT* grad_weights,
+                         const hipStream_t stream = 0) {
+  using ElemT = detail::DeviceElemT<GetElemT<InputT>>;
+  CUEMBED_ASSERT((offsets != nullptr && num_hots == 0) || (offsets == nullptr && num_hots > 0));
+  if (batch_size <= 0) return;
+  const detail::RowSplit split = detail::SplitRow<ElemT>(embed_width, params, grad_y);
+  int group = 1;
+  while (group < split.lanes_per_row && group < 64) group *= 2;
+  const int samples_per_block = detail::kDefaultBlockThreads / group;
+  const dim3 block(group, samples_per_block, 1);
+  const dim3 grid((batch_size + samples_per_block - 1) / samples_per_block, 1, 1);
+  const ElemT* table = reinterpret_cast<const ElemT*>(params);
+  const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
+  ElemT* gw = reinterpret_cast<ElemT*>(grad_weights);
+  constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
+#define CUEMBED_LAUNCH_WG(NN)                                                                   \
+  detail::WeightGradKernel<ElemT, IndexT, OffsetT, NN><<<grid, block, 0, stream>>>(             \
+      table, embed_width, batch_size, indices, offsets, num_hots, gy, gw)
+  if (split.elems_per_lane == kMaxN) CUEMBED_LAUNCH_WG(kMaxN);
+  else if (split.elems_per_lane == kMaxN / 2) CUEMBED_LAUNCH_WG(kMaxN / 2);
+  else CUEMBED_LAUNCH_WG(kMaxN / 4);
+#undef CUEMBED_LAUNCH_WG
+}
+
 }  // namespace cuembed
 
 #include "cuembed/include/embedding_backward.hpp"

@@ -439,6 +439,79 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
 }
 
 // ---------------------------------------------------------------------------
+// Gradient with respect to the per-lookup weights (an extension: the reference's torch example
+// returns None for it, cuembed_pyt.py:34-35):
+//     grad_w[s, j] = < table[idx[s, j], :], grad_y[s, :] >
+// Same mapping as the forward: a group of `blockDim.x` lanes (a power of two <= 64, so a group
+// never straddles a wavefront) owns a sample, batches kForwardUnroll row loads, multiplies
+// them with its slice of grad_y (fp32), folds the per-lane partial dots with a cross-lane
+// butterfly (`__shfl_xor`) and lane 0 stores one value per lookup.  Rows wider than the group
+// are walked in strides of the group.
+//   block = (group, samples_per_block); grid = ceil(batch / samples_per_block)
+// ---------------------------------------------------------------------------
+template <typename ElemT, typename IndexT, typename OffsetT, int N>
+__global__ void __launch_bounds__(kMaxBlockThreads)
+WeightGradKernel(const ElemT* __restrict__ table,
+                 const int width,
+                 const int batch,
+                 const IndexT* __restrict__ indices,
+                 const OffsetT* __restrict__ offsets,  // null => fixed hotness
+                 const int num_hots,
+                 const ElemT* __restrict__ grad_y,
+                 ElemT* __restrict__ grad_w) {
+  const int lane_x = threadIdx.x;
+  const int group = blockDim.x;
+  const int64_t sample = static_cast<int64_t>(blockIdx.x) * blockDim.y + threadIdx.y;
+  if (sample >= batch) return;
+  int64_t begin;
+  int hot = num_hots;
+  if (offsets != nullptr) {
+    begin = static_cast<int64_t>(offsets[sample]);
+    hot = static_cast<int>(static_cast<int64_t>(offsets[sample + 1]) - begin);
+  } else {
+    begin = sample * num_hots;
+  }
+  const IndexT* my_idx = indices + begin;
+  ElemT* my_out = grad_w + begin;
+  const ElemT* my_gy = grad_y + sample * width;
+  const int chunks = width / N;  // N-element slices per row
+
+  for (int j0 = 0; j0 < hot; j0 += kForwardUnroll) {
+    const int nb = hot - j0 < kForwardUnroll ? hot - j0 : kForwardUnroll;
+    float dot[kForwardUnroll];
+#pragma unroll
+    for (int u = 0; u < kForwardUnroll; ++u) dot[u] = 0.f;
+    for (int c = lane_x; c < chunks; c += group) {
+      const Pack<ElemT, N> g = LoadPack<ElemT, N>(my_gy + static_cast<int64_t>(c) * N);
+      Pack<ElemT, N> row[kForwardUnroll];
+#pragma unroll
+      for (int u = 0; u < kForwardUnroll; ++u) {
+        if (u < nb)
+          row[u] = LoadPack<ElemT, N>(table + static_cast<int64_t>(my_idx[j0 + u]) * width +
+                                      static_cast<int64_t>(c) * N);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kForwardUnroll; ++u) {
+        if (u < nb) {
+#pragma unroll
+          for (int e = 0; e < N; ++e) dot[u] += static_cast<float>(row[u].v[e]) * static_cast<float>(g.v[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kForwardUnroll; ++u) {
+      for (int d = group >> 1; d > 0; d >>= 1) dot[u] += __shfl_xor(dot[u], d, group);
+    }
+    if (lane_x == 0) {
+#pragma unroll
+      for (int u = 0; u < kForwardUnroll; ++u)
+        if (u < nb) my_out[j0 + u] = static_cast<ElemT>(dot[u]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Concat (fixed hotness only): out[s, j, :] = table[idx[s, j], :].
 // Same block/grid shape; indices always read from global (each is used once).
 // ---------------------------------------------------------------------------

@@ -31,6 +31,8 @@ _lib.define("cuembed_embedding_backward_compressed(Tensor y_grad, int num_unique
 # (the reference binding only exposes CSR + sum, cuembed_embedding.cu:29-32).
 _lib.define("cuembed_embedding_forward_fixed(Tensor params, Tensor indices, Tensor weights, str mode)"
             " -> Tensor")
+_lib.define("cuembed_embedding_weight_grad(Tensor params, Tensor indices, Tensor offsets, Tensor y_grad)"
+            " -> Tensor")
 _lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor offsets, Tensor weights,"
             " str mode) -> Tensor")
 _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
@@ -115,6 +117,12 @@ def _forward_fixed_impl(params, indices, weights, mode):
                                   batch_size=batch, num_hots=hot, mode=mode)
 
 
+def _weight_grad_impl(params, indices, offsets, y_grad):
+    _require(params.is_cuda and indices.is_cuda and offsets.is_cuda and y_grad.is_cuda, "tensors must be on the GPU")
+    return _ops.embedding_weight_grad(params.contiguous(), indices.contiguous(), y_grad.contiguous(),
+                                      offsets=offsets.contiguous(), batch_size=offsets.numel() - 1, num_hots=0)
+
+
 def _compress_impl(transpose_indices):
     _require(transpose_indices.is_cuda and transpose_indices.dtype in _INTS, "indices must be int tensors on the GPU")
     return _ops.compute_compressed_grad_indices(transpose_indices.contiguous())
@@ -132,6 +140,7 @@ def _backward_compressed_impl(y_grad, num_unique, transpose_indices, transpose_s
     return grad, inv
 
 
+_lib.impl("cuembed_embedding_weight_grad", _weight_grad_impl, "CUDA")
 _lib.impl("cuembed_embedding_forward_fixed", _forward_fixed_impl, "CUDA")
 _lib.impl("cuembed_compute_compressed_grad_indices", _compress_impl, "CUDA")
 _lib.impl("cuembed_embedding_backward_compressed", _backward_compressed_impl, "CUDA")
@@ -196,18 +205,30 @@ class _CuEmbEmbedding(torch.autograd.Function):
         ctx.save_for_backward(idx, offsets, weights)
         ctx.num_categories = params.size(0)
         ctx.sparse_grad = sparse_grad
+        # the weight gradient (an extension; the reference returns None) needs the table rows
+        ctx.params_for_weight_grad = params.detach() if (weights is not None and weights.requires_grad) else None
         return cuembed_forward(params, idx, offsets, weights)
 
     @staticmethod
     def backward(ctx, out_grad):
-        return cuembed_backward(ctx, out_grad) + (None,)
+        if ctx.needs_input_grad[0]:
+            grads = list(cuembed_backward(ctx, out_grad))
+        else:
+            grads = [None, None, None, None]
+        if ctx.params_for_weight_grad is not None:
+            idx, offsets, _ = ctx.saved_tensors
+            grads[3] = torch.ops.cuembed_pyt.cuembed_embedding_weight_grad(
+                ctx.params_for_weight_grad, idx, offsets, out_grad.to(ctx.params_for_weight_grad.dtype))
+        return tuple(grads) + (None,)
 
 
 def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False):
-    """Sum-pooled embedding bag (offsets include the last offset).  Differentiable w.r.t. params.
-    sparse_grad=True (this library's extension) makes params.grad a coalesced sparse COO tensor
-    holding only the rows that were looked up."""
-    if not torch.is_grad_enabled() or not params.requires_grad:
+    """Sum-pooled embedding bag (offsets include the last offset).  Differentiable w.r.t. params
+    and -- an extension over the reference -- w.r.t. the per-lookup weights.
+    sparse_grad=True (extension) makes params.grad a sparse COO tensor holding only the rows that
+    were looked up."""
+    needs_grad = params.requires_grad or (weights is not None and weights.requires_grad)
+    if not torch.is_grad_enabled() or not needs_grad:
         return cuembed_forward(params, idx, offsets, weights)
     return _CuEmbEmbedding.apply(params, idx, offsets, weights, sparse_grad)
 
@@ -269,6 +290,11 @@ def _(rows, cols, weights=None):
     n = 0 if weights is None else cols.shape[0]
     return (torch.empty_like(cols), torch.empty_like(rows),
             torch.empty((n,), device=rows.device, dtype=torch.float32 if weights is None else weights.dtype))
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_embedding_weight_grad")
+def _(params, indices, offsets, y_grad):
+    return torch.empty((indices.shape[0],), device=params.device, dtype=params.dtype)
 
 
 @torch.library.register_fake("cuembed_pyt::cuembed_transpose_bounded")

@@ -140,6 +140,37 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
     return out
 
 
+def embedding_weight_grad(params, indices, grad_y, offsets=None, batch_size=None, num_hots=0):
+    """grad_weights[s, j] = dot(params[indices[s, j]], grad_y[s]) -- the gradient of a weighted
+    sum-forward w.r.t. its per-lookup weights (extension).  Returns a tensor with one entry per lookup."""
+    _check_dev("params", params)
+    dev = params.device
+    _check_dev("indices", indices, dev)
+    _check_dev("grad_y", grad_y, dev)
+    et = _elem_code("params", params)
+    it = _index_code("indices", indices)
+    if grad_y.dtype != params.dtype or grad_y.dim() != 2 or grad_y.shape[1] != params.shape[1]:
+        raise ValueError("grad_y must be [batch, width] of the table's dtype")
+    if not ((offsets is not None and num_hots == 0) or (offsets is None and num_hots > 0)):
+        raise ValueError("either CSR (offsets given, num_hots == 0) or fixed hotness")
+    ot = 0
+    if offsets is not None:
+        _check_dev("offsets", offsets, dev)
+        ot = _index_code("offsets", offsets)
+        if batch_size is None:
+            batch_size = offsets.numel() - 1
+    elif batch_size is None:
+        batch_size = indices.numel() // num_hots
+    if grad_y.shape[0] < batch_size:
+        raise ValueError("grad_y must have one row per sample")
+    out = torch.empty((indices.numel(),), dtype=params.dtype, device=dev)
+    if batch_size > 0 and indices.numel() > 0:
+        _lib.lib().cuembed_embedding_weight_grad(_ptr(params), et, params.shape[1], _ptr(indices), it,
+                                                 _ptr(offsets), ot, _ptr(grad_y), batch_size, num_hots,
+                                                 _ptr(out), _stream(params))
+    return out
+
+
 def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, transpose_sample_ids,
                        transpose_remapped_indices=None, transpose_weights=None,
                        skip_grad_init=False, grad_embedding=None, inverse_mapping=None):

@@ -188,6 +188,14 @@ void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int 
 void cuembed_extract_row_ids_for_concat(int nnz, int index_type, void* row_ids,
                                         cuembed_stream_t stream);
 
+/* ---- extension: gradient w.r.t. the per-lookup weights ---------------------- */
+/* grad_weights[s, j] = dot(params[indices[s, j], :], grad_y[s, :]); one entry per lookup;
+ * index layouts as in cuembed_embedding_forward (cuembed::EmbeddingWeightGrad). */
+void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_width,
+                                   const void* indices, int index_type, const void* offsets,
+                                   int offset_type, const void* grad_y, int batch_size, int num_hots,
+                                   void* grad_weights, cuembed_stream_t stream);
+
 /* ---- options ------------------------------------------------------------- */
 /* cuembed::SetForwardReductionOrder / GetForwardReductionOrder (this library's addition):
  * 0 = sequential (default; bit-identical to the reference for every batch size),

@@ -220,3 +220,29 @@ def test_fixed_hotness_2d_indices_all_modes(pyt, mode, weighted):
     (out * up).sum().backward()
     (ref * up).sum().backward()
     assert torch.allclose(table.grad, ref_table.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("d", [8, 36, 128, 512])
+def test_per_sample_weights_gradient_extension(pyt, d):
+    """cuemb_embedding is differentiable w.r.t. the per-lookup weights (the reference returns None,
+    cuembed_pyt.py:34-35): against nn.EmbeddingBag's per_sample_weights gradient."""
+    k, B = 3000, 600
+    bag = make_bag(k, d)
+    lens = torch.randint(0, 30, (B,), device="cuda")
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens.cumsum(0)])
+    n = int(offsets[-1])
+    indices = torch.randint(0, k, (n,), device="cuda")
+    w1 = torch.rand(n, device="cuda", requires_grad=True)
+    w2 = w1.detach().clone().requires_grad_(True)
+    up = torch.randn(B, d, device="cuda")
+    bag.weight.grad = None
+    (pyt.cuemb_embedding(bag.weight, indices, offsets, w1) * up).sum().backward()
+    g_table = bag.weight.grad.clone()
+    bag.weight.grad = None
+    (bag(indices, offsets, w2) * up).sum().backward()
+    assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(g_table, bag.weight.grad, rtol=1e-4, atol=1e-4)
+    # frozen table, trainable weights only
+    w3 = w1.detach().clone().requires_grad_(True)
+    (pyt.cuemb_embedding(bag.weight.detach(), indices, offsets, w3) * up).sum().backward()
+    assert torch.allclose(w3.grad, w2.grad, rtol=1e-4, atol=1e-4)
