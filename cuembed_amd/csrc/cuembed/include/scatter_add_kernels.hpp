@@ -67,7 +67,11 @@ __device__ __forceinline__ void FlushStore(GradT* dst, const float (&acc)[N]) {
   Pack<GradT, N> p;
 #pragma unroll
   for (int e = 0; e < N; ++e) p.v[e] = static_cast<GradT>(acc[e]);
-  StorePack<GradT, N>(dst, p);
+  // gradient rows are written once and not read again by this kernel: a non-temporal store
+  // keeps them from evicting the grad_y lines that the gather re-reads from L2 (measured:
+  // -10 % on the write-heavy uniform-index case, -1..2 % at C4)
+  typedef unsigned __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
+  __builtin_nontemporal_store(*reinterpret_cast<raw_t*>(&p), reinterpret_cast<raw_t*>(dst));
 }
 
 //! LDS needed by SegmentedScatterAddKernel for `segments_per_block` segments of
@@ -158,7 +162,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     for (int k = tid; k < block_len; k += nthreads) {
       const int64_t g = block_begin + k;
       if (g < nnz) {
-        st_sids[k] = sample_ids[g];
+        st_sids[k] = sample_ids[g];  // (non-temporal loads here measured 6-20 % slower)
         if constexpr (kWeighted) st_w[k] = weights[g];
       }
     }
