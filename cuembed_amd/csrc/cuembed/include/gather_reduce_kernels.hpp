@@ -89,6 +89,14 @@ __device__ __forceinline__ void StorePack(ElemT* p, const Pack<ElemT, N>& v) {
   *reinterpret_cast<Pack<ElemT, N>*>(p) = v;
 }
 
+//! Store for data this kernel never reads back (pooled output rows): non-temporal, so that it
+//! does not displace table rows in L2.
+template <typename ElemT, int N>
+__device__ __forceinline__ void StorePackStreaming(ElemT* p, const Pack<ElemT, N>& v) {
+  typedef unsigned __attribute__((ext_vector_type(sizeof(Pack<ElemT, N>) / 4))) raw_t;
+  __builtin_nontemporal_store(*reinterpret_cast<const raw_t*>(&v), reinterpret_cast<raw_t*>(p));
+}
+
 //! Running state of one lane while it pools the rows of its sample.
 template <typename ElemT, typename AccT, int N, bool kWeighted>
 struct RowPool {
@@ -323,7 +331,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
   Pack<ElemT, N> result;
 #pragma unroll
   for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
-  StorePack<ElemT, N>(out + sample * width + column0, result);
+  StorePackStreaming<ElemT, N>(out + sample * width + column0, result);
 }
 
 // ---------------------------------------------------------------------------
