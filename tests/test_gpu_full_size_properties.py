@@ -1,0 +1,100 @@
+"""BASELINE.json configs 3 and 4 at FULL size, checked through size-independent properties
+(the oracle would need minutes at these sizes): sortedness / stability / permutation of the
+transpose, conservation of column sums, checksum of checksums on exactly representable data,
+plus bit-exact oracle comparisons on slices that the oracle finishes in seconds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ce():
+    import cuembed_amd
+    return cuembed_amd
+
+
+def test_config3_fp32_weighted_csr_full_size(ce, oracle):
+    """C3: fp32 weighted sum, CSR with hotness U[0,128] (mean 64), 10M x 128 table, batch 65536."""
+    from cuembed_amd import harness
+    rows, W, B, H = 10_000_000, 128, 65536, 128
+    a = harness.allocate_forward(rows, W, B, H, alpha=1.15, is_csr=True, with_table=False,
+                                 consume_table_draws=False)
+    idx, off, w = (torch.from_numpy(a[k]).cuda() for k in ("indices", "offsets", "weights"))
+    nnz = idx.numel()
+    assert abs(nnz / B - 64) < 1 and set(np.unique(a["weights"]).tolist()) == {0.25, 0.5}
+    g = torch.Generator(device="cuda").manual_seed(5)
+    table = torch.randint(-2, 3, (rows, W), device="cuda", generator=g).float()   # integers: exact sums
+    out = ce.embedding_forward(table, idx, off, w, num_hots=0)
+    # (a) checksum of checksums: sum_s out[s,:] == (weighted histogram of indices) @ table
+    hist = torch.zeros(rows, dtype=torch.float64, device="cuda").index_add_(0, idx.long(), w.double())
+    assert torch.equal(out.double().sum(0), (hist.unsqueeze(0) @ table.double()).squeeze(0))
+    # (b) empty bags give exact zeros; (c) first / last 200 samples bit-exact against the oracle
+    lens = np.diff(a["offsets"])
+    assert (lens == 0).any() and not out[torch.from_numpy(lens == 0).cuda()].any()
+    for lo in (0, B - 200):
+        o = a["offsets"][lo:lo + 201].astype(np.int64)
+        sub_idx = a["indices"][o[0]:o[-1]]
+        uniq, inv = np.unique(sub_idx, return_inverse=True)
+        small = table[torch.from_numpy(uniq).cuda().long()].cpu().numpy()
+        want = oracle.embedding_forward(small, inv.astype(np.int32), (o - o[0]).astype(np.int32),
+                                        a["weights"][o[0]:o[-1]], num_hots=0)
+        assert np.array_equal(out[lo:lo + 200].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # (d) mean == sum / sum-of-weights
+    mean = ce.embedding_forward(table, idx, off, w, num_hots=0, mode="mean")
+    wsum = torch.zeros(B, device="cuda").index_add_(0, ce.extract_row_ids_from_csr(off, nnz=nnz).long(), w)
+    ref = torch.where(wsum[:, None] > 0, out * (1.0 / wsum)[:, None], torch.zeros_like(out))
+    assert torch.equal(mean, ref)
+
+
+@pytest.mark.parametrize("idx_t", [torch.int32, torch.int64], ids=["i32", "i64"])
+def test_config4_backward_compressed_full_size(ce, oracle, idx_t):
+    """C4: transpose + compressed gradient at the C2 shape (10M x 256, batch 65536, hotness 64)."""
+    from cuembed_amd import harness
+    rows, W, B, H = 10_000_000, 256, 65536, 64
+    idx_np = harness.generate_indices(rows, B, H, alpha=1.15)
+    idx = torch.from_numpy(idx_np).cuda().to(idx_t)
+    nnz = idx.numel()
+    sid = ce.extract_row_ids_from_fixed(B, H, idx_t, "cuda")
+    assert torch.equal(sid, torch.arange(nnz, device="cuda").div(H, rounding_mode="floor").to(idx_t))
+    t_idx, t_sid, _ = ce.transpose(sid, idx, num_categories=rows)
+    # sorted by index; stable (sample ids ascend inside a run); a permutation of the input pairs
+    assert bool((t_idx[1:] >= t_idx[:-1]).all())
+    same = t_idx[1:] == t_idx[:-1]
+    assert bool((t_sid[1:][same] > t_sid[:-1][same]).all())
+    ref_idx, order = torch.sort(idx, stable=True)
+    assert torch.equal(t_idx, ref_idx) and torch.equal(t_sid, sid[order])
+    t_idx_full, t_sid_full, _ = ce.transpose(sid, idx)                      # all key bits: same result
+    assert torch.equal(t_idx_full, t_idx) and torch.equal(t_sid_full, t_sid)
+    remap = ce.compute_compressed_grad_indices(t_idx)
+    uniq = torch.unique(idx)
+    nu = int(remap[-1].item()) + 1
+    assert nu == uniq.numel() == 572029 or idx_t != torch.int32 or nu == uniq.numel()
+    assert torch.equal(uniq.to(idx_t)[remap.long()], t_idx)                 # remap is the dense rank of the id
+    # gradient: fp32 (exact for any run length) and fp16 on sparse +-1 data (exact below 2048)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    gy = torch.randint(-3, 4, (B, W), device="cuda", generator=g).float()
+    grad, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
+    assert torch.equal(inv, uniq.to(idx_t))
+    assert torch.equal(grad.double().sum(0), gy.double().sum(0) * H)        # every sample is used H times
+    hottest = int(torch.mode(t_idx).values)
+    run = (t_idx == hottest).nonzero().squeeze(1)
+    assert run.numel() > 60000                                              # one row owns a 65k-lookup run
+    assert torch.equal(grad[int(remap[run[0]])], gy[t_sid[run].long()].sum(0))
+    once = (torch.bincount(remap.long()) == 1).nonzero().squeeze(1)[:1000]   # rows looked up exactly once
+    pos = torch.searchsorted(remap, once.to(remap.dtype))
+    assert torch.equal(grad[once], gy[t_sid[pos].long()])
+    gy16 = (torch.rand((B, W), device="cuda", generator=g) < 0.02).half() * \
+        (torch.randint(0, 2, (B, W), device="cuda", generator=g).half() * 2 - 1)
+    grad16, _ = ce.embedding_backward(gy16, nu, t_idx, t_sid, remap)
+    ref16 = torch.zeros((nu, W), device="cuda").index_add_(0, remap.long(), gy16.float()[t_sid.long()])
+    assert float(ref16.abs().max()) < 2048 and torch.equal(grad16.float(), ref16)
+    # dense gradient of a smaller table slice of the same lookups == scatter of the compressed one
+    small_rows = 200_000
+    keep = t_idx < small_rows
+    dense, _ = ce.embedding_backward(gy, small_rows, t_idx[keep].contiguous(), t_sid[keep].contiguous())
+    ref = torch.zeros((small_rows, W), device="cuda")
+    sel = inv < small_rows
+    ref[inv[sel].long()] = grad[sel.nonzero().squeeze(1)]
+    assert torch.equal(dense, ref)
