@@ -13,6 +13,9 @@
 //   RadixTileHistogramKernel   per 4096-key tile: 256-bin histogram of the current digit
 //   RadixScanTilesKernel       per bin: exclusive prefix over the tiles, and the bin total
 //   RadixScatterKernel         per tile: stable rank of every key among equal digits, scatter
+// (A single-kernel-per-pass variant with decoupled look-back was built and measured 30 % SLOWER
+// here: the per-tile status words have to bypass the XCDs' non-coherent L2s, so every look-back
+// hop is a ~1 us memory-side access, and with 1024 tiles starting together the walks are long.)
 // Ranking is wave-synchronous: a 64-lane wavefront handles 64 consecutive keys per round, finds
 // the lanes holding the same digit with 8 ballots (`match-any`), takes its rank from the
 // popcount of the lower peers, and the lowest peer bumps the wave's digit counter in LDS -- no
