@@ -373,6 +373,7 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
                         const bool is_mean,
                         ElemT* __restrict__ out) {
   using A = Arith<AccT>;
+  (void)batch;  // grid == batch: one workgroup per sample
   constexpr int kWaves = kSplitBlockThreads / 64;
   __shared__ AccT partial[kWaves][N][64];
   __shared__ float partial_w[kWaves];
