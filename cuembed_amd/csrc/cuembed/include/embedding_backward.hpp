@@ -46,7 +46,8 @@ inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row, c
 template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
-                             GradT* grad_out, RowSplit split, hipStream_t stream) {
+                             GradT* grad_out, RowSplit split, hipStream_t stream,
+                             const int64_t zero_rows /* > 0: zero only what needs it, see below */) {
   const int slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row, nnz);
   const int lanes = split.lanes_per_row / slices;  // lanes of one column slice
   int segments_per_block = lanes >= kDefaultBlockThreads ? 1 : kDefaultBlockThreads / lanes;
@@ -68,6 +69,11 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
   const int64_t grid_blocks = slices > 1 ? (nz_blocks + per_slice - 1) / per_slice * 8 : nz_blocks;
   const dim3 block(lanes, segments_per_block, 1);
   const dim3 grid(static_cast<unsigned>(grid_blocks), 1, 1);
+  if (zero_rows > 0) {
+    const int64_t tail_blocks = (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock;
+    ZeroSharedAndTailRowsKernel<GradT, IndexT><<<static_cast<unsigned>(nz_blocks + tail_blocks), 256, 0, stream>>>(
+        rows, nnz, segments_per_block * segment_len, nz_blocks, width, zero_rows, grad_out);
+  }
   const size_t lds =
       ScatterStageBytes<GradT, IndexT>(segments_per_block, segment_len, lanes, N, weights != nullptr);
   if (weights != nullptr)
@@ -117,13 +123,18 @@ void EmbeddingBackward(const GradT* grad_y,
     detail::CompactRunHeadsKernel<IndexT><<<(nnz + threads - 1) / threads, threads, 0, stream>>>(
         transpose_indices, transpose_remapped_indices, inverse_mapping, nnz);
   }
-  if (!skip_grad_init) {
+  // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
+  // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
+  // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
+  const bool compressed = transpose_remapped_indices != nullptr;
+  if (!skip_grad_init && (!compressed || nnz <= 0)) {
     (void)hipMemsetAsync(grad_embedding, 0,
                          static_cast<size_t>(num_grad_embedding_rows) *
                              static_cast<size_t>(embed_width) * sizeof(GradT),
                          stream);
   }
   if (nnz <= 0) return;
+  const int64_t zero_rows = (!skip_grad_init && compressed) ? num_grad_embedding_rows : 0;
 
   const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
   const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
@@ -132,15 +143,15 @@ void EmbeddingBackward(const GradT* grad_y,
   constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
   if (split.elems_per_lane == kMaxN)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w,
-                                                   nnz, out, split, stream);
+                                                   nnz, out, split, stream, zero_rows);
   else if (split.elems_per_lane == kMaxN / 2)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows,
                                                        transpose_sample_ids, w, nnz, out, split,
-                                                       stream);
+                                                       stream, zero_rows);
   else
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows,
                                                        transpose_sample_ids, w, nnz, out, split,
-                                                       stream);
+                                                       stream, zero_rows);
 }
 
 }  // namespace cuembed

@@ -296,3 +296,24 @@ def test_transpose_tile_boundaries_and_degenerate_keys(ce, oracle, idx):
             assert np.array_equal(host(tw).view(np.uint16), ow.view(np.uint16)), (nnz, name)
             assert np.array_equal(host(ce.compute_compressed_grad_indices(ti)),
                                   oracle.compute_compressed_grad_indices(oi)), (nnz, name)
+
+
+def test_backward_compressed_zero_init_without_full_memset(ce, oracle):
+    """Compressed gradient with skip_grad_init=False: only rows that can receive atomics and an
+    over-allocated tail are zeroed by the library; every other row is overwritten.  The result must
+    equal the oracle's (which memsets everything) on a garbage-filled, over-allocated buffer."""
+    W, B, H, ncat = 128, 3000, 16, 700
+    for elem in ELEMS:
+        a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15, elem=elem[0])
+        sid = oracle.extract_row_ids_from_fixed(B, H)
+        ti, ts, _ = oracle.transpose(sid, a["indices"])
+        remap = oracle.compute_compressed_grad_indices(ti)
+        nu = int(remap[-1]) + 1
+        gy = (np.mod(oracle.allocate_grad_y(B * W).reshape(B, W), 3) - 1).astype(elem[0])
+        for extra in (0, 1, 130):
+            buf = torch.full((nu + extra, W), 123.0, dtype=elem[1], device="cuda")
+            got, inv = ce.embedding_backward(dev(gy), nu + extra, dev(ti), dev(ts), dev(remap),
+                                             skip_grad_init=False, grad_embedding=buf)
+            want, winv = oracle.embedding_backward(gy.astype(np.float32), W, nu + extra, ti, ts, remap)
+            assert np.array_equal(host(got).astype(np.float32), want), (elem[0], extra)
+            assert np.array_equal(host(inv)[:nu], winv[:nu])
