@@ -10,17 +10,23 @@
 //   * one lane owns 16 (or 8/4) bytes of the row; a 512-byte row is 32 lanes, so a
 //     64-lane wavefront streams TWO samples and every global_load_dwordx4 moves
 //     1 KiB as two fully coalesced 512-B row segments;
-//   * the hotness loop is batched: kUnroll independent row loads are issued
-//     back-to-back (kUnroll KiB in flight per wave) before the first one is
-//     consumed -- with 6..8 waves per SIMD that is far more than the ~10-20 KiB
-//     per CU needed to cover HBM/L2 latency;
+//   * the hotness loop is batched: kForwardUnroll independent row loads are issued
+//     back-to-back (8 KiB in flight per wave) before the first one is consumed, the
+//     tail of a bag included (one predicated batch, not one latency per leftover row);
 //   * accumulation is strictly in lookup order, one unfused add (and one unfused
 //     multiply when weighted) per element, so results are bit-identical to the
 //     sequential host loop of the reference (embedding_lookup_cpu.hpp:57-93);
-//   * fixed-hotness indices (and weights) of the workgroup's samples are staged
-//     once into LDS with coalesced loads; CSR bags read their index straight
-//     from global memory (a wave-broadcast load that hits L1 31 times out of 32);
-//   * all row addressing is 64-bit (a 10M x 256 table is 2.56 G elements).
+//   * indices reach the lanes in one of three ways (IndexSource): staged once per
+//     workgroup in LDS (fixed hotness), fetched 64-wide by the sample's own lanes and
+//     handed around with cross-lane reads (CSR, lanes_per_row | 64), or read per lookup
+//     as a wave-broadcast load (any other row split);
+//   * small batches can opt into GatherReduceSplitKernel: the hotness loop of one sample
+//     split over the waves of a workgroup, partial pooled rows combined through LDS;
+//   * pooled rows leave with non-temporal stores; all row addressing is 64-bit
+//     (a 10M x 256 table is 2.56 G elements).
+// Measured on MI355X the kernel sits on the memory system's own limits in every regime
+// (L2-resident table 25-28 TB/s, Infinity-Cache-resident 8.4 TB/s, HBM 6.1 TB/s for random
+// 512-byte rows); unroll depth, workgroup shape and occupancy do not move it.
 // No MFMA: the op is a bandwidth-bound gather, there is no contraction to feed.
 #ifndef CUEMBED_INCLUDE_GATHER_REDUCE_KERNELS_HPP_
 #define CUEMBED_INCLUDE_GATHER_REDUCE_KERNELS_HPP_
