@@ -189,6 +189,15 @@ RadixScatterKernel(const KeyT* __restrict__ keys_in, const V1* __restrict__ v1_i
     const int64_t i = wave_base + r * 64 + lane;
     key[r] = i < n ? keys_in[i] : KeyT(0);
   }
+  // the first payload is requested now as well, so that its latency overlaps the ranking
+  V1 item1[kSortItems];
+  if constexpr (!std::is_same<V1, NoPayload>::value) {
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+      const int64_t i = wave_base + r * 64 + lane;
+      if (i < n) item1[r] = v1_in[i];
+    }
+  }
   unsigned slot[kSortItems];  // first: rank in wave; finally: tile-local position in digit order
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
@@ -243,15 +252,7 @@ RadixScatterKernel(const KeyT* __restrict__ keys_in, const V1* __restrict__ v1_i
     }
   }
   // ---- payloads take the same route ----
-  if constexpr (!std::is_same<V1, NoPayload>::value) {
-    V1 item[kSortItems];
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-      const int64_t i = wave_base + r * 64 + lane;
-      if (i < n) item[r] = v1_in[i];
-    }
-    StageAndStore<V1>(stage, item, slot, dest, count, v1_out);
-  }
+  if constexpr (!std::is_same<V1, NoPayload>::value) StageAndStore<V1>(stage, item1, slot, dest, count, v1_out);
   if constexpr (!std::is_same<V2, NoPayload>::value) {
     V2 item[kSortItems];
 #pragma unroll
