@@ -20,6 +20,9 @@
 // the lanes holding the same digit with 8 ballots (`match-any`), takes its rank from the
 // popcount of the lower peers, and the lowest peer bumps the wave's digit counter in LDS -- no
 // LDS atomics, no dependence on digit skew, and input order is preserved by construction.
+// (Finding the peers through per-wave lane bitmaps in LDS -- ds_or, read back, clear -- removes
+// ~50 VALU instructions per round but measured 1-5 % slower: the scatter pass is bound by its
+// 64-byte-average bin segments in memory, not by the ranking arithmetic.)
 #ifndef CUEMBED_INCLUDE_RADIX_SORT_KERNELS_HPP_
 #define CUEMBED_INCLUDE_RADIX_SORT_KERNELS_HPP_
 
