@@ -87,7 +87,13 @@ __device__ __forceinline__ __bf16 ShuffleElem(__bf16 v, int src, int width) {
 
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
+#if defined(CUEMBED_TUNE_ROW_LOAD_NT)   // tools/tune_forward.py --policies: rejected, see DESIGN.md
+  typedef unsigned __attribute__((ext_vector_type(sizeof(Pack<ElemT, N>) / 4))) raw_t;
+  const raw_t raw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
+  return *reinterpret_cast<const Pack<ElemT, N>*>(&raw);
+#else
   return *reinterpret_cast<const Pack<ElemT, N>*>(p);
+#endif
 }
 
 template <typename ElemT, int N>

@@ -12,18 +12,31 @@ sys.path.insert(0, ROOT)
 SO = os.path.join(ROOT, "tools", "forward_variants.so")
 
 
-def build():
+def build(so=SO, defines=()):
     src = os.path.join(ROOT, "tools", "forward_variants.hip")
-    if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+    hdr = os.path.join(ROOT, "cuembed_amd", "csrc", "cuembed", "include", "gather_reduce_kernels.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                "-munsafe-fp-atomics", "-I" + os.path.join(ROOT, "cuembed_amd", "csrc"),
-                               "-I" + os.path.join(ROOT, "include"), src, "-o", SO])
+                               "-I" + os.path.join(ROOT, "include"), src, "-o", so] + ["-D" + d for d in defines])
+
+
+# A/B of compile-time policies of the product kernel (variant 0): each policy is its own .so.
+POLICIES = {"plain": (), "row_nt": ("CUEMBED_TUNE_ROW_LOAD_NT",)}
+
+
+def policy_so(name):
+    return SO if name == "plain" else SO.replace(".so", "_%s.so" % name)
 
 
 def main():
     if "--build-only" in sys.argv:
         build()
+        for name, defs in POLICIES.items():
+            build(policy_so(name), defs)
         return
+    if "--policies" in sys.argv:
+        return policies_main()
     import numpy as np
     import torch
     from cuembed_amd import harness
@@ -82,6 +95,46 @@ def main():
             med = ms[len(ms) // 2]
             print("  %-22s spb=%2d  median %.4f ms (%6.0f GB/s)  min %.4f ms" %
                   (L.variant_name(v).decode(), spb, med, nbytes / med / 1e6, ms[0]))
+
+
+def policies_main():
+    import numpy as np
+    import torch
+    from cuembed_amd import harness
+    libs = {n: ctypes.CDLL(policy_so(n)) for n in POLICIES}
+    dev = torch.device("cuda", 0)
+    B, H, W = 65536, 64, 256
+    out = torch.empty((B, W), dtype=torch.float16, device=dev)
+    ref = torch.empty((B, W), dtype=torch.float16, device=dev)
+    nbytes = 2 * B * (H + 1) * W
+    big = torch.empty((10_000_000, W), dtype=torch.float16, device=dev).uniform_(-1, 1)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for alpha in (1.15, 1.05, 0.0):
+        idx = harness.generate_indices(10_000_000, 4 * B, H, alpha=alpha).reshape(4, -1)
+        idxs = [torch.from_numpy(np.ascontiguousarray(idx[i])).to(dev) for i in range(4)]
+
+        def launch(L, i, o):
+            L.variant_launch(0, ctypes.c_void_p(big.data_ptr()), W, B, ctypes.c_void_p(idxs[i].data_ptr()), H,
+                             ctypes.c_void_p(o.data_ptr()), 8, stream)
+        launch(libs["plain"], 0, ref)
+        res = {}
+        for r in range(9):
+            for n, L in libs.items():
+                if r == 0:
+                    launch(L, 0, out)
+                    torch.cuda.synchronize()
+                    assert torch.equal(out, ref), n
+                a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for t in range(12):
+                    launch(L, t % 4, out)
+                z.record()
+                z.synchronize()
+                res.setdefault(n, []).append(a.elapsed_time(z) / 12)
+        for n, ms in res.items():
+            ms = sorted(ms)
+            print("alpha=%.2f  %-8s median %.4f ms (%6.0f GB/s)  min %.4f" %
+                  (alpha, n, ms[len(ms) // 2], nbytes / ms[len(ms) // 2] / 1e6, ms[0]))
 
 
 if __name__ == "__main__":
