@@ -143,7 +143,7 @@ def main():
     B, H, W = cfg["batch"], cfg["hotness"], cfg["width"]
 
     ce._lib.lib()  # fail loudly if the HIP library is absent
-    table = fill_table(torch, cfg["rows"], W, tdtype, device, seed=1234 + rank)
+    table = fill_table(torch, cfg["rows"], W, tdtype, device, seed=1234)  # replicated: every rank holds the same table
     nb = args.index_batches if args.index_batches > 0 else (4 if world <= 2 else 2)
     host_batches = make_batches(harness, np, cfg, alpha, nb, rank, world, np.int32)
     dev_batches = []
