@@ -60,8 +60,7 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
 }
 
 //! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
-//! Plain LDS atomics: order does not matter for counting, and even the worst case (every key of
-//! the tile in one bin: 4096 serialised ds_add) is ~2 us, far cheaper than ranking by ballots.
+//! Plain LDS atomics: order does not matter for counting.
 template <typename KeyT>
 __global__ void __launch_bounds__(kSortThreads)
 RadixTileHistogramKernel(const KeyT* __restrict__ keys, const int64_t n, const int shift,
@@ -79,10 +78,22 @@ RadixTileHistogramKernel(const KeyT* __restrict__ keys, const int64_t n, const i
     const int64_t i = base + static_cast<int64_t>(r) * kSortThreads;
     key[r] = i < n ? keys[i] : KeyT(0);
   }
+  // From the second pass on, equal keys sit next to each other, and a power-law batch has runs
+  // of thousands of them: 64 lanes adding to ONE counter serialise.  So only the first lane of
+  // every run of equal digits inside the wavefront adds, and it adds the run's length (the
+  // distance to the next run head in the ballot of heads).  Random digits: every lane is a head.
+  const int lane = tid & 63;
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
-    if (base + static_cast<int64_t>(r) * kSortThreads < n)
-      atomicAdd(&count[wave][static_cast<unsigned>((key[r] >> shift) & 0xff)], 1u);
+    const bool in_range = base + static_cast<int64_t>(r) * kSortThreads < n;
+    const unsigned digit = in_range ? static_cast<unsigned>((key[r] >> shift) & 0xff) : 0xffffffffu;
+    const unsigned before = __shfl_up(digit, 1);
+    const bool head = lane == 0 || before != digit;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    const unsigned run = above != 0 ? static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
+                                    : static_cast<unsigned>(64 - lane);
+    if (head && in_range) atomicAdd(&count[wave][digit], run);
   }
   __syncthreads();
   unsigned total = 0;
