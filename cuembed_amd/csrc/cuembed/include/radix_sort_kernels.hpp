@@ -44,15 +44,21 @@ constexpr int kSortBins = 256;                          // 8-bit digits
 struct NoPayload {};
 
 //! Lanes of the wavefront (among `valid` ones) whose 8-bit digit equals this lane's.
+//! Per digit bit b: m = ballot(bit b set); a lane keeps the peers that agree with it on bit b,
+//! peers &= ~(m ^ sel) with sel = all-ones if its own bit is set.  That three-input function is
+//! ONE v_bitop3_b32 per mask half on gfx950 (truth table 0x90 = S0 & ~(S1 ^ S2)).
 __device__ __forceinline__ unsigned long long MatchDigit(const unsigned digit, const bool valid) {
-  unsigned long long peers = __ballot(valid);
+  const unsigned long long v = __ballot(valid);
+  unsigned lo = static_cast<unsigned>(v);
+  unsigned hi = static_cast<unsigned>(v >> 32);
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
-    const bool bit = (digit >> b) & 1u;
-    const unsigned long long m = __ballot(bit);
-    peers &= bit ? m : ~m;
+    const int sel = static_cast<int>(digit << (31 - b)) >> 31;  // bit b ? -1 : 0
+    const unsigned long long m = __ballot(sel != 0);
+    lo = __builtin_amdgcn_bitop3_b32(lo, static_cast<unsigned>(m), static_cast<unsigned>(sel), 0x90);
+    hi = __builtin_amdgcn_bitop3_b32(hi, static_cast<unsigned>(m >> 32), static_cast<unsigned>(sel), 0x90);
   }
-  return peers;
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
 __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
