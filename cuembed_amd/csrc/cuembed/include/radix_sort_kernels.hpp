@@ -224,14 +224,15 @@ RadixScatterKernel(const KeyT* __restrict__ keys_in, const V1* __restrict__ v1_i
     const bool valid = wave_base + r * 64 + lane < n;
     const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
     const unsigned long long peers = MatchDigit(digit, valid);
-    const int leader = __ffsll(static_cast<long long>(peers)) - 1;
+    // every peer reads the wave's running count of its digit (one LDS broadcast per digit), then
+    // the lowest peer bumps it; a wavefront's LDS operations execute in program order
+    const unsigned lower = static_cast<unsigned>(__popcll(peers & LanesBelow(lane)));
     unsigned start = 0;
-    if (valid && lane == leader) {
-      start = wave_count[wave][digit];
-      wave_count[wave][digit] = start + static_cast<unsigned>(__popcll(peers));
-    }
-    start = __shfl(start, leader < 0 ? 0 : leader);
-    slot[r] = valid ? start + static_cast<unsigned>(__popcll(peers & LanesBelow(lane))) : 0xffffffffu;
+    if (valid) start = wave_count[wave][digit];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lower == 0) wave_count[wave][digit] = start + static_cast<unsigned>(__popcll(peers));
+    __builtin_amdgcn_wave_barrier();
+    slot[r] = valid ? start + lower : 0xffffffffu;
   }
   __syncthreads();
   {  // per digit: wave counts -> exclusive prefix over waves; tile totals -> tile-local starts
