@@ -65,15 +65,64 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
   return (1ull << lane) - 1ull;
 }
 
+// Passes that cannot move anything are skipped ON THE DEVICE.  The first pass also reduces the
+// keys to `varying` = the bits in which any two keys differ (OR of all keys & ~AND of all keys);
+// a later pass whose digit of `varying` is zero would be the identity permutation, so its three
+// kernels return at once (an empty launch is ~2 us instead of ~35 us of work), and the remaining
+// passes pick their source and destination buffers so that the last one that runs still writes
+// the caller's output.  The host enqueues the same launches whatever the data (no read-back, graph
+// capturable): int64 indices below 2^24 cost 3 working passes + 5 empty ones, not 8.
+// Reading `varying` first costs every kernel ~1 us, so sorts of at most kStaticRoutePasses passes
+// (a caller-supplied key bound, where a constant digit is unlikely) pass varying == nullptr and
+// take the fixed route.
+constexpr int kStaticRoutePasses = 3;
+enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp = 2 };
+
+struct PassRoute {
+  bool active;
+  int src, dst;
+};
+
+//! Pass 0 always runs.  Buffers alternate out/tmp backwards from the last active pass.
+__device__ __forceinline__ PassRoute RoutePass(const unsigned long long varying, const int pass,
+                                               const int passes) {
+  unsigned active = 1u;
+  for (int q = 1; q < passes; ++q)
+    if ((varying >> (8 * q)) & 0xffull) active |= 1u << q;
+  PassRoute route;
+  route.active = (active >> pass) & 1u;
+  const int later = __popc(active >> (pass + 1));
+  route.dst = (later % 2 == 0) ? kBufOut : kBufTmp;
+  route.src = pass == 0 ? kBufIn : (route.dst == kBufOut ? kBufTmp : kBufOut);
+  return route;
+}
+
+template <typename T>
+__device__ __forceinline__ T* PickBuffer(const int which, const T* in, T* out, T* tmp) {
+  return which == kBufIn ? const_cast<T*>(in) : (which == kBufOut ? out : tmp);
+}
+
 //! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
-//! Plain LDS atomics: order does not matter for counting.
+//! Plain LDS atomics: order does not matter for counting.  In pass 0 the tile's OR and AND of
+//! its keys go to tile_bits[2 * tile], [2 * tile + 1].
 template <typename KeyT>
 __global__ void __launch_bounds__(kSortThreads)
-RadixTileHistogramKernel(const KeyT* __restrict__ keys, const int64_t n, const int shift,
-                         unsigned* __restrict__ tile_hist, const int num_tiles) {
+RadixTileHistogramKernel(const KeyT* __restrict__ keys_in, const KeyT* __restrict__ keys_out,
+                         const KeyT* __restrict__ keys_tmp, const int64_t n, const int pass,
+                         const int passes, unsigned* __restrict__ tile_hist, const int num_tiles,
+                         unsigned long long* __restrict__ tile_bits,
+                         const unsigned long long* __restrict__ varying) {
   __shared__ unsigned count[kSortWaves][kSortBins];  // one sub-histogram per wave: 4x less contention
+  __shared__ unsigned long long wave_bits[kSortWaves][2];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
+  const int shift = 8 * pass;
+  const KeyT* keys = keys_in;
+  if (pass > 0) {
+    const PassRoute route = RoutePass(varying != nullptr ? *varying : ~0ull, pass, passes);
+    if (!route.active) return;
+    keys = PickBuffer<KeyT>(route.src, keys_in, const_cast<KeyT*>(keys_out), const_cast<KeyT*>(keys_tmp));
+  }
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) count[w][tid] = 0;
   __syncthreads();
@@ -83,6 +132,26 @@ RadixTileHistogramKernel(const KeyT* __restrict__ keys, const int64_t n, const i
   for (int r = 0; r < kSortItems; ++r) {  // all loads in flight first
     const int64_t i = base + static_cast<int64_t>(r) * kSortThreads;
     key[r] = i < n ? keys[i] : KeyT(0);
+  }
+  const bool reduce_bits = pass == 0 && tile_bits != nullptr;
+  if (reduce_bits) {
+    unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+      if (base + static_cast<int64_t>(r) * kSortThreads < n) {
+        any |= static_cast<unsigned long long>(key[r]);
+        all &= static_cast<unsigned long long>(key[r]);
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      any |= __shfl_xor(any, d);
+      all &= __shfl_xor(all, d);
+    }
+    if ((tid & 63) == 0) {
+      wave_bits[wave][0] = any;
+      wave_bits[wave][1] = all;
+    }
   }
   // From the second pass on, equal keys sit next to each other, and a power-law batch has runs
   // of thousands of them: 64 lanes adding to ONE counter serialise.  So only the first lane of
@@ -106,6 +175,16 @@ RadixTileHistogramKernel(const KeyT* __restrict__ keys, const int64_t n, const i
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) total += count[w][tid];
   tile_hist[static_cast<size_t>(tid) * num_tiles + blockIdx.x] = total;
+  if (reduce_bits && tid == 0) {
+    unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      any |= wave_bits[w][0];
+      all &= wave_bits[w][1];
+    }
+    tile_bits[2 * blockIdx.x] = any;
+    tile_bits[2 * blockIdx.x + 1] = all;
+  }
 }
 
 //! Block-wide exclusive scan helper (256 threads): returns the exclusive prefix of `v` and the
@@ -135,10 +214,43 @@ __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* tot
 }
 
 //! One workgroup per bin: tile_hist[bin][*] becomes its exclusive prefix over the tiles;
-//! bin_total[bin] receives the sum.
+//! bin_total[bin] receives the sum.  In pass 0 an extra workgroup (blockIdx.x == kSortBins) folds
+//! the tiles' OR/AND words into `varying` (single writer, so nothing has to be zeroed first).
 __global__ void __launch_bounds__(kSortThreads)
 RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
-                     unsigned* __restrict__ bin_total) {
+                     unsigned* __restrict__ bin_total, const int pass, const int passes,
+                     const unsigned long long* __restrict__ tile_bits,
+                     unsigned long long* __restrict__ varying) {
+  if (blockIdx.x == kSortBins) {  // only launched in pass 0
+    __shared__ unsigned long long wave_bits[kSortWaves][2];
+    unsigned long long any = 0ull, all = ~0ull;
+    for (int t = threadIdx.x; t < num_tiles; t += kSortThreads) {
+      any |= tile_bits[2 * t];
+      all &= tile_bits[2 * t + 1];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      any |= __shfl_xor(any, d);
+      all &= __shfl_xor(all, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      wave_bits[threadIdx.x >> 6][0] = any;
+      wave_bits[threadIdx.x >> 6][1] = all;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      any = 0ull;
+      all = ~0ull;
+#pragma unroll
+      for (int w = 0; w < kSortWaves; ++w) {
+        any |= wave_bits[w][0];
+        all &= wave_bits[w][1];
+      }
+      *varying = any & ~all;
+    }
+    return;
+  }
+  if (pass > 0 && varying != nullptr && !RoutePass(*varying, pass, passes).active) return;
   unsigned* row = tile_hist + static_cast<size_t>(blockIdx.x) * num_tiles;
   unsigned carry = 0;
   for (int base = 0; base < num_tiles; base += kSortThreads) {
@@ -177,11 +289,23 @@ __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T 
 
 template <typename KeyT, typename V1, typename V2>
 __global__ void __launch_bounds__(kSortThreads)
-RadixScatterKernel(const KeyT* __restrict__ keys_in, const V1* __restrict__ v1_in,
-                   const V2* __restrict__ v2_in, const int64_t n, const int shift,
+RadixScatterKernel(const KeyT* __restrict__ keys_src, const V1* __restrict__ v1_src,
+                   const V2* __restrict__ v2_src, const int64_t n, const int pass, const int passes,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
-                   const int num_tiles, KeyT* __restrict__ keys_out, V1* __restrict__ v1_out,
-                   V2* __restrict__ v2_out) {
+                   const int num_tiles, KeyT* __restrict__ keys_dst, V1* __restrict__ v1_dst,
+                   V2* __restrict__ v2_dst, KeyT* __restrict__ keys_tmp, V1* __restrict__ v1_tmp,
+                   V2* __restrict__ v2_tmp, const unsigned long long* __restrict__ varying) {
+  // (keys_src, v1_src, v2_src) = the sort's inputs, (.._dst) = its outputs, (.._tmp) = scratch;
+  // which of them this pass reads and writes follows from the passes that run at all
+  const PassRoute route = RoutePass(varying != nullptr ? *varying : ~0ull, pass, passes);
+  if (!route.active) return;
+  const int shift = 8 * pass;
+  const KeyT* __restrict__ keys_in = PickBuffer<KeyT>(route.src, keys_src, keys_dst, keys_tmp);
+  const V1* __restrict__ v1_in = PickBuffer<V1>(route.src, v1_src, v1_dst, v1_tmp);
+  const V2* __restrict__ v2_in = PickBuffer<V2>(route.src, v2_src, v2_dst, v2_tmp);
+  KeyT* __restrict__ keys_out = route.dst == kBufOut ? keys_dst : keys_tmp;
+  V1* __restrict__ v1_out = route.dst == kBufOut ? v1_dst : v1_tmp;
+  V2* __restrict__ v2_out = route.dst == kBufOut ? v2_dst : v2_tmp;
   constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
   __shared__ __attribute__((aligned(16))) unsigned char stage[kSortTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
   __shared__ unsigned digit_base[kSortBins];   // global position of the tile's first key with this digit
@@ -291,7 +415,7 @@ template <typename KeyT, typename V1, typename V2>
 struct RadixSortPlan {
   int passes;
   int num_tiles;
-  size_t keys_tmp, v1_tmp, v2_tmp, tile_hist, bin_total, total;  // byte offsets / total bytes
+  size_t keys_tmp, v1_tmp, v2_tmp, tile_hist, bin_total, tile_bits, varying, total;  // byte offsets
   RadixSortPlan(const size_t n, const int key_bits) {
     passes = (key_bits + 7) / 8;
     if (passes < 1) passes = 1;
@@ -308,6 +432,10 @@ struct RadixSortPlan {
     off += SortAlign(static_cast<size_t>(kSortBins) * num_tiles * sizeof(unsigned));
     bin_total = off;
     off += SortAlign(kSortBins * sizeof(unsigned));
+    tile_bits = off;
+    off += SortAlign(static_cast<size_t>(2) * num_tiles * sizeof(unsigned long long));
+    varying = off;
+    off += SortAlign(sizeof(unsigned long long));
     total = off;
   }
 };
@@ -326,25 +454,20 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   V2* v2_tmp = reinterpret_cast<V2*>(work + plan.v2_tmp);
   unsigned* tile_hist = reinterpret_cast<unsigned*>(work + plan.tile_hist);
   unsigned* bin_total = reinterpret_cast<unsigned*>(work + plan.bin_total);
-  const KeyT* src_k = keys_in;
-  const V1* src_1 = v1_in;
-  const V2* src_2 = v2_in;
+  const bool skip_on_device = plan.passes > kStaticRoutePasses;
+  unsigned long long* tile_bits =
+      skip_on_device ? reinterpret_cast<unsigned long long*>(work + plan.tile_bits) : nullptr;
+  unsigned long long* varying =
+      skip_on_device ? reinterpret_cast<unsigned long long*>(work + plan.varying) : nullptr;
+  const int64_t count = static_cast<int64_t>(n);
   for (int p = 0; p < plan.passes; ++p) {
-    // ping-pong so that the LAST pass writes the caller's output buffers
-    const bool to_out = ((plan.passes - 1 - p) % 2) == 0;
-    KeyT* dst_k = to_out ? keys_out : keys_tmp;
-    V1* dst_1 = to_out ? v1_out : v1_tmp;
-    V2* dst_2 = to_out ? v2_out : v2_tmp;
-    const int shift = 8 * p;
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        src_k, static_cast<int64_t>(n), shift, tile_hist, plan.num_tiles);
-    RadixScanTilesKernel<<<kSortBins, kSortThreads, 0, stream>>>(tile_hist, plan.num_tiles, bin_total);
+        keys_in, keys_out, keys_tmp, count, p, plan.passes, tile_hist, plan.num_tiles, tile_bits, varying);
+    RadixScanTilesKernel<<<kSortBins + (p == 0 && skip_on_device ? 1 : 0), kSortThreads, 0, stream>>>(
+        tile_hist, plan.num_tiles, bin_total, p, plan.passes, tile_bits, varying);
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        src_k, src_1, src_2, static_cast<int64_t>(n), shift, tile_hist, bin_total, plan.num_tiles,
-        dst_k, dst_1, dst_2);
-    src_k = dst_k;
-    src_1 = dst_1;
-    src_2 = dst_2;
+        keys_in, v1_in, v2_in, count, p, plan.passes, tile_hist, bin_total, plan.num_tiles, keys_out,
+        v1_out, v2_out, keys_tmp, v1_tmp, v2_tmp, varying);
   }
 }
 

@@ -298,6 +298,36 @@ def test_transpose_tile_boundaries_and_degenerate_keys(ce, oracle, idx):
                                   oracle.compute_compressed_grad_indices(oi)), (nnz, name)
 
 
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_skips_identity_passes_on_device(ce, oracle, idx):
+    """Radix passes whose digit is the same for every key are skipped on the device and the
+    remaining passes re-route their buffers: every combination of varying digits must still give
+    the stable order in the caller's output arrays (odd and even numbers of working passes)."""
+    rng = np.random.default_rng(21)
+    ndig = np.dtype(idx[0]).itemsize
+    nnz = 3 * 4096 + 123
+    combos = [(0,), (1,), (2,), (3,), (0, 2), (1, 2), (1, 3), (0, 1, 2), (0, 1, 2, 3)]
+    if ndig == 8:
+        combos += [(5,), (0, 5), (2, 4, 6), (1, 2, 3, 4, 5, 6), (0, 1, 2, 3, 4, 5, 6, 7)]
+    for combo in combos:
+        cols = np.zeros(nnz, dtype=np.uint64)
+        for d in range(ndig):
+            hi = 128 if d == ndig - 1 else 256                 # keys stay non-negative
+            if d in combo:
+                cols |= rng.integers(0, hi, nnz).astype(np.uint64) << np.uint64(8 * d)
+            else:
+                cols |= np.uint64(int(rng.integers(0, hi))) << np.uint64(8 * d)   # constant digit
+        cols = cols.astype(idx[0])
+        rows = rng.integers(0, 1000, nnz).astype(idx[0])
+        w = rng.uniform(0, 1, nnz).astype(np.float32)
+        oi, os_, ow = oracle.transpose(rows, cols, w, stable=True)
+        for weights in (None, w):
+            ti, ts, tw = ce.transpose(dev(rows), dev(cols), dev(weights))
+            assert np.array_equal(host(ti), oi) and np.array_equal(host(ts), os_), combo
+            if weights is not None:
+                assert np.array_equal(host(tw), ow), combo
+
+
 def test_backward_compressed_zero_init_without_full_memset(ce, oracle):
     """Compressed gradient with skip_grad_init=False: only rows that can receive atomics and an
     over-allocated tail are zeroed by the library; every other row is overwritten.  The result must
