@@ -459,6 +459,30 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
   StorePack<ElemT, N>(out + sample * width + static_cast<int64_t>(column_lane) * N, result);
 }
 
+//! acc + <row, g> over the N elements of a pack, fp32 accumulation.  16-bit tables use the packed
+//! dot instructions (v_dot2_f32_f16 / v_dot2_f32_bf16: two products and the add per instruction,
+//! no separate conversions).
+template <typename ElemT, int N>
+__device__ __forceinline__ float DotPack(const Pack<ElemT, N>& row, const Pack<ElemT, N>& g, float acc) {
+  if constexpr (std::is_same<ElemT, _Float16>::value) {
+    typedef _Float16 pair_t __attribute__((ext_vector_type(2)));
+    const pair_t* r2 = reinterpret_cast<const pair_t*>(row.v);
+    const pair_t* g2 = reinterpret_cast<const pair_t*>(g.v);
+#pragma unroll
+    for (int e = 0; e < N / 2; ++e) acc = __builtin_amdgcn_fdot2(r2[e], g2[e], acc, false);
+  } else if constexpr (std::is_same<ElemT, __bf16>::value) {
+    typedef __bf16 pair_t __attribute__((ext_vector_type(2)));
+    const pair_t* r2 = reinterpret_cast<const pair_t*>(row.v);
+    const pair_t* g2 = reinterpret_cast<const pair_t*>(g.v);
+#pragma unroll
+    for (int e = 0; e < N / 2; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(r2[e], g2[e], acc, false);
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc += static_cast<float>(row.v[e]) * static_cast<float>(g.v[e]);
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------------------
 // Gradient with respect to the per-lookup weights (an extension: the reference's torch example
 // returns None for it, cuembed_pyt.py:34-35):
@@ -497,6 +521,88 @@ WeightGradKernel(const ElemT* __restrict__ table,
   const ElemT* my_gy = grad_y + sample * width;
   const int chunks = width / N;  // N-element slices per row
 
+  static_assert(kForwardUnroll == 8, "the transposing reduction below is written for 8 partial dots");
+  if (chunks <= group && group >= 8) {
+    // ---- a row fits one pass of the group (every shape up to 64 lanes x 16 B) ----
+    // Software-pipelined: the rows of batch k+1 (and the row ids of batch k+2) are requested
+    // BEFORE the cross-lane reduction of batch k, so loads are in flight during the ~15 dependent
+    // cross-lane steps and a row request never waits for its own id.
+    // The 8 partial dots are folded with a transposing butterfly: each exchange step halves the
+    // number of values a lane still carries (4 + 2 + 1 exchanges leave lane l with the sum, over
+    // its 8-lane subgroup, of lookup l & 7), then log2(group / 8) plain steps finish it --
+    // 7..10 cross-lane operations per 8 lookups instead of 8 x log2(group).
+    const bool has_column = lane_x < chunks;
+    Pack<ElemT, N> g;
+    if (has_column) g = LoadPack<ElemT, N>(my_gy + static_cast<int64_t>(lane_x) * N);
+    const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
+    Pack<ElemT, N> row[kForwardUnroll];
+    IndexT ahead[kForwardUnroll];  // row ids of the batch AFTER the one whose rows are in flight
+    // full batches take the branch-free path; only the last, partial batch is predicated
+    auto request_ids = [&](const int j0) {
+      if (j0 + kForwardUnroll <= hot) {
+#pragma unroll
+        for (int u = 0; u < kForwardUnroll; ++u) ahead[u] = my_idx[j0 + u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < kForwardUnroll; ++u)
+          if (j0 + u < hot) ahead[u] = my_idx[j0 + u];
+      }
+    };
+    auto request_rows = [&](const int j0) {  // consumes `ahead`
+      if (!has_column) return;
+      if (j0 + kForwardUnroll <= hot) {
+#pragma unroll
+        for (int u = 0; u < kForwardUnroll; ++u)
+          row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(ahead[u]) * width);
+      } else {
+#pragma unroll
+        for (int u = 0; u < kForwardUnroll; ++u)
+          if (j0 + u < hot) row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(ahead[u]) * width);
+      }
+    };
+    request_ids(0);
+    request_rows(0);
+    request_ids(kForwardUnroll);
+    for (int j0 = 0; j0 < hot; j0 += kForwardUnroll) {
+      float dot[kForwardUnroll];
+      if (j0 + kForwardUnroll <= hot) {
+#pragma unroll
+        for (int u = 0; u < kForwardUnroll; ++u) dot[u] = has_column ? DotPack<ElemT, N>(row[u], g, 0.f) : 0.f;
+      } else {
+#pragma unroll
+        for (int u = 0; u < kForwardUnroll; ++u)
+          dot[u] = (j0 + u < hot && has_column) ? DotPack<ElemT, N>(row[u], g, 0.f) : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_rows(j0 + kForwardUnroll);
+      request_ids(j0 + 2 * kForwardUnroll);
+      __builtin_amdgcn_sched_barrier(0);
+      float four[4], two[2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // exchange with lane ^ 1: keep the even or the odd lookup of a pair
+        const bool odd = lane_x & 1;
+        const float got = __shfl_xor(odd ? dot[2 * k] : dot[2 * k + 1], 1, group);
+        four[k] = (odd ? dot[2 * k + 1] : dot[2 * k]) + got;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool odd = lane_x & 2;
+        const float got = __shfl_xor(odd ? four[2 * k] : four[2 * k + 1], 2, group);
+        two[k] = (odd ? four[2 * k + 1] : four[2 * k]) + got;
+      }
+      float one;
+      {
+        const bool odd = lane_x & 4;
+        const float got = __shfl_xor(odd ? two[0] : two[1], 4, group);
+        one = (odd ? two[1] : two[0]) + got;
+      }
+      for (int d = 8; d < group; d <<= 1) one += __shfl_xor(one, d, group);
+      // lane l < 8 now holds lookup j0 + l: one coalesced store per batch
+      if (lane_x < kForwardUnroll && j0 + lane_x < hot) my_out[j0 + lane_x] = static_cast<ElemT>(one);
+    }
+    return;
+  }
+
   for (int j0 = 0; j0 < hot; j0 += kForwardUnroll) {
     const int nb = hot - j0 < kForwardUnroll ? hot - j0 : kForwardUnroll;
     float dot[kForwardUnroll];
@@ -514,10 +620,7 @@ WeightGradKernel(const ElemT* __restrict__ table,
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < kForwardUnroll; ++u) {
-        if (u < nb) {
-#pragma unroll
-          for (int e = 0; e < N; ++e) dot[u] += static_cast<float>(row[u].v[e]) * static_cast<float>(g.v[e]);
-        }
+        if (u < nb) dot[u] = DotPack<ElemT, N>(row[u], g, dot[u]);
       }
     }
 #pragma unroll

@@ -241,3 +241,38 @@ def test_forward_csr_skewed_bags_large_batch(ce, oracle, elem, W, B):
         want = oracle.embedding_forward(table, idx, off, weights, num_hots=0, mode=mode, threads=8)
         got = ce.embedding_forward(dev(table), dev(idx), dev(off), dev(weights), num_hots=0, mode=mode)
         assert (bits(got.cpu().numpy()) == bits(want)).all(), mode
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "f16", "bf16"])
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_weight_gradient_all_types_and_layouts(ce, tdtype, idx):
+    """EmbeddingWeightGrad (extension): grad_w[s, j] = <table[idx[s, j]], grad_y[s]>.  Small-integer
+    data keep every partial sum exactly representable (|dot| <= 6 * W... capped below 2^8 for bf16),
+    so the packed-dot / transposing-butterfly kernel must agree EXACTLY with a float64 dot product,
+    whatever order it adds in; widths cover the 2-lane fallback, a masked 9-of-16-lane group, the
+    32- and 64-lane groups and rows wider than a wavefront; fixed hotness (full and partial batches of
+    8 lookups) and ragged CSR bags."""
+    rng = np.random.default_rng(5)
+    ncat = 700
+    for W in (8, 36, 64, 256, 512, 1024):
+        lim = 1 if tdtype == torch.bfloat16 else 2                # bf16 has 8 significant bits
+        table = rng.integers(-lim, lim + 1, (ncat, W)).astype(np.float32)
+        cases = [("fixed", 37, H) for H in (1, 7, 8, 19, 64)] + [("csr", 53, 21)]
+        for layout, B, H in cases:
+            gy = rng.integers(-1, 2, (B, W)).astype(np.float32)
+            if layout == "fixed":
+                offsets = None
+                indices = rng.integers(0, ncat, B * H).astype(idx[0])
+                sample_of = np.repeat(np.arange(B), H)
+            else:
+                lens = rng.integers(0, H + 1, B)
+                lens[3] = 0
+                offsets = np.concatenate([[0], np.cumsum(lens)]).astype(idx[0])
+                indices = rng.integers(0, ncat, int(offsets[-1])).astype(idx[0])
+                sample_of = np.repeat(np.arange(B), lens)
+            want = np.einsum("nw,nw->n", table[indices].astype(np.float64), gy[sample_of].astype(np.float64))
+            assert np.abs(want).max() < 256
+            got = ce.embedding_weight_grad(dev(table).to(tdtype), dev(indices), dev(gy).to(tdtype),
+                                           offsets=dev(offsets), num_hots=0 if layout == "csr" else H)
+            assert got.dtype == tdtype and got.numel() == indices.size
+            assert np.array_equal(got.float().cpu().numpy().astype(np.float64), want), (W, layout, H)
