@@ -131,11 +131,22 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if shared_gpus:
+        backend = "gloo" if shared_gpus else "nccl"
+        if backend == "nccl":
+            try:
+                dist.init_process_group(backend="nccl", device_id=device)
+                probe = torch.zeros(1, device=device)
+                dist.all_reduce(probe)          # RCCL communicators are created lazily: fail here, not mid-run
+                torch.cuda.synchronize()
+            except Exception as e:              # the forward has no collective; only the timing
+                sys.stderr.write("bench.py: RCCL unavailable (%s); timing reductions over gloo\n" % e)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+        if backend == "gloo":
             dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)
-    reduce_device = torch.device("cpu") if shared_gpus else device
+        shared_gpus = shared_gpus or backend == "gloo"
+    reduce_device = torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else device
 
     cfg = dict(WORKLOADS[args.workload])
     alpha = cfg["alpha"] if args.alpha is None else args.alpha
@@ -206,7 +217,8 @@ def main():
         "config": {"workload": cfg["desc"], "name": args.workload, "alpha": alpha,
                    "global_batch": world * B, "per_gpu_batch": B, "index_dtype": "int32",
                    "index_batches_cycled": nb, "parallelism": "batch-shard x%d, table replicated" % world,
-                   "ranks_share_gpus": shared_gpus,
+                   "ranks_share_gpus": world > ngpu,
+                   "rendezvous_backend": None if dist is None else dist.get_backend(),
                    "algorithmic_bytes_per_step_per_gpu": bytes_per_step[0]},
         "pct_of_hbm_peak": round(100.0 * total_bytes / wall_max / 1e9 / (HBM_PEAK_GBPS * world), 2),
         "roofline": {"bound": "hbm", "kernel": "GatherReduceKernel", "achieved": round(achieved, 2),
