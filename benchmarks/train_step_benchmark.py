@@ -31,6 +31,7 @@ def main():
     p.add_argument("--hotness", type=int, default=64)
     p.add_argument("--alpha", type=float, default=1.15)
     p.add_argument("--exchange", default="sparse", choices=["sparse", "dense", "none"])
+    p.add_argument("--sparse_algorithm", default="auto", choices=["auto", "allgather", "owner"])
     a = p.parse_args()
     import numpy as np
     import torch
@@ -76,7 +77,7 @@ def main():
             rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
             ev[3].record()
             if a.exchange == "sparse" and use_dist:
-                D.allreduce_sparse_grad(rows, inv, a.rows)
+                D.allreduce_sparse_grad(rows, inv, a.rows, algorithm=a.sparse_algorithm)
         ev[4].record()
 
     def sync():

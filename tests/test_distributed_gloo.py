@@ -66,13 +66,26 @@ def _worker(rank, world, port, csr, ret):
         remap = O.compute_compressed_grad_indices(t_idx)
         nu = int(remap[-1]) + 1
         comp, inv = O.embedding_backward(gy, W, nu, t_idx, t_sid, remap, t_w)
-        ids, rows = D.allreduce_sparse_grad(torch.from_numpy(comp), torch.from_numpy(inv), ncat)
-        rebuilt = np.zeros_like(want)
-        rebuilt[ids.numpy()] = rows.numpy()
-        assert np.array_equal(rebuilt, want)
+        for algorithm in ("allgather", "owner", "auto"):
+            ids, rows = D.allreduce_sparse_grad(torch.from_numpy(comp), torch.from_numpy(inv), ncat,
+                                                algorithm=algorithm)
+            assert np.all(np.diff(ids.numpy()) > 0), algorithm          # ascending, no duplicates
+            rebuilt = np.zeros_like(want)
+            rebuilt[ids.numpy()] = rows.numpy()
+            assert np.array_equal(rebuilt, want), algorithm
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
+
+
+def test_batch_shard_world3_owner_exchange(oracle):
+    """Three ranks: uneven sample shards AND uneven owner ranges (300 ids over 3 owners is even,
+    101 samples are not); a rank may own ids it has no lookups for."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), False, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok", 2: "ok"}
 
 
 @pytest.mark.parametrize("csr", [False, True], ids=["fixed", "csr"])

@@ -46,9 +46,10 @@ def test_fwd_bwd_allreduce_world1(oracle):
         remap = ce.compute_compressed_grad_indices(t_idx)
         nu = int(remap[-1].item()) + 1
         rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
-        ids, summed = D.allreduce_sparse_grad(rows, inv, ncat)          # RCCL all-gather based
-        rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device="cuda")
-        rebuilt[ids] = summed
-        assert np.array_equal(rebuilt.cpu().numpy().view(np.uint16), o_grad.view(np.uint16))
+        for algorithm in ("allgather", "owner"):       # RCCL all-gather / all-to-all + all-gather
+            ids, summed = D.allreduce_sparse_grad(rows, inv, ncat, algorithm=algorithm)
+            rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device="cuda")
+            rebuilt[ids] = summed
+            assert np.array_equal(rebuilt.cpu().numpy().view(np.uint16), o_grad.view(np.uint16)), algorithm
     finally:
         dist.destroy_process_group()
