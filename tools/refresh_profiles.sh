@@ -1,0 +1,32 @@
+#!/bin/bash
+# Re-measures everything DESIGN.md section 5 quotes and writes the raw material under
+# gpurun_out/refresh/ (copy the summaries you want judged into profiles/).  Run on the GPU box:
+#     gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/refresh
+rm -rf "$O"; mkdir -p "$O"
+cd "$R"
+python bench.py > "$O/bench_c2_line.json" 2> "$O/bench.err"
+C2="--num_categories 10000000 --embed_width 256 --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true"
+C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 --hotness 128 --csr_input=true --weighted_sum=true"
+{
+  for ex in "" "--bounded_sort" "--use_int64_indices" "--use_int64_indices --bounded_sort"; do
+    echo "== C2/C4 $ex"; benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
+  done
+  for ex in "" "--bounded_sort"; do
+    echo "== C3 $ex"; benchmarks/manual_benchmark $C3 --iterations 30 $ex 2>&1 | grep -E "Iterations"
+  done
+} > "$O/manual_benchmark_c2_c3.txt"
+python tools/secondary_kernels.py > "$O/secondary_kernels.txt" 2>&1
+python benchmarks/train_step_benchmark.py --exchange none > "$O/train_step_none.json" 2> "$O/train_step.err"
+python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
+# profiler passes last (they clock lower); the program goes directly after `--`
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-cpu-baseline > "$O/prof_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pipeline" -- "$R/benchmarks/manual_benchmark" $C2 --iterations 10 --clear_caches=false > "$O/prof_pipeline.log" 2>&1
+cd "$R"
+python tools/rocprof_summary.py "$O/prof_bench" > "$O/bench_c2_kernel_trace_stats.txt" 2>/dev/null
+python tools/rocprof_summary.py "$O/prof_pipeline" > "$O/pipeline_c2_kernel_trace_stats.txt" 2>/dev/null
+rm -rf "$O/prof_bench" "$O/prof_pipeline"   # raw traces are large; the summaries stay
+ls -la "$O"
