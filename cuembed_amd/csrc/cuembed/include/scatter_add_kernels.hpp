@@ -83,7 +83,9 @@ __host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int 
                                                     int lanes_per_row, int elems_per_lane,
                                                     bool weighted) {
   const size_t n = static_cast<size_t>(segments_per_block) * segment_len;
-  size_t bytes = (n + 2) * sizeof(IndexT) + n * sizeof(IndexT);
+  // ids are staged as 32-bit whatever IndexT is: nnz and num_grad_embedding_rows are `int` in the
+  // API (embedding_lookup.cuh:423-435), so every row id and sample id fits
+  size_t bytes = (n + 2) * sizeof(int32_t) + n * sizeof(int32_t);
   bytes = (bytes + 15) / 16 * 16;
   if (weighted) bytes += n * sizeof(GradT);
   bytes = (bytes + 15) / 16 * 16;
@@ -140,9 +142,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * lanes + lane_x) * N;
 
   // ---- LDS carve-up (must match ScatterStageBytes) ----
-  IndexT* st_rows = reinterpret_cast<IndexT*>(lds_raw);            // [block_len + 2], [0] = lookup before
-  IndexT* st_sids = st_rows + block_len + 2;                       // [block_len]
-  size_t off = ((static_cast<size_t>(block_len) * 2 + 2) * sizeof(IndexT) + 15) / 16 * 16;
+  int32_t* st_rows = reinterpret_cast<int32_t*>(lds_raw);          // [block_len + 2], [0] = lookup before
+  int32_t* st_sids = st_rows + block_len + 2;                      // [block_len]
+  size_t off = ((static_cast<size_t>(block_len) * 2 + 2) * sizeof(int32_t) + 15) / 16 * 16;
   GradT* st_w = reinterpret_cast<GradT*>(lds_raw + off);
   if (kWeighted) off += static_cast<size_t>(block_len) * sizeof(GradT);
   off = (off + 15) / 16 * 16;
@@ -157,12 +159,12 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     const int nthreads = lanes * segments_per_block;
     for (int k = tid; k < block_len + 2; k += nthreads) {
       const int64_t g = block_begin - 1 + k;
-      st_rows[k] = (g >= 0 && g < nnz) ? rows[g] : static_cast<IndexT>(-1);
+      st_rows[k] = (g >= 0 && g < nnz) ? static_cast<int32_t>(rows[g]) : -1;
     }
     for (int k = tid; k < block_len; k += nthreads) {
       const int64_t g = block_begin + k;
       if (g < nnz) {
-        st_sids[k] = sample_ids[g];  // (non-temporal loads here measured 6-20 % slower)
+        st_sids[k] = static_cast<int32_t>(sample_ids[g]);  // (non-temporal loads here measured 6-20 % slower)
         if constexpr (kWeighted) st_w[k] = weights[g];
       }
     }
@@ -179,8 +181,8 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 
   if (active) {
     const int count = static_cast<int>((begin + segment_len < nnz) ? segment_len : nnz - begin);
-    const IndexT* my_rows = st_rows + 1 + seg_off;   // my_rows[-1] = lookup before the segment
-    const IndexT* my_sids = st_sids + seg_off;
+    const int32_t* my_rows = st_rows + 1 + seg_off;  // my_rows[-1] = lookup before the segment
+    const int32_t* my_sids = st_sids + seg_off;
     const GradT* my_w = st_w + seg_off;
 
     // A run is "shared" when it also has lookups in a neighbouring segment.
