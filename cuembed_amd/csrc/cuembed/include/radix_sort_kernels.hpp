@@ -73,33 +73,99 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
 // the caller's output.  The host enqueues the same launches whatever the data (no read-back, graph
 // capturable): int64 indices below 2^24 cost 3 working passes + 5 empty ones, not 8.
 // Reading `varying` first costs every kernel ~1 us, so sorts of at most kStaticRoutePasses passes
-// (a caller-supplied key bound, where a constant digit is unlikely) pass varying == nullptr and
+// (a caller-supplied key bound, where a constant digit is unlikely) pass state == nullptr and
 // take the fixed route.
+//
+// 64-bit arrays travel NARROW between passes.  Sample ids are < nnz <= INT_MAX, so an int64
+// payload is always kept as 32 bits in the scratch buffers; int64 keys are kept as their low 32
+// bits when their high halves do not vary (known from the caller's bound, or from `varying` on the
+// device -- the constant high half is put back on the way out).  A scratch buffer of n 64-bit
+// elements then holds TWO 32-bit arrays, so all intermediate passes ping-pong inside the scratch
+// and only the last one touches the caller's output: a middle pass moves 8 bytes per pair and
+// direction instead of 16.
 constexpr int kStaticRoutePasses = 3;
-enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp = 2 };
+enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
+enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
 
-struct PassRoute {
-  bool active;
-  int src, dst;
+//! What the device knows about the keys after pass 0: state[0] = bits in which keys differ,
+//! state[1] = AND of all keys.  state == nullptr: fixed route, all passes run.
+struct PassPlan {
+  bool active;        //!< this pass moves data
+  bool first;         //!< reads the caller's input
+  int later;          //!< working passes after this one
+  bool narrow_keys;   //!< 64-bit keys are stored as 32 bits in the scratch buffers
+  unsigned long long key_high;  //!< constant high half to put back (narrow_keys only)
 };
 
-//! Pass 0 always runs.  Buffers alternate out/tmp backwards from the last active pass.
-__device__ __forceinline__ PassRoute RoutePass(const unsigned long long varying, const int pass,
-                                               const int passes) {
-  unsigned active = 1u;
+__device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restrict__ state, const int pass,
+                                             const int passes, const int narrow_mode) {
+  const unsigned long long varying = state != nullptr ? state[0] : ~0ull;
+  unsigned active = 1u;  // pass 0 always runs
   for (int q = 1; q < passes; ++q)
     if ((varying >> (8 * q)) & 0xffull) active |= 1u << q;
-  PassRoute route;
-  route.active = (active >> pass) & 1u;
-  const int later = __popc(active >> (pass + 1));
-  route.dst = (later % 2 == 0) ? kBufOut : kBufTmp;
-  route.src = pass == 0 ? kBufIn : (route.dst == kBufOut ? kBufTmp : kBufOut);
-  return route;
+  PassPlan plan;
+  plan.active = (active >> pass) & 1u;
+  plan.first = pass == 0;
+  plan.later = __popc(active >> (pass + 1));
+  plan.narrow_keys = narrow_mode == kNarrowAlways ||
+                     (narrow_mode == kNarrowIfConstantHigh && state != nullptr && (varying >> 32) == 0);
+  plan.key_high = (narrow_mode == kNarrowIfConstantHigh && plan.narrow_keys) ? (state[1] & 0xffffffff00000000ull) : 0ull;
+  return plan;
 }
 
+//! Buffers of one array.  Wide: out / scratch alternate backwards from the last working pass.
+//! Narrow: the two halves of the scratch alternate, the last working pass writes `out`.
+struct ArrayRoute {
+  int src, dst;
+};
+__device__ __forceinline__ ArrayRoute RouteArray(const PassPlan& plan, const bool narrow) {
+  ArrayRoute r;
+  if (narrow) {
+    r.dst = plan.later == 0 ? kBufOut : (plan.later & 1 ? kBufTmp1 : kBufTmp0);
+    r.src = plan.first ? kBufIn : ((plan.later + 1) & 1 ? kBufTmp1 : kBufTmp0);
+  } else {
+    r.dst = (plan.later % 2 == 0) ? kBufOut : kBufTmp0;
+    r.src = plan.first ? kBufIn : (r.dst == kBufOut ? kBufTmp0 : kBufOut);
+  }
+  return r;
+}
+
+//! One array of the sort in its three places; `tmp` holds n elements of T, or two arrays of n
+//! 32-bit elements when the array travels narrow.
 template <typename T>
-__device__ __forceinline__ T* PickBuffer(const int which, const T* in, T* out, T* tmp) {
-  return which == kBufIn ? const_cast<T*>(in) : (which == kBufOut ? out : tmp);
+struct SortArray {
+  const T* in;
+  T* out;
+  T* tmp;
+};
+
+//! Reads kSortItems elements per lane (positions pos0 + r * stride, r = 0..) from wherever the
+//! route says.  `high` is OR-ed onto narrow elements.
+template <typename T>
+__device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int where, const bool narrow,
+                                           const int64_t n, const int64_t pos0, const int stride, const T high,
+                                           T (&item)[kSortItems]) {
+  if constexpr (sizeof(T) == 8) {
+    if (narrow && where >= kBufTmp0) {
+      const unsigned* p = reinterpret_cast<const unsigned*>(a.tmp) + (where == kBufTmp1 ? n : 0);
+#pragma unroll
+      for (int r = 0; r < kSortItems; ++r) {
+        const int64_t i = pos0 + static_cast<int64_t>(r) * stride;
+        item[r] = i < n ? static_cast<T>(static_cast<T>(p[i]) | high) : T(0);
+      }
+      return;
+    }
+  }
+  const T* p = where == kBufIn ? a.in : (where == kBufOut ? a.out : a.tmp);
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = pos0 + static_cast<int64_t>(r) * stride;
+    if constexpr (std::is_empty<T>::value) {
+      (void)i;
+    } else {
+      item[r] = i < n ? p[i] : T();
+    }
+  }
 }
 
 //! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
@@ -107,32 +173,31 @@ __device__ __forceinline__ T* PickBuffer(const int which, const T* in, T* out, T
 //! its keys go to tile_bits[2 * tile], [2 * tile + 1].
 template <typename KeyT>
 __global__ void __launch_bounds__(kSortThreads)
-RadixTileHistogramKernel(const KeyT* __restrict__ keys_in, const KeyT* __restrict__ keys_out,
-                         const KeyT* __restrict__ keys_tmp, const int64_t n, const int pass,
-                         const int passes, unsigned* __restrict__ tile_hist, const int num_tiles,
+RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int pass, const int passes,
+                         const int narrow_mode, unsigned* __restrict__ tile_hist, const int num_tiles,
                          unsigned long long* __restrict__ tile_bits,
-                         const unsigned long long* __restrict__ varying) {
+                         const unsigned long long* __restrict__ state) {
   __shared__ unsigned count[kSortWaves][kSortBins];  // one sub-histogram per wave: 4x less contention
   __shared__ unsigned long long wave_bits[kSortWaves][2];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int shift = 8 * pass;
-  const KeyT* keys = keys_in;
+  int where = kBufIn;
+  bool narrow = false;
+  KeyT high = 0;
   if (pass > 0) {
-    const PassRoute route = RoutePass(varying != nullptr ? *varying : ~0ull, pass, passes);
-    if (!route.active) return;
-    keys = PickBuffer<KeyT>(route.src, keys_in, const_cast<KeyT*>(keys_out), const_cast<KeyT*>(keys_tmp));
+    const PassPlan plan = PlanPass(state, pass, passes, narrow_mode);
+    if (!plan.active) return;
+    narrow = plan.narrow_keys;
+    high = static_cast<KeyT>(plan.key_high);
+    where = RouteArray(plan, narrow).src;
   }
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) count[w][tid] = 0;
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile + tid;
   KeyT key[kSortItems];
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {  // all loads in flight first
-    const int64_t i = base + static_cast<int64_t>(r) * kSortThreads;
-    key[r] = i < n ? keys[i] : KeyT(0);
-  }
+  LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
   const bool reduce_bits = pass == 0 && tile_bits != nullptr;
   if (reduce_bits) {
     unsigned long long any = 0ull, all = ~0ull;
@@ -215,12 +280,12 @@ __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* tot
 
 //! One workgroup per bin: tile_hist[bin][*] becomes its exclusive prefix over the tiles;
 //! bin_total[bin] receives the sum.  In pass 0 an extra workgroup (blockIdx.x == kSortBins) folds
-//! the tiles' OR/AND words into `varying` (single writer, so nothing has to be zeroed first).
+//! the tiles' OR/AND words into `state` (single writer, so nothing has to be zeroed first).
 __global__ void __launch_bounds__(kSortThreads)
 RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
                      unsigned* __restrict__ bin_total, const int pass, const int passes,
                      const unsigned long long* __restrict__ tile_bits,
-                     unsigned long long* __restrict__ varying) {
+                     unsigned long long* __restrict__ state) {
   if (blockIdx.x == kSortBins) {  // only launched in pass 0
     __shared__ unsigned long long wave_bits[kSortWaves][2];
     unsigned long long any = 0ull, all = ~0ull;
@@ -246,11 +311,12 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
         any |= wave_bits[w][0];
         all &= wave_bits[w][1];
       }
-      *varying = any & ~all;
+      state[0] = any & ~all;
+      state[1] = all;
     }
     return;
   }
-  if (pass > 0 && varying != nullptr && !RoutePass(*varying, pass, passes).active) return;
+  if (pass > 0 && state != nullptr && !PlanPass(state, pass, passes, kNarrowNever).active) return;
   unsigned* row = tile_hist + static_cast<size_t>(blockIdx.x) * num_tiles;
   unsigned carry = 0;
   for (int base = 0; base < num_tiles; base += kSortThreads) {
@@ -270,10 +336,25 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
 //! global stores of a wavefront are runs of consecutive addresses (one run per digit present)
 //! instead of 64 scattered elements: 2-3x faster on the low, uniformly distributed digits.
 template <typename T>
+__device__ __forceinline__ void StoreRouted(const SortArray<T>& a, const int where, const bool narrow,
+                                            const int64_t n, const unsigned dest, const T value) {
+  if constexpr (sizeof(T) == 8) {
+    if (narrow && where >= kBufTmp0) {
+      unsigned* p = reinterpret_cast<unsigned*>(a.tmp) + (where == kBufTmp1 ? n : 0);
+      p[dest] = static_cast<unsigned>(value);
+      return;
+    }
+  }
+  T* p = where == kBufOut ? a.out : a.tmp;
+  p[dest] = value;
+}
+
+template <typename T>
 __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T (&item)[kSortItems],
                                               const unsigned (&slot)[kSortItems],
                                               const unsigned (&dest)[kSortItems], const int count,
-                                              T* __restrict__ out) {
+                                              const SortArray<T>& a, const int where, const bool narrow,
+                                              const int64_t n) {
   T* stage = reinterpret_cast<T*>(stage_raw);
   __syncthreads();  // previous user of the staging buffer is done
 #pragma unroll
@@ -283,29 +364,27 @@ __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T 
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const int q = r * kSortThreads + threadIdx.x;
-    if (q < count) out[dest[r]] = stage[q];
+    if (q < count) StoreRouted<T>(a, where, narrow, n, dest[r], stage[q]);
   }
 }
 
 template <typename KeyT, typename V1, typename V2>
 __global__ void __launch_bounds__(kSortThreads)
-RadixScatterKernel(const KeyT* __restrict__ keys_src, const V1* __restrict__ v1_src,
-                   const V2* __restrict__ v2_src, const int64_t n, const int pass, const int passes,
+RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
+                   const int64_t n, const int pass, const int passes, const int narrow_mode,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
-                   const int num_tiles, KeyT* __restrict__ keys_dst, V1* __restrict__ v1_dst,
-                   V2* __restrict__ v2_dst, KeyT* __restrict__ keys_tmp, V1* __restrict__ v1_tmp,
-                   V2* __restrict__ v2_tmp, const unsigned long long* __restrict__ varying) {
-  // (keys_src, v1_src, v2_src) = the sort's inputs, (.._dst) = its outputs, (.._tmp) = scratch;
-  // which of them this pass reads and writes follows from the passes that run at all
-  const PassRoute route = RoutePass(varying != nullptr ? *varying : ~0ull, pass, passes);
-  if (!route.active) return;
+                   const int num_tiles, const unsigned long long* __restrict__ state) {
+  // which of (caller's input, caller's output, scratch) this pass reads and writes follows from
+  // the passes that run at all and from how each array is stored in the scratch
+  const PassPlan plan = PlanPass(state, pass, passes, narrow_mode);
+  if (!plan.active) return;
   const int shift = 8 * pass;
-  const KeyT* __restrict__ keys_in = PickBuffer<KeyT>(route.src, keys_src, keys_dst, keys_tmp);
-  const V1* __restrict__ v1_in = PickBuffer<V1>(route.src, v1_src, v1_dst, v1_tmp);
-  const V2* __restrict__ v2_in = PickBuffer<V2>(route.src, v2_src, v2_dst, v2_tmp);
-  KeyT* __restrict__ keys_out = route.dst == kBufOut ? keys_dst : keys_tmp;
-  V1* __restrict__ v1_out = route.dst == kBufOut ? v1_dst : v1_tmp;
-  V2* __restrict__ v2_out = route.dst == kBufOut ? v2_dst : v2_tmp;
+  constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
+  constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
+  constexpr bool kNarrowV1 = kHasV1 && sizeof(V1) == 8;  // sample ids < nnz <= INT_MAX
+  const ArrayRoute key_route = RouteArray(plan, plan.narrow_keys);
+  const ArrayRoute v1_route = RouteArray(plan, kNarrowV1);
+  const ArrayRoute v2_route = RouteArray(plan, false);
   constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
   __shared__ __attribute__((aligned(16))) unsigned char stage[kSortTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
   __shared__ unsigned digit_base[kSortBins];   // global position of the tile's first key with this digit
@@ -328,20 +407,14 @@ RadixScatterKernel(const KeyT* __restrict__ keys_src, const V1* __restrict__ v1_
   // ---- load (everything in flight at once), then rank inside the wave ----
   const int64_t wave_base = tile_base + wave * (64 * kSortItems);
   KeyT key[kSortItems];
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const int64_t i = wave_base + r * 64 + lane;
-    key[r] = i < n ? keys_in[i] : KeyT(0);
-  }
-  // the first payload is requested now as well, so that its latency overlaps the ranking
+  LoadRouted<KeyT>(keys, key_route.src, plan.narrow_keys, n, wave_base + lane, 64,
+                   static_cast<KeyT>(plan.key_high), key);
+  // A 32-bit first payload is requested now as well, so that its latency overlaps the ranking.
+  // A 64-bit one would push the kernel past 128 VGPRs (3 instead of 4 resident workgroups per CU,
+  // i.e. a second round for a quarter of the 1024 tiles); it is loaded after the keys have left.
+  constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
   V1 item1[kSortItems];
-  if constexpr (!std::is_same<V1, NoPayload>::value) {
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-      const int64_t i = wave_base + r * 64 + lane;
-      if (i < n) item1[r] = v1_in[i];
-    }
-  }
+  if constexpr (kEarlyV1) LoadRouted<V1>(v1, v1_route.src, kNarrowV1, n, wave_base + lane, 64, V1(0), item1);
   unsigned slot[kSortItems];  // first: rank in wave; finally: tile-local position in digit order
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
@@ -393,19 +466,18 @@ RadixScatterKernel(const KeyT* __restrict__ keys_src, const V1* __restrict__ v1_
       const KeyT k = stage_keys[q];
       const unsigned digit = static_cast<unsigned>((k >> shift) & 0xff);
       dest[r] = digit_base[digit] + (static_cast<unsigned>(q) - tile_start[digit]);
-      keys_out[dest[r]] = k;
+      StoreRouted<KeyT>(keys, key_route.dst, plan.narrow_keys, n, dest[r], k);
     }
   }
   // ---- payloads take the same route ----
-  if constexpr (!std::is_same<V1, NoPayload>::value) StageAndStore<V1>(stage, item1, slot, dest, count, v1_out);
-  if constexpr (!std::is_same<V2, NoPayload>::value) {
+  if constexpr (kHasV1) {
+    if constexpr (!kEarlyV1) LoadRouted<V1>(v1, v1_route.src, kNarrowV1, n, wave_base + lane, 64, V1(0), item1);
+    StageAndStore<V1>(stage, item1, slot, dest, count, v1, v1_route.dst, kNarrowV1, n);
+  }
+  if constexpr (kHasV2) {
     V2 item[kSortItems];
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-      const int64_t i = wave_base + r * 64 + lane;
-      if (i < n) item[r] = v2_in[i];
-    }
-    StageAndStore<V2>(stage, item, slot, dest, count, v2_out);
+    LoadRouted<V2>(v2, v2_route.src, false, n, wave_base + lane, 64, V2(), item);
+    StageAndStore<V2>(stage, item, slot, dest, count, v2, v2_route.dst, false, n);
   }
 }
 
@@ -435,39 +507,44 @@ struct RadixSortPlan {
     tile_bits = off;
     off += SortAlign(static_cast<size_t>(2) * num_tiles * sizeof(unsigned long long));
     varying = off;
-    off += SortAlign(sizeof(unsigned long long));
+    off += SortAlign(2 * sizeof(unsigned long long));
     total = off;
   }
 };
 
 //! Stable sort of n (key, v1[, v2]) by the low `key_bits` bits of the key (keys must be
 //! non-negative and < 2^key_bits).  Inputs are not modified; outputs and `work` (at least
-//! RadixSortPlan::total bytes) must not overlap the inputs.
+//! RadixSortPlan::total bytes) must not overlap the inputs.  A 64-bit v1 must hold values
+//! below 2^32 (it is kept as 32 bits between passes; here: sample ids < nnz <= INT_MAX).
 template <typename KeyT, typename V1, typename V2>
 inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in, V1* v1_out,
                            const V2* v2_in, V2* v2_out, const size_t n, const int key_bits,
                            char* work, hipStream_t stream) {
   if (n == 0) return;
   const RadixSortPlan<KeyT, V1, V2> plan(n, key_bits);
-  KeyT* keys_tmp = reinterpret_cast<KeyT*>(work + plan.keys_tmp);
-  V1* v1_tmp = reinterpret_cast<V1*>(work + plan.v1_tmp);
-  V2* v2_tmp = reinterpret_cast<V2*>(work + plan.v2_tmp);
+  const SortArray<KeyT> keys{keys_in, keys_out, reinterpret_cast<KeyT*>(work + plan.keys_tmp)};
+  const SortArray<V1> v1{v1_in, v1_out, reinterpret_cast<V1*>(work + plan.v1_tmp)};
+  const SortArray<V2> v2{v2_in, v2_out, reinterpret_cast<V2*>(work + plan.v2_tmp)};
   unsigned* tile_hist = reinterpret_cast<unsigned*>(work + plan.tile_hist);
   unsigned* bin_total = reinterpret_cast<unsigned*>(work + plan.bin_total);
   const bool skip_on_device = plan.passes > kStaticRoutePasses;
   unsigned long long* tile_bits =
       skip_on_device ? reinterpret_cast<unsigned long long*>(work + plan.tile_bits) : nullptr;
-  unsigned long long* varying =
+  unsigned long long* state =
       skip_on_device ? reinterpret_cast<unsigned long long*>(work + plan.varying) : nullptr;
+  int narrow_mode = kNarrowNever;
+  if (sizeof(KeyT) == 8) {
+    if (key_bits <= 32) narrow_mode = kNarrowAlways;            // the caller's bound says so
+    else if (skip_on_device) narrow_mode = kNarrowIfConstantHigh;  // decided from the keys themselves
+  }
   const int64_t count = static_cast<int64_t>(n);
   for (int p = 0; p < plan.passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        keys_in, keys_out, keys_tmp, count, p, plan.passes, tile_hist, plan.num_tiles, tile_bits, varying);
+        keys, count, p, plan.passes, narrow_mode, tile_hist, plan.num_tiles, tile_bits, state);
     RadixScanTilesKernel<<<kSortBins + (p == 0 && skip_on_device ? 1 : 0), kSortThreads, 0, stream>>>(
-        tile_hist, plan.num_tiles, bin_total, p, plan.passes, tile_bits, varying);
+        tile_hist, plan.num_tiles, bin_total, p, plan.passes, tile_bits, state);
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        keys_in, v1_in, v2_in, count, p, plan.passes, tile_hist, bin_total, plan.num_tiles, keys_out,
-        v1_out, v2_out, keys_tmp, v1_tmp, v2_tmp, varying);
+        keys, v1, v2, count, p, plan.passes, narrow_mode, tile_hist, bin_total, plan.num_tiles, state);
   }
 }
 
