@@ -47,7 +47,8 @@ template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream,
-                             const int64_t zero_rows /* > 0: zero only what needs it, see below */) {
+                             const int64_t zero_rows /* > 0: zero only what needs it, see below */,
+                             const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */) {
   const int slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row, nnz);
   const int lanes = split.lanes_per_row / slices;  // lanes of one column slice
   int segments_per_block = lanes >= kDefaultBlockThreads ? 1 : kDefaultBlockThreads / lanes;
@@ -78,10 +79,10 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
       ScatterStageBytes<GradT, IndexT>(segments_per_block, segment_len, lanes, N, weights != nullptr);
   if (weights != nullptr)
     SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out, slices);
+        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out, slices, run_ids, inverse_mapping);
   else
     SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out, slices);
+        grad_y, width, rows, sample_ids, weights, nnz, segment_len, grad_out, slices, run_ids, inverse_mapping);
 }
 
 }  // namespace detail
@@ -117,12 +118,7 @@ void EmbeddingBackward(const GradT* grad_y,
   const IndexT* rows =
       transpose_remapped_indices != nullptr ? transpose_remapped_indices : transpose_indices;
 
-  if (transpose_remapped_indices != nullptr && nnz > 0) {
-    CUEMBED_ASSERT(inverse_mapping != nullptr);
-    const int threads = detail::kDefaultBlockThreads;
-    detail::CompactRunHeadsKernel<IndexT><<<(nnz + threads - 1) / threads, threads, 0, stream>>>(
-        transpose_indices, transpose_remapped_indices, inverse_mapping, nnz);
-  }
+  if (transpose_remapped_indices != nullptr && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
   // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
   // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
   // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
@@ -136,6 +132,7 @@ void EmbeddingBackward(const GradT* grad_y,
   if (nnz <= 0) return;
   const int64_t zero_rows = (!skip_grad_init && compressed) ? num_grad_embedding_rows : 0;
 
+  const IndexT* run_ids = compressed ? transpose_indices : nullptr;  // inverse mapping is written by the scatter
   const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
   const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
   ElemT* out = reinterpret_cast<ElemT*>(grad_embedding);
@@ -143,15 +140,15 @@ void EmbeddingBackward(const GradT* grad_y,
   constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
   if (split.elems_per_lane == kMaxN)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w,
-                                                   nnz, out, split, stream, zero_rows);
+                                                   nnz, out, split, stream, zero_rows, run_ids, inverse_mapping);
   else if (split.elems_per_lane == kMaxN / 2)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows,
                                                        transpose_sample_ids, w, nnz, out, split,
-                                                       stream, zero_rows);
+                                                       stream, zero_rows, run_ids, inverse_mapping);
   else
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows,
                                                        transpose_sample_ids, w, nnz, out, split,
-                                                       stream, zero_rows);
+                                                       stream, zero_rows, run_ids, inverse_mapping);
 }
 
 }  // namespace cuembed

@@ -129,7 +129,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int64_t nnz,
                           const int segment_len,
                           GradT* __restrict__ grad_out,
-                          const int column_slices) {  // 1, 2 or 4: see ColumnSlice
+                          const int column_slices,  // 1, 2 or 4: see ColumnSlice
+                          const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
+                          IndexT* __restrict__ inverse_mapping) {    // ... and where the id of every run goes
   using A = Arith<float>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane_x = threadIdx.x;
@@ -171,6 +173,18 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     if (lane_x == 0) part_flags[seg] = 0;
   }
   __syncthreads();
+  // Compressed gradient: inverse_mapping[dense id] = table row id, written at the first lookup of
+  // every run (the reference's CompactSparseIndicesKernel, embedding_lookup_kernels.cuh:289-302, is
+  // a separate launch over all nnz; here the dense ids are already in LDS and only the run heads
+  // load their table row id).
+  if (run_ids != nullptr && cs.slice == 0) {
+    const int tid = seg * lanes + lane_x;
+    const int nthreads = lanes * segments_per_block;
+    for (int k = tid; k < block_len; k += nthreads) {
+      const int64_t g = block_begin + k;
+      if (g < nnz && st_rows[k + 1] != st_rows[k]) inverse_mapping[st_rows[k + 1]] = run_ids[g];
+    }
+  }
 
   const int seg_off = seg * segment_len;  // offset of this segment inside the block
   const int64_t begin = block_begin + seg_off;
@@ -330,19 +344,6 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
   const int64_t end = begin + kZeroTailRowsPerBlock < num_rows ? begin + kZeroTailRowsPerBlock : num_rows;
   for (int64_t i = begin * width + threadIdx.x; i < end * width; i += blockDim.x)
     grad_out[i] = static_cast<GradT>(0);
-}
-
-//! inverse_mapping[remapped[i]] = indices[i] at the first lookup of every run
-//! (reference: CompactSparseIndicesKernel, embedding_lookup_kernels.cuh:289-302).
-template <typename IndexT>
-__global__ void CompactRunHeadsKernel(const IndexT* __restrict__ indices,
-                                      const IndexT* __restrict__ remapped,
-                                      IndexT* __restrict__ inverse_mapping,
-                                      const int64_t nnz) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= nnz) return;
-  const IndexT v = indices[i];
-  if (i == 0 || indices[i - 1] != v) inverse_mapping[remapped[i]] = v;
 }
 
 }  // namespace detail
