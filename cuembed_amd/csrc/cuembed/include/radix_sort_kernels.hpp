@@ -330,6 +330,57 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
   if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
+//! Stable rank of the tile's keys by the digit at `shift`.  Lane l of wave w holds the keys at
+//! positions first_pos + r * 64 (r = 0..kSortItems-1; first_pos = wave base + lane); slot[r]
+//! receives the key's tile-local position in digit order (0xffffffff for positions >= n).
+//! `wave_count` ([kSortWaves][kSortBins], zeroed by the caller, barrier before the call) ends as
+//! the exclusive prefix over waves, `tile_start[d]` as the tile-local position of the first key
+//! with digit d.  Contains barriers: every thread of the workgroup must call it.
+template <typename KeyT>
+__device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const int shift,
+                                         const int64_t first_pos, const int64_t n,
+                                         unsigned (*wave_count)[kSortBins], unsigned* tile_start,
+                                         unsigned (&slot)[kSortItems]) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const bool valid = first_pos + r * 64 < n;
+    const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
+    const unsigned long long peers = MatchDigit(digit, valid);
+    // every peer reads the wave's running count of its digit (one LDS broadcast per digit), then
+    // the lowest peer bumps it; a wavefront's LDS operations execute in program order
+    const unsigned lower = static_cast<unsigned>(__popcll(peers & LanesBelow(lane)));
+    unsigned start = 0;
+    if (valid) start = wave_count[wave][digit];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lower == 0) wave_count[wave][digit] = start + static_cast<unsigned>(__popcll(peers));
+    __builtin_amdgcn_wave_barrier();
+    slot[r] = valid ? start + lower : 0xffffffffu;
+  }
+  __syncthreads();
+  {  // per digit: wave counts -> exclusive prefix over waves; tile totals -> tile-local starts
+    unsigned run = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      const unsigned c = wave_count[w][tid];
+      wave_count[w][tid] = run;
+      run += c;
+    }
+    unsigned total;
+    tile_start[tid] = BlockExclusiveScan(run, &total);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    if (slot[r] != 0xffffffffu) {
+      const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
+      slot[r] += tile_start[digit] + wave_count[wave][digit];
+    }
+  }
+}
+
 //! Scatter pass.  Position of a key = (keys with a smaller digit) + (equal-digit keys in
 //! earlier tiles) + (equal-digit keys of earlier waves of this tile) + (its rank in its wave).
 //! Keys and payloads are first put in digit order INSIDE the tile through LDS, so that the
@@ -415,42 +466,8 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
   V1 item1[kSortItems];
   if constexpr (kEarlyV1) LoadRouted<V1>(v1, v1_route.src, kNarrowV1, n, wave_base + lane, 64, V1(0), item1);
-  unsigned slot[kSortItems];  // first: rank in wave; finally: tile-local position in digit order
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const bool valid = wave_base + r * 64 + lane < n;
-    const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
-    const unsigned long long peers = MatchDigit(digit, valid);
-    // every peer reads the wave's running count of its digit (one LDS broadcast per digit), then
-    // the lowest peer bumps it; a wavefront's LDS operations execute in program order
-    const unsigned lower = static_cast<unsigned>(__popcll(peers & LanesBelow(lane)));
-    unsigned start = 0;
-    if (valid) start = wave_count[wave][digit];
-    __builtin_amdgcn_wave_barrier();
-    if (valid && lower == 0) wave_count[wave][digit] = start + static_cast<unsigned>(__popcll(peers));
-    __builtin_amdgcn_wave_barrier();
-    slot[r] = valid ? start + lower : 0xffffffffu;
-  }
-  __syncthreads();
-  {  // per digit: wave counts -> exclusive prefix over waves; tile totals -> tile-local starts
-    unsigned run = 0;
-#pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) {
-      const unsigned c = wave_count[w][tid];
-      wave_count[w][tid] = run;
-      run += c;
-    }
-    unsigned total;
-    tile_start[tid] = BlockExclusiveScan(run, &total);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    if (slot[r] != 0xffffffffu) {
-      const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
-      slot[r] += tile_start[digit] + wave_count[wave][digit];
-    }
-  }
+  unsigned slot[kSortItems];  // tile-local position in digit order
+  RankTile<KeyT>(key, shift, wave_base + lane, n, wave_count, tile_start, slot);
 
   // ---- keys: through LDS into digit order, then out in runs ----
   KeyT* stage_keys = reinterpret_cast<KeyT*>(stage);
@@ -478,6 +495,99 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     V2 item[kSortItems];
     LoadRouted<V2>(v2, v2_route.src, false, n, wave_base + lane, 64, V2(), item);
     StageAndStore<V2>(stage, item, slot, dest, count, v2, v2_route.dst, false, n);
+  }
+}
+
+//! Whole sort of at most kSortTile elements in ONE launch: keys and payloads stay in registers,
+//! every working pass ranks them (RankTile) and permutes them through LDS; digits that do not
+//! vary are skipped (the OR / AND reduction is block-local here).  Small problems are launch
+//! bound: this replaces 3 launches per pass.
+template <typename T>
+__device__ __forceinline__ void PermuteThroughLds(unsigned char* stage_raw, T (&item)[kSortItems],
+                                                  const unsigned (&slot)[kSortItems], const int first_pos,
+                                                  const int n) {
+  T* stage = reinterpret_cast<T*>(stage_raw);
+  __syncthreads();  // previous user of the staging buffer is done
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r)
+    if (slot[r] != 0xffffffffu) stage[slot[r]] = item[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r)
+    if (first_pos + r * 64 < n) item[r] = stage[first_pos + r * 64];
+}
+
+template <typename KeyT, typename V1, typename V2>
+__global__ void __launch_bounds__(kSortThreads)
+SingleTileSortKernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_out,
+                     const V1* __restrict__ v1_in, V1* __restrict__ v1_out,
+                     const V2* __restrict__ v2_in, V2* __restrict__ v2_out, const int n, const int passes) {
+  constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
+  constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
+  constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
+  __shared__ __attribute__((aligned(16))) unsigned char stage[kSortTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
+  __shared__ unsigned tile_start[kSortBins];
+  __shared__ unsigned wave_count[kSortWaves][kSortBins];
+  __shared__ unsigned long long wave_bits[kSortWaves][2];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int first_pos = wave * (64 * kSortItems) + lane;
+  KeyT key[kSortItems];
+  V1 item1[kSortItems];
+  V2 item2[kSortItems];
+  unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int i = first_pos + r * 64;
+    key[r] = KeyT(0);
+    if (i < n) {
+      key[r] = keys_in[i];
+      if constexpr (kHasV1) item1[r] = v1_in[i];
+      if constexpr (kHasV2) item2[r] = v2_in[i];
+      any |= static_cast<unsigned long long>(key[r]);
+      all &= static_cast<unsigned long long>(key[r]);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    any |= __shfl_xor(any, d);
+    all &= __shfl_xor(all, d);
+  }
+  if (lane == 0) {
+    wave_bits[wave][0] = any;
+    wave_bits[wave][1] = all;
+  }
+  __syncthreads();
+  any = 0ull;
+  all = ~0ull;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; ++w) {
+    any |= wave_bits[w][0];
+    all &= wave_bits[w][1];
+  }
+  const unsigned long long varying = any & ~all;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 8 * pass;
+    if (((varying >> shift) & 0xffull) == 0) continue;  // every key has the same digit here
+    __syncthreads();                                     // wave_count / tile_start of the previous pass are done
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) wave_count[w][tid] = 0;
+    __syncthreads();
+    unsigned slot[kSortItems];
+    RankTile<KeyT>(key, shift, first_pos, n, wave_count, tile_start, slot);
+    PermuteThroughLds<KeyT>(stage, key, slot, first_pos, n);
+    if constexpr (kHasV1) PermuteThroughLds<V1>(stage, item1, slot, first_pos, n);
+    if constexpr (kHasV2) PermuteThroughLds<V2>(stage, item2, slot, first_pos, n);
+  }
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int i = first_pos + r * 64;
+    if (i < n) {
+      keys_out[i] = key[r];
+      if constexpr (kHasV1) v1_out[i] = item1[r];
+      if constexpr (kHasV2) v2_out[i] = item2[r];
+    }
   }
 }
 
@@ -522,6 +632,11 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
                            char* work, hipStream_t stream) {
   if (n == 0) return;
   const RadixSortPlan<KeyT, V1, V2> plan(n, key_bits);
+  if (n <= static_cast<size_t>(kSortTile)) {
+    SingleTileSortKernel<KeyT, V1, V2><<<1, kSortThreads, 0, stream>>>(
+        keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes);
+    return;
+  }
   const SortArray<KeyT> keys{keys_in, keys_out, reinterpret_cast<KeyT*>(work + plan.keys_tmp)};
   const SortArray<V1> v1{v1_in, v1_out, reinterpret_cast<V1*>(work + plan.v1_tmp)};
   const SortArray<V2> v2{v2_in, v2_out, reinterpret_cast<V2*>(work + plan.v2_tmp)};
@@ -611,7 +726,7 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
   }
   if (lane == 0) wave_sum[wave] = c;
   __syncthreads();
-  unsigned running = tile_offset[blockIdx.x];
+  unsigned running = tile_offset != nullptr ? tile_offset[blockIdx.x] : 0u;  // null: the only tile
   for (int w = 0; w < wave; ++w) running += wave_sum[w];
   const unsigned long long upto = LanesBelow(lane) | (1ull << lane);  // lanes <= this one
 #pragma unroll
@@ -633,6 +748,10 @@ inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped,
   if (n == 0) return;
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
   unsigned* tile_sum = reinterpret_cast<unsigned*>(work);
+  if (tiles == 1) {  // one launch instead of three
+    RunHeadScanKernel<IndexT><<<1, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), nullptr, remapped);
+    return;
+  }
   RunHeadCountKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum);
   ScanTileSumsKernel<<<1, kSortThreads, 0, stream>>>(tile_sum, tiles);
   RunHeadScanKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum,
