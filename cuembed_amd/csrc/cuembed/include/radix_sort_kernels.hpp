@@ -84,6 +84,7 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
 // and only the last one touches the caller's output: a middle pass moves 8 bytes per pair and
 // direction instead of 16.
 constexpr int kStaticRoutePasses = 3;
+constexpr int kFoldScanTiles = 32;  // up to 131072 keys the tile scan is done inside the scatter kernel
 enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
 
@@ -279,14 +280,16 @@ __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* tot
 }
 
 //! One workgroup per bin: tile_hist[bin][*] becomes its exclusive prefix over the tiles;
-//! bin_total[bin] receives the sum.  In pass 0 an extra workgroup (blockIdx.x == kSortBins) folds
+//! bin_total[bin] receives the sum.  In pass 0 an extra workgroup (the last of the grid) folds
 //! the tiles' OR/AND words into `state` (single writer, so nothing has to be zeroed first).
+//! Few tiles (<= kFoldScanTiles): the per-bin work is folded into the scatter kernel and only
+//! that extra workgroup is launched (grid = 1), in pass 0.
 __global__ void __launch_bounds__(kSortThreads)
 RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
                      unsigned* __restrict__ bin_total, const int pass, const int passes,
                      const unsigned long long* __restrict__ tile_bits,
                      unsigned long long* __restrict__ state) {
-  if (blockIdx.x == kSortBins) {  // only launched in pass 0
+  if (blockIdx.x == gridDim.x - 1 && gridDim.x != kSortBins) {  // the extra workgroup of pass 0
     __shared__ unsigned long long wave_bits[kSortWaves][2];
     unsigned long long any = 0ull, all = ~0ull;
     for (int t = threadIdx.x; t < num_tiles; t += kSortThreads) {
@@ -447,9 +450,24 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   const int64_t tile_base = static_cast<int64_t>(blockIdx.x) * kSortTile;
   const int count = static_cast<int>(n - tile_base < kSortTile ? n - tile_base : kSortTile);
   {
+    unsigned before_me, bin_sum;
+    if (bin_total != nullptr) {
+      before_me = tile_prefix[static_cast<size_t>(tid) * num_tiles + blockIdx.x];
+      bin_sum = bin_total[tid];
+    } else {
+      // few tiles: no scan launch -- thread `bin` adds up the raw tile histograms of its bin itself
+      const unsigned* row = tile_prefix + static_cast<size_t>(tid) * num_tiles;
+      before_me = 0;
+      bin_sum = 0;
+      for (int t = 0; t < num_tiles; ++t) {
+        const unsigned c = row[t];
+        if (t < static_cast<int>(blockIdx.x)) before_me += c;
+        bin_sum += c;
+      }
+    }
     unsigned total;
-    const unsigned smaller = BlockExclusiveScan(bin_total[tid], &total);
-    digit_base[tid] = smaller + tile_prefix[static_cast<size_t>(tid) * num_tiles + blockIdx.x];
+    const unsigned smaller = BlockExclusiveScan(bin_sum, &total);
+    digit_base[tid] = smaller + before_me;
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) wave_count[w][tid] = 0;
   }
@@ -653,13 +671,17 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     else if (skip_on_device) narrow_mode = kNarrowIfConstantHigh;  // decided from the keys themselves
   }
   const int64_t count = static_cast<int64_t>(n);
+  const bool fold_scan = plan.num_tiles <= kFoldScanTiles;  // launch-bound sizes: one launch less per pass
   for (int p = 0; p < plan.passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, count, p, plan.passes, narrow_mode, tile_hist, plan.num_tiles, tile_bits, state);
-    RadixScanTilesKernel<<<kSortBins + (p == 0 && skip_on_device ? 1 : 0), kSortThreads, 0, stream>>>(
-        tile_hist, plan.num_tiles, bin_total, p, plan.passes, tile_bits, state);
+    const int scan_blocks = (fold_scan ? 0 : kSortBins) + (p == 0 && skip_on_device ? 1 : 0);
+    if (scan_blocks > 0)
+      RadixScanTilesKernel<<<scan_blocks, kSortThreads, 0, stream>>>(
+          tile_hist, plan.num_tiles, bin_total, p, plan.passes, tile_bits, state);
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        keys, v1, v2, count, p, plan.passes, narrow_mode, tile_hist, bin_total, plan.num_tiles, state);
+        keys, v1, v2, count, p, plan.passes, narrow_mode, tile_hist, fold_scan ? nullptr : bin_total,
+        plan.num_tiles, state);
   }
 }
 
