@@ -9,7 +9,10 @@
 //   * no per-call state to zero: nothing but kernels is enqueued (a library sort issues several
 //     small memsets per call, each a 5 us launch at this problem size);
 //   * workspace size is pure host arithmetic (no device query).
-// One pass = three launches:
+//   * passes in which every key has the same digit are skipped on the device, and 64-bit
+//     arrays travel as 32 bits between passes when their high halves carry nothing (see PlanPass).
+// One pass = three launches (two when there are at most kFoldScanTiles tiles; the whole sort is
+// one launch, SingleTileSortKernel, up to one tile):
 //   RadixTileHistogramKernel   per 4096-key tile: 256-bin histogram of the current digit
 //   RadixScanTilesKernel       per bin: exclusive prefix over the tiles, and the bin total
 //   RadixScatterKernel         per tile: stable rank of every key among equal digits, scatter
@@ -20,9 +23,11 @@
 // the lanes holding the same digit with 8 ballots (`match-any`), takes its rank from the
 // popcount of the lower peers, and the lowest peer bumps the wave's digit counter in LDS -- no
 // LDS atomics, no dependence on digit skew, and input order is preserved by construction.
-// (Finding the peers through per-wave lane bitmaps in LDS -- ds_or, read back, clear -- removes
-// ~50 VALU instructions per round but measured 1-5 % slower: the scatter pass is bound by its
-// 64-byte-average bin segments in memory, not by the ranking arithmetic.)
+// What bounds the scatter pass (23 us for 4.19M pairs): a build that stores every tile back
+// contiguously takes 21 us, so it is the ~110 VALU instructions per key of the ranking and the
+// dependent LDS steps, not the scattered stores.  Measured and rejected: peers through per-wave
+// lane bitmaps in LDS (ds_or, read back, clear: -50 VALU per round, 1-5 % slower); a one-compare
+// shortcut for wavefronts whose 64 keys share the digit (2 % slower); 2048-key tiles (10 % slower).
 #ifndef CUEMBED_INCLUDE_RADIX_SORT_KERNELS_HPP_
 #define CUEMBED_INCLUDE_RADIX_SORT_KERNELS_HPP_
 
