@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the whole path against the CPU oracle (test infrastructure):
+random table shapes, batch sizes, hotness, index distributions and types, fixed / CSR layouts,
+weights -- forward (bit-exact), row-id extraction, Transpose (bit-exact, stable), compressed-index
+remap, EmbeddingBackward dense and compressed (exact on small-integer gradients).
+
+    python tools/fuzz_parity.py [--seconds 300] [--seed 0]
+
+Not part of pytest's default run (it is open-ended); `tests/test_gpu_fuzz_smoke.py` runs a few
+iterations of it."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def dev(a):
+    import numpy as np
+    import torch
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def one_case(rng, ce, O, np, torch, verbose=False):
+    elem = [np.float32, np.float16][rng.integers(0, 2)]
+    idx_t = [np.int32, np.int64][rng.integers(0, 2)]
+    lane_bytes = [4, 8, 16][rng.integers(0, 3)]
+    es = np.dtype(elem).itemsize
+    W = int(rng.integers(1, 40)) * (lane_bytes // es if lane_bytes >= es else 1)
+    if (W * es) % 4:
+        W *= 2
+    scale = rng.integers(0, 4)
+    B = int(rng.integers(1, [40, 700, 5000, 20000][scale]))
+    H = int(rng.integers(1, [70, 40, 20, 9][scale]))
+    ncat = int(rng.integers(H + 1, [300, 5000, 100000, 3000000][rng.integers(0, 4)]))
+    alpha = [0.0, 1.05, 1.15, 1.6][rng.integers(0, 4)]
+    csr = bool(rng.integers(0, 2))
+    weighted = bool(rng.integers(0, 2))
+    mode = ["sum", "mean"][rng.integers(0, 2)] if not weighted or True else "sum"
+    desc = dict(elem=elem.__name__, idx=idx_t.__name__, W=W, B=B, H=H, ncat=ncat, alpha=alpha, csr=csr,
+                weighted=weighted, mode=mode)
+    if verbose:
+        print(desc, flush=True)
+    a = O.allocate_forward(ncat, W, B, H, alpha=alpha, is_csr=csr, elem=elem, index=idx_t)
+    indices, offsets = a["indices"], (a["offsets"] if csr else None)
+    weights = a["weights"] if weighted else None
+    nnz = indices.size
+    # ---- forward
+    if not (weighted and mode == "mean" and False):
+        want = O.embedding_forward(a["table"], indices, offsets, weights, batch_size=B, num_hots=0 if csr else H,
+                                   mode=mode)
+        got = ce.embedding_forward(dev(a["table"]), dev(indices), dev(offsets), dev(weights), batch_size=B,
+                                   num_hots=0 if csr else H, mode=mode)
+        view = np.uint16 if es == 2 else np.uint32
+        assert np.array_equal(got.cpu().numpy().view(view), want.view(view)), ("forward", desc)
+    if nnz == 0:
+        return desc
+    # ---- row ids, transpose, remap
+    if csr:
+        sid = O.extract_row_ids_from_csr(offsets, idx_t)
+        d_sid = ce.extract_row_ids_from_csr(dev(offsets), nnz, dev(indices).dtype)
+    else:
+        sid = O.extract_row_ids_from_fixed(B, H, idx_t)
+        d_sid = ce.extract_row_ids_from_fixed(B, H, dev(indices).dtype, "cuda")
+    assert np.array_equal(d_sid.cpu().numpy(), sid), ("extract", desc)
+    ti, ts, tw = O.transpose(sid, indices, weights, stable=True)
+    bound = ncat if rng.integers(0, 2) else None
+    d_ti, d_ts, d_tw = ce.transpose(d_sid, dev(indices), dev(weights), num_categories=bound)
+    assert np.array_equal(d_ti.cpu().numpy(), ti) and np.array_equal(d_ts.cpu().numpy(), ts), ("transpose", desc)
+    if weighted:
+        assert np.array_equal(d_tw.cpu().numpy().view(np.uint16 if es == 2 else np.uint32),
+                              tw.view(np.uint16 if es == 2 else np.uint32)), ("transpose weights", desc)
+    remap = O.compute_compressed_grad_indices(ti)
+    d_remap = ce.compute_compressed_grad_indices(d_ti)
+    assert np.array_equal(d_remap.cpu().numpy(), remap), ("remap", desc)
+    nu = int(remap[-1]) + 1
+    # ---- backward: small-integer grad_y and (if weighted) weights 0.5/0.25 keep sums exact as long
+    # as runs are short enough for the element type
+    counts = np.bincount(remap)
+    max_run = int(counts.max())
+    limit = 2048 if es == 2 else (1 << 22)
+    gy = (np.mod(O.allocate_grad_y(B * W), 3) - 1).reshape(B, W).astype(elem)
+    use_w = weighted and max_run * 4 < limit
+    if max_run < limit:
+        w32 = None if not use_w else tw.astype(np.float32)
+        want_c, want_inv = O.embedding_backward(gy.astype(np.float32), W, nu, ti, ts, remap, w32)
+        got_c, got_inv = ce.embedding_backward(dev(gy), nu, d_ti, d_ts, d_remap, d_tw if use_w else None)
+        assert np.array_equal(got_c.float().cpu().numpy(), want_c), ("backward compressed", desc)
+        assert np.array_equal(got_inv.cpu().numpy(), want_inv), ("inverse mapping", desc)
+        if ncat * W <= 40_000_000:
+            want_d, _ = O.embedding_backward(gy.astype(np.float32), W, ncat, ti, ts, None, w32)
+            got_d, _ = ce.embedding_backward(dev(gy), ncat, d_ti, d_ts, None, d_tw if use_w else None)
+            assert np.array_equal(got_d.float().cpu().numpy(), want_d), ("backward dense", desc)
+    return desc
+
+
+def run(seconds=60.0, seed=0, max_cases=None, verbose=False):
+    import numpy as np
+    import torch
+    import cuembed_amd as ce
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds and (max_cases is None or n < max_cases):
+        one_case(rng, ce, O, np, torch, verbose)
+        n += 1
+    torch.cuda.synchronize()
+    assert ce._lib.lib().cuembed_peek_last_error() == 0
+    return n
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--seconds", type=float, default=300)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--verbose", action="store_true")
+    a = p.parse_args()
+    print("fuzz_parity: %d cases passed (seed %d)" % (run(a.seconds, a.seed, verbose=a.verbose), a.seed))
