@@ -427,8 +427,10 @@ __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T 
   }
 }
 
+// (second launch bound = wavefronts per SIMD: 4 workgroups of 4 waves per CU, i.e. at most 128
+// VGPRs -- with 1024 tiles on 256 CUs a fifth of the tiles would otherwise wait for a second round)
 template <typename KeyT, typename V1, typename V2>
-__global__ void __launch_bounds__(kSortThreads)
+__global__ void __launch_bounds__(kSortThreads, 4)
 RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
                    const int64_t n, const int pass, const int passes, const int narrow_mode,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
