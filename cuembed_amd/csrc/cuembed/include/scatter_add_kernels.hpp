@@ -82,12 +82,14 @@ template <typename GradT, typename IndexT>
 __host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int segment_len,
                                                     int lanes_per_row, int elems_per_lane,
                                                     bool weighted) {
-  const size_t n = static_cast<size_t>(segments_per_block) * segment_len;
   // ids are staged as 32-bit whatever IndexT is: nnz and num_grad_embedding_rows are `int` in the
-  // API (embedding_lookup.cuh:423-435), so every row id and sample id fits
-  size_t bytes = (n + 2) * sizeof(int32_t) + n * sizeof(int32_t);
+  // API (embedding_lookup.cuh:423-435), so every row id and sample id fits.  Every segment has its
+  // own padded slice: a wavefront reads the SAME position of 8 different
+  // segments at a time, and with a power-of-two stride all 8 would hit one LDS bank.
+  const size_t segs = static_cast<size_t>(segments_per_block);
+  size_t bytes = segs * (segment_len + 2) * sizeof(int32_t) + segs * (segment_len + 1) * sizeof(int32_t);
   bytes = (bytes + 15) / 16 * 16;
-  if (weighted) bytes += n * sizeof(GradT);
+  if (weighted) bytes += segs * (segment_len + 2) * sizeof(GradT);
   bytes = (bytes + 15) / 16 * 16;
   bytes += static_cast<size_t>(segments_per_block) * 2 * lanes_per_row * elems_per_lane * sizeof(float);
   bytes += static_cast<size_t>(segments_per_block) * (2 * sizeof(int64_t) + sizeof(int));
@@ -144,11 +146,17 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * lanes + lane_x) * N;
 
   // ---- LDS carve-up (must match ScatterStageBytes) ----
-  int32_t* st_rows = reinterpret_cast<int32_t*>(lds_raw);          // [block_len + 2], [0] = lookup before
-  int32_t* st_sids = st_rows + block_len + 2;                      // [block_len]
-  size_t off = ((static_cast<size_t>(block_len) * 2 + 2) * sizeof(int32_t) + 15) / 16 * 16;
+  // per segment: rows [segment_len + 2] = (lookup before, the segment's row ids, lookup after);
+  // sample ids [segment_len + 1]; weights [segment_len + 2] -- strides that are not multiples of
+  // the 64 LDS banks, so the 8 segments of a wavefront read from 8 different banks
+  const int row_stride = segment_len + 2;
+  const int sid_stride = segment_len + 1;
+  const int w_stride = segment_len + 2;
+  int32_t* st_rows = reinterpret_cast<int32_t*>(lds_raw);
+  int32_t* st_sids = st_rows + segments_per_block * row_stride;
+  size_t off = (static_cast<size_t>(segments_per_block) * (row_stride + sid_stride) * sizeof(int32_t) + 15) / 16 * 16;
   GradT* st_w = reinterpret_cast<GradT*>(lds_raw + off);
-  if (kWeighted) off += static_cast<size_t>(block_len) * sizeof(GradT);
+  if (kWeighted) off += static_cast<size_t>(segments_per_block) * w_stride * sizeof(GradT);
   off = (off + 15) / 16 * 16;
   float* part = reinterpret_cast<float*>(lds_raw + off);          // [seg][2][N][lanes]
   off += static_cast<size_t>(segments_per_block) * 2 * lanes * N * sizeof(float);
@@ -157,18 +165,21 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   int* part_flags = reinterpret_cast<int*>(lds_raw + off);         // [seg]
 
   {
-    const int tid = seg * lanes + lane_x;
-    const int nthreads = lanes * segments_per_block;
-    for (int k = tid; k < block_len + 2; k += nthreads) {
-      const int64_t g = block_begin - 1 + k;
-      st_rows[k] = (g >= 0 && g < nnz) ? static_cast<int32_t>(rows[g]) : -1;
-    }
-    for (int k = tid; k < block_len; k += nthreads) {
-      const int64_t g = block_begin + k;
+    // every segment's lanes stage their own segment (no index arithmetic beyond a stride)
+    int32_t* seg_rows = st_rows + seg * row_stride;
+    const int64_t seg_begin = block_begin + static_cast<int64_t>(seg) * segment_len;
+    for (int i = lane_x; i < segment_len; i += lanes) {
+      const int64_t g = seg_begin + i;
+      seg_rows[1 + i] = g < nnz ? static_cast<int32_t>(rows[g]) : -1;
       if (g < nnz) {
-        st_sids[k] = static_cast<int32_t>(sample_ids[g]);  // (non-temporal loads here measured 6-20 % slower)
-        if constexpr (kWeighted) st_w[k] = weights[g];
+        st_sids[seg * sid_stride + i] = static_cast<int32_t>(sample_ids[g]);  // (non-temporal: 6-20 % slower)
+        if constexpr (kWeighted) st_w[seg * w_stride + i] = weights[g];
       }
+    }
+    if (lane_x == 0) {
+      seg_rows[0] = (seg_begin > 0 && seg_begin - 1 < nnz) ? static_cast<int32_t>(rows[seg_begin - 1]) : -1;
+      const int64_t after = seg_begin + segment_len;
+      seg_rows[segment_len + 1] = after < nnz ? static_cast<int32_t>(rows[after]) : -1;
     }
     if (lane_x == 0) part_flags[seg] = 0;
   }
@@ -178,14 +189,13 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   // a separate launch over all nnz; here the dense ids are already in LDS and only the run heads
   // load their table row id).
   if (run_ids != nullptr && cs.slice == 0) {
-    const int tid = seg * lanes + lane_x;
-    const int nthreads = lanes * segments_per_block;
-    for (int k = tid; k < block_len; k += nthreads) {
-      const int64_t g = block_begin + k;
-      if (g < nnz && st_rows[k + 1] != st_rows[k]) inverse_mapping[st_rows[k + 1]] = run_ids[g];
+    const int32_t* seg_rows = st_rows + seg * row_stride;
+    const int64_t seg_begin = block_begin + static_cast<int64_t>(seg) * segment_len;
+    for (int i = lane_x; i < segment_len; i += lanes) {
+      const int64_t g = seg_begin + i;
+      if (g < nnz && seg_rows[1 + i] != seg_rows[i]) inverse_mapping[seg_rows[1 + i]] = run_ids[g];
     }
   }
-
   const int seg_off = seg * segment_len;  // offset of this segment inside the block
   const int64_t begin = block_begin + seg_off;
   const bool active = begin < nnz;
@@ -195,9 +205,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 
   if (active) {
     const int count = static_cast<int>((begin + segment_len < nnz) ? segment_len : nnz - begin);
-    const int32_t* my_rows = st_rows + 1 + seg_off;  // my_rows[-1] = lookup before the segment
-    const int32_t* my_sids = st_sids + seg_off;
-    const GradT* my_w = st_w + seg_off;
+    const int32_t* my_rows = st_rows + seg * row_stride + 1;  // my_rows[-1] = lookup before the segment
+    const int32_t* my_sids = st_sids + seg * sid_stride;
+    const GradT* my_w = st_w + seg * w_stride;
 
     // A run is "shared" when it also has lookups in a neighbouring segment.
     bool run_shared = my_rows[-1] == my_rows[0];                    // sentinel -1 never matches
