@@ -339,14 +339,16 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
 }
 
 //! Stable rank of the tile's keys by the digit at `shift`.  Lane l of wave w holds the keys at
-//! positions first_pos + r * 64 (r = 0..kSortItems-1; first_pos = wave base + lane); slot[r]
-//! receives the key's tile-local position in digit order (0xffffffff for positions >= n).
+//! TILE-LOCAL positions first_pos + r * 64 (r = 0..kSortItems-1; first_pos = wave * 1024 + lane;
+//! 32-bit on purpose: 64-bit position compares cost the int64 scatter kernel 17 VGPRs); slot[r]
+//! receives the key's tile-local position in digit order (0xffffffff for positions >= n, the
+//! number of keys in the tile).
 //! `wave_count` ([kSortWaves][kSortBins], zeroed by the caller, barrier before the call) ends as
 //! the exclusive prefix over waves, `tile_start[d]` as the tile-local position of the first key
 //! with digit d.  Contains barriers: every thread of the workgroup must call it.
 template <typename KeyT>
 __device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const int shift,
-                                         const int64_t first_pos, const int64_t n,
+                                         const int first_pos, const int n,
                                          unsigned (*wave_count)[kSortBins], unsigned* tile_start,
                                          unsigned (&slot)[kSortItems]) {
   const int tid = threadIdx.x;
@@ -492,7 +494,7 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   V1 item1[kSortItems];
   if constexpr (kEarlyV1) LoadRouted<V1>(v1, v1_route.src, kNarrowV1, n, wave_base + lane, 64, V1(0), item1);
   unsigned slot[kSortItems];  // tile-local position in digit order
-  RankTile<KeyT>(key, shift, wave_base + lane, n, wave_count, tile_start, slot);
+  RankTile<KeyT>(key, shift, wave * (64 * kSortItems) + lane, count, wave_count, tile_start, slot);
 
   // ---- keys: through LDS into digit order, then out in runs ----
   KeyT* stage_keys = reinterpret_cast<KeyT*>(stage);
