@@ -347,3 +347,33 @@ def test_backward_compressed_zero_init_without_full_memset(ce, oracle):
             want, winv = oracle.embedding_backward(gy.astype(np.float32), W, nu + extra, ti, ts, remap)
             assert np.array_equal(host(got).astype(np.float32), want), (elem[0], extra)
             assert np.array_equal(host(inv)[:nu], winv[:nu])
+
+
+@pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])
+def test_very_wide_rows_forward_weight_grad_backward(ce, oracle, elem):
+    """Rows at the API limit of 1024 lanes (embedding_lookup.cuh:179): 16 KiB rows, one sample or one
+    nz-segment per 1024-thread workgroup, in every kernel family."""
+    es = np.dtype(elem[0]).itemsize
+    for W in (16 // es * 1024, 16 // es * 512 + 16 // es * 3, 2040, 2042):   # 16-, 16-, 16- and 4-byte lanes
+        if (W * es) % 4:
+            continue
+        ncat, B, H = 300, 37, 9
+        a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15, elem=elem[0])
+        want = oracle.embedding_forward(a["table"], a["indices"], None, a["weights"], num_hots=H)
+        got = ce.embedding_forward(dev(a["table"]), dev(a["indices"]), None, dev(a["weights"]), num_hots=H)
+        view = np.uint16 if es == 2 else np.uint32
+        assert np.array_equal(host(got).view(view), want.view(view)), W
+        sid = oracle.extract_row_ids_from_fixed(B, H)
+        ti, ts, tw = oracle.transpose(sid, a["indices"], a["weights"])
+        remap = oracle.compute_compressed_grad_indices(ti)
+        nu = int(remap[-1]) + 1
+        gy = (np.mod(oracle.allocate_grad_y(B * W), 3) - 1).reshape(B, W).astype(elem[0])
+        want_g, want_inv = oracle.embedding_backward(gy.astype(np.float32), W, nu, ti, ts, remap, tw.astype(np.float32))
+        got_g, got_inv = ce.embedding_backward(dev(gy), nu, dev(ti), dev(ts), dev(remap), dev(tw))
+        assert np.array_equal(host(got_g).astype(np.float32), want_g), W
+        assert np.array_equal(host(got_inv), want_inv)
+        gw = ce.embedding_weight_grad(dev(a["table"]), dev(a["indices"]), dev(gy), num_hots=H)
+        ref = np.einsum("nw,nw->n", a["table"][a["indices"]].astype(np.float64),
+                        gy[np.repeat(np.arange(B), H)].astype(np.float64))
+        tol = 2e-2 if es == 2 else 1e-4
+        assert np.allclose(host(gw).astype(np.float64), ref, rtol=tol, atol=tol * np.abs(ref).max()), W
