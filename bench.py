@@ -51,6 +51,9 @@ def parse_args():
     p.add_argument("--index-batches", type=int, default=0,
                    help="distinct index batches cycled through (default: 4, or 2 with more than 2 GPUs "
                         "because every rank walks the whole generator stream)")
+    p.add_argument("--strong", action="store_true",
+                   help="strong scaling: the workload's batch is the GLOBAL batch, split over the ranks "
+                        "(default: weak scaling, every rank gets the full per-GPU batch)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the cold-cache and alpha=0 companions")
     p.add_argument("--cold-iters", type=int, default=20)
@@ -151,6 +154,10 @@ def main():
     cfg = dict(WORKLOADS[args.workload])
     alpha = cfg["alpha"] if args.alpha is None else args.alpha
     tdtype = torch.float16 if cfg["elem"] == "f16" else torch.float32
+    if args.strong:
+        if cfg["batch"] % world:
+            raise SystemExit("--strong needs the batch (%d) to be a multiple of the number of ranks" % cfg["batch"])
+        cfg["batch"] //= world
     B, H, W = cfg["batch"], cfg["hotness"], cfg["width"]
 
     ce._lib.lib()  # fail loudly if the HIP library is absent
@@ -223,7 +230,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall_max / args.steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f16 table, f32 accumulate" if cfg["elem"] == "f16" else "f32",
         "data": "synthetic",
