@@ -313,6 +313,36 @@ def extras(args, torch, ce, harness, np, cfg, table, out, device, dev_batches, b
             "pct_of_hbm_peak": round(100 * bytes_per_step[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2)}
         ex["alpha0_uniform_cold"] = timed_cold(b0, bytes_per_step[0])
     del flush
+    if not cfg["csr"]:
+        # the rest of the training step at the same shape (BASELINE configs[3]): not part of `value`
+        idx = dev_batches[0]["indices"]
+        gy = torch.randint(-10, 11, (B, cfg["width"]), device=device).to(table.dtype)
+
+        def timed(fn, n=20):
+            for _ in range(3):
+                fn()
+            a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            z.record()
+            z.synchronize()
+            return round(a.elapsed_time(z) / n, 5)
+
+        state = {}
+
+        def transpose():
+            sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, device)
+            state["ti"], state["ts"], _ = ce.transpose(sid, idx)
+            state["remap"] = ce.compute_compressed_grad_indices(state["ti"])
+
+        ex["transpose_and_remap_ms"] = timed(transpose)
+        nu = int(state["remap"][-1].item()) + 1
+        grad = torch.empty((nu, cfg["width"]), dtype=table.dtype, device=device)
+        inv = torch.empty((nu,), dtype=torch.int32, device=device)
+        ex["backward_compressed_ms"] = timed(lambda: ce.embedding_backward(
+            gy, nu, state["ti"], state["ts"], state["remap"], grad_embedding=grad, inverse_mapping=inv))
+        ex["backward_unique_rows"] = nu
     return ex
 
 
