@@ -696,8 +696,8 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
 
 // ---------------------------------------------------------------------------
 // Run-head scan: remapped[i] = number of positions k in (0, i] with indices[k] != indices[k-1].
-// Three launches over 4096-element tiles: count the run heads per tile, exclusive-scan the tile
-// counts (one workgroup), then scan inside every tile on top of its offset.
+// Two launches over 4096-element tiles: count the run heads per tile, then scan inside every tile
+// on top of the sum of the earlier tiles' counts (which every workgroup adds up itself).
 // ---------------------------------------------------------------------------
 template <typename IndexT>
 __device__ __forceinline__ unsigned RunHead(const IndexT* __restrict__ indices, const int64_t i,
@@ -727,23 +727,11 @@ RunHeadCountKernel(const IndexT* __restrict__ indices, const int64_t n, unsigned
   }
 }
 
-__global__ void __launch_bounds__(kSortThreads)
-ScanTileSumsKernel(unsigned* __restrict__ tile_sum, const int num_tiles) {
-  unsigned carry = 0;
-  for (int base = 0; base < num_tiles; base += kSortThreads) {
-    const int t = base + threadIdx.x;
-    const unsigned v = t < num_tiles ? tile_sum[t] : 0u;
-    unsigned total;
-    const unsigned excl = BlockExclusiveScan(v, &total);
-    if (t < num_tiles) tile_sum[t] = carry + excl;
-    carry += total;
-  }
-}
-
 template <typename IndexT>
 __global__ void __launch_bounds__(kSortThreads)
 RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
-                  const unsigned* __restrict__ tile_offset, IndexT* __restrict__ remapped) {
+                  const unsigned* __restrict__ tile_count /* run heads per tile; null: one tile */,
+                  IndexT* __restrict__ remapped) {
   __shared__ unsigned wave_sum[kSortWaves];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -755,9 +743,22 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
     heads[r] = __ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0);
     c += static_cast<unsigned>(__popcll(heads[r]));
   }
-  if (lane == 0) wave_sum[wave] = c;
+  // run heads in all earlier tiles: every workgroup adds up the raw per-tile counts itself (at
+  // most a few thousand words from L2) -- cheaper than a separate single-workgroup scan launch
+  __shared__ unsigned wave_before[kSortWaves];
+  unsigned before = 0;
+  if (tile_count != nullptr)
+    for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += kSortThreads) before += tile_count[t];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  if (lane == 0) {
+    wave_sum[wave] = c;
+    wave_before[wave] = before;
+  }
   __syncthreads();
-  unsigned running = tile_offset != nullptr ? tile_offset[blockIdx.x] : 0u;  // null: the only tile
+  unsigned running = 0;
+#pragma unroll
+  for (int w = 0; w < kSortWaves; ++w) running += wave_before[w];
   for (int w = 0; w < wave; ++w) running += wave_sum[w];
   const unsigned long long upto = LanesBelow(lane) | (1ull << lane);  // lanes <= this one
 #pragma unroll
@@ -779,12 +780,11 @@ inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped,
   if (n == 0) return;
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
   unsigned* tile_sum = reinterpret_cast<unsigned*>(work);
-  if (tiles == 1) {  // one launch instead of three
+  if (tiles == 1) {  // one launch instead of two
     RunHeadScanKernel<IndexT><<<1, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), nullptr, remapped);
     return;
   }
   RunHeadCountKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum);
-  ScanTileSumsKernel<<<1, kSortThreads, 0, stream>>>(tile_sum, tiles);
   RunHeadScanKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum,
                                                                remapped);
 }
