@@ -653,21 +653,28 @@ GatherConcatKernel(const ElemT* __restrict__ table,
   const IndexT* my_idx = indices + sample * num_hots;
   const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
   ElemT* dst = out + sample * num_hots * width + static_cast<int64_t>(lane_x) * N;
-  int j = 0;
-  for (; j + kForwardUnroll <= num_hots; j += kForwardUnroll) {
+  // The output is written once and never read here: non-temporal stores keep it from displacing
+  // table rows in L2.  The row ids of batch k+1 are requested before the rows of batch k are
+  // stored, so a row request never waits for its own id.
+  IndexT ahead[kForwardUnroll];
+  auto request_ids = [&](const int j0) {
+#pragma unroll
+    for (int u = 0; u < kForwardUnroll; ++u)
+      if (j0 + u < num_hots) ahead[u] = my_idx[j0 + u];
+  };
+  request_ids(0);
+  for (int j = 0; j < num_hots; j += kForwardUnroll) {
     Pack<ElemT, N> row[kForwardUnroll];
 #pragma unroll
     for (int u = 0; u < kForwardUnroll; ++u) {
-      row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(my_idx[j + u]) * width);
+      if (j + u < num_hots) row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(ahead[u]) * width);
     }
+    request_ids(j + kForwardUnroll);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < kForwardUnroll; ++u) {
-      StorePack<ElemT, N>(dst + static_cast<int64_t>(j + u) * width, row[u]);
+      if (j + u < num_hots) StorePackStreaming<ElemT, N>(dst + static_cast<int64_t>(j + u) * width, row[u]);
     }
-  }
-  for (; j < num_hots; ++j) {
-    StorePack<ElemT, N>(dst + static_cast<int64_t>(j) * width,
-                        LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(my_idx[j]) * width));
   }
 }
 
