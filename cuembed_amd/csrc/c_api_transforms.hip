@@ -74,11 +74,19 @@ void cuembed_transpose_bounded(const void* rows, const void* cols, const void* w
                                int index_type, int weight_type, void* transpose_rows,
                                void* transpose_cols, void* transpose_weights, char* work,
                                size_t* lwork, int index_bits, cuembed_stream_t stream) {
+  cuembed_transpose_hinted(rows, cols, weights, nnz, index_type, weight_type, transpose_rows,
+                           transpose_cols, transpose_weights, work, lwork, index_bits, 0, stream);
+}
+
+void cuembed_transpose_hinted(const void* rows, const void* cols, const void* weights, int nnz,
+                              int index_type, int weight_type, void* transpose_rows,
+                              void* transpose_cols, void* transpose_weights, char* work,
+                              size_t* lwork, int index_bits, int row_bits, cuembed_stream_t stream) {
 #define TR(I, W)                                                                              \
   cuembed::Transpose<I, W>(static_cast<const I*>(rows), static_cast<const I*>(cols),          \
                            static_cast<const W*>(weights), nnz, static_cast<I*>(transpose_rows), \
                            static_cast<I*>(transpose_cols), static_cast<W*>(transpose_weights), \
-                           work, lwork, Stream(stream), index_bits)
+                           work, lwork, Stream(stream), index_bits, row_bits)
   // weights are only moved, never computed on: fp16 and bf16 share the 2-byte instantiation
   switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {
     case 0: TR(int32_t, float); break;

@@ -92,10 +92,18 @@ void ExtractRowIdsForConcat(const int nnz, IndexT* row_ids, const hipStream_t st
  * Two-phase: call with work == nullptr to get *lwork, then with a buffer of at
  * least that many bytes.
  *
- * Extension over the reference: `index_bits` (default: all bits of IndexT, the reference's
- * behaviour).  A caller that knows every lookup index is < 2^index_bits -- e.g.
- * index_bits = ceil(log2(num_categories)) -- lets the radix sort skip the always-zero high
- * digits: 3 passes instead of 8 for int64 ids of a 10M-row table.  Results are identical.
+ * Like the reference (cub::DeviceRadixSort::SortPairs over all bits of a signed key type) this
+ * is a generic COO transpose: `cols` may hold any IndexT values -- negative keys sort first -- and
+ * `rows` any IndexT values (int64 rows beyond 2^32 or negative are carried at full width).
+ *
+ * Extensions over the reference (results identical, fewer bytes moved):
+ *  - `index_bits` (default: all bits of IndexT, the reference's behaviour).  A caller that knows
+ *    every lookup index lies in [0, 2^index_bits) -- e.g. index_bits = ceil(log2(num_categories))
+ *    -- lets the radix sort skip the always-zero high digits: 3 passes instead of 8 for int64 ids
+ *    of a 10M-row table.  Keys outside that range are a contract violation (undefined order).
+ *  - `row_bits` (default 0 = unknown).  int64 `rows` known to lie in [0, 2^row_bits), row_bits <=
+ *    32 (sample ids always do: they are < nnz <= INT_MAX), travel as 32 bits between the passes
+ *    without the library having to look at them first.
  */
 template <typename IndexT, typename WeightT>
 void Transpose(const IndexT* rows,
@@ -108,8 +116,9 @@ void Transpose(const IndexT* rows,
                char* work,
                size_t* lwork,
                const hipStream_t stream = 0,
-               const int index_bits = static_cast<int>(sizeof(IndexT) * 8)) {
-  using KeyT = typename std::make_unsigned<IndexT>::type;  // ids are non-negative
+               const int index_bits = static_cast<int>(sizeof(IndexT) * 8),
+               const int row_bits = 0) {
+  using KeyT = typename std::make_unsigned<IndexT>::type;  // bit pattern; signed order via the top digit
   const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
                            ? index_bits
                            : static_cast<int>(sizeof(IndexT) * 8);
@@ -126,7 +135,8 @@ void Transpose(const IndexT* rows,
     }
     assert(*lwork >= plan.total);
     detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
-        keys_in, keys_out, rows, transpose_cols, nullptr, nullptr, n, key_bits, work, stream);
+        keys_in, keys_out, rows, transpose_cols, nullptr, nullptr, n, key_bits, work, stream,
+        /*signed_keys=*/true, row_bits);
     return;
   }
   // weighted: sample id AND weight move with the key as two payload arrays (the reference
@@ -139,7 +149,8 @@ void Transpose(const IndexT* rows,
   }
   assert(*lwork >= plan.total);
   detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, rows, transpose_cols, weights,
-                                                transpose_weights, n, key_bits, work, stream);
+                                                transpose_weights, n, key_bits, work, stream,
+                                                /*signed_keys=*/true, row_bits);
 }
 
 /**

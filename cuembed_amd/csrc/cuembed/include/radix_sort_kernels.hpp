@@ -81,31 +81,56 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
 // (a caller-supplied key bound, where a constant digit is unlikely) pass state == nullptr and
 // take the fixed route.
 //
-// 64-bit arrays travel NARROW between passes.  Sample ids are < nnz <= INT_MAX, so an int64
-// payload is always kept as 32 bits in the scratch buffers; int64 keys are kept as their low 32
-// bits when their high halves do not vary (known from the caller's bound, or from `varying` on the
-// device -- the constant high half is put back on the way out).  A scratch buffer of n 64-bit
-// elements then holds TWO 32-bit arrays, so all intermediate passes ping-pong inside the scratch
-// and only the last one touches the caller's output: a middle pass moves 8 bytes per pair and
-// direction instead of 16.
+// 64-bit arrays travel NARROW between passes when their high halves carry nothing.  An int64
+// first payload (sample ids: < nnz <= INT_MAX) is kept as 32 bits in the scratch buffers when
+// every value is in [0, 2^32) -- known from the caller's bound, or found out on the device: pass 0
+// ORs all payload values next to the key bits (a negative or >= 2^32 value sets a high bit and the
+// array travels wide, like cub::DeviceRadixSort::SortPairs carries it in the reference,
+// index_transforms.cuh:108-136).  int64 keys are kept as their low 32 bits when their high halves
+// do not vary (known from the caller's bound, or from `varying` on the device -- the constant high
+// half is put back on the way out).  A scratch buffer of n 64-bit elements then holds TWO 32-bit
+// arrays, so all intermediate passes ping-pong inside the scratch and only the last one touches
+// the caller's output: a middle pass moves 8 bytes per pair and direction instead of 16.
+//
+// Keys are SIGNED integers in the API (IndexT): sorting all 8 * sizeof(IndexT) bits orders them as
+// signed numbers, as cub does for signed key types -- the digit that holds the sign bit is XOR-ed
+// with 0x80 (`sign_pass`).  A caller-supplied bound (index_bits < all bits) promises keys in
+// [0, 2^index_bits); no digit is flipped then.
 constexpr int kStaticRoutePasses = 3;
 constexpr int kFoldScanTiles = 32;  // up to 131072 keys the tile scan is done inside the scatter kernel
+constexpr int kSelfSumTiles = 4096; // up to 16.7M keys every run-head scan workgroup sums the earlier tiles itself
 enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
+enum : int { kStateVarying = 0, kStateAllBits = 1, kStatePayloadBits = 2, kStateWords = 3 };
 
-//! What the device knows about the keys after pass 0: state[0] = bits in which keys differ,
-//! state[1] = AND of all keys.  state == nullptr: fixed route, all passes run.
+//! How one sort treats its arrays; the same for every pass and kernel of the sort.
+struct SortMode {
+  int narrow_keys;   //!< NarrowKeys: 64-bit keys stored as 32 bits in the scratch
+  int narrow_v1;     //!< NarrowKeys: 64-bit first payload stored as 32 bits (IfConstantHigh: if all values < 2^32)
+  int use_varying;   //!< passes whose digit is the same for every key are skipped on the device
+  int sign_pass;     //!< pass whose digit holds the sign bit of the keys, or -1
+};
+
+__device__ __forceinline__ unsigned SignFlip(const SortMode& mode, const int pass) {
+  return pass == mode.sign_pass ? 0x80u : 0u;
+}
+
+//! What the device knows about the arrays after pass 0: state[kStateVarying] = bits in which keys
+//! differ, state[kStateAllBits] = AND of all keys, state[kStatePayloadBits] = OR of all 64-bit first
+//! payloads.  state == nullptr: nothing is decided on the device (fixed route, all passes run).
 struct PassPlan {
   bool active;        //!< this pass moves data
   bool first;         //!< reads the caller's input
   int later;          //!< working passes after this one
   bool narrow_keys;   //!< 64-bit keys are stored as 32 bits in the scratch buffers
+  bool narrow_v1;     //!< a 64-bit first payload is stored as 32 bits in the scratch buffers
   unsigned long long key_high;  //!< constant high half to put back (narrow_keys only)
 };
 
 __device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restrict__ state, const int pass,
-                                             const int passes, const int narrow_mode) {
-  const unsigned long long varying = state != nullptr ? state[0] : ~0ull;
+                                             const int passes, const SortMode& mode) {
+  const bool know_keys = state != nullptr && mode.use_varying;
+  const unsigned long long varying = know_keys ? state[kStateVarying] : ~0ull;
   unsigned active = 1u;  // pass 0 always runs
   for (int q = 1; q < passes; ++q)
     if ((varying >> (8 * q)) & 0xffull) active |= 1u << q;
@@ -113,9 +138,13 @@ __device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restric
   plan.active = (active >> pass) & 1u;
   plan.first = pass == 0;
   plan.later = __popc(active >> (pass + 1));
-  plan.narrow_keys = narrow_mode == kNarrowAlways ||
-                     (narrow_mode == kNarrowIfConstantHigh && state != nullptr && (varying >> 32) == 0);
-  plan.key_high = (narrow_mode == kNarrowIfConstantHigh && plan.narrow_keys) ? (state[1] & 0xffffffff00000000ull) : 0ull;
+  plan.narrow_keys = mode.narrow_keys == kNarrowAlways ||
+                     (mode.narrow_keys == kNarrowIfConstantHigh && know_keys && (varying >> 32) == 0);
+  plan.key_high = (mode.narrow_keys == kNarrowIfConstantHigh && plan.narrow_keys)
+                      ? (state[kStateAllBits] & 0xffffffff00000000ull) : 0ull;
+  plan.narrow_v1 = mode.narrow_v1 == kNarrowAlways ||
+                   (mode.narrow_v1 == kNarrowIfConstantHigh && state != nullptr &&
+                    (state[kStatePayloadBits] >> 32) == 0);
   return plan;
 }
 
@@ -176,23 +205,26 @@ __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int wher
 
 //! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
 //! Plain LDS atomics: order does not matter for counting.  In pass 0 the tile's OR and AND of
-//! its keys go to tile_bits[2 * tile], [2 * tile + 1].
+//! its keys, and the OR of its 64-bit first payloads (`payload64`, or nullptr), go to
+//! tile_bits[kStateWords * tile + ...].
 template <typename KeyT>
 __global__ void __launch_bounds__(kSortThreads)
 RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int pass, const int passes,
-                         const int narrow_mode, unsigned* __restrict__ tile_hist, const int num_tiles,
+                         const SortMode mode, unsigned* __restrict__ tile_hist, const int num_tiles,
                          unsigned long long* __restrict__ tile_bits,
-                         const unsigned long long* __restrict__ state) {
+                         const unsigned long long* __restrict__ state,
+                         const unsigned long long* __restrict__ payload64) {
   __shared__ unsigned count[kSortWaves][kSortBins];  // one sub-histogram per wave: 4x less contention
-  __shared__ unsigned long long wave_bits[kSortWaves][2];
+  __shared__ unsigned long long wave_bits[kSortWaves][kStateWords];
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int shift = 8 * pass;
+  const unsigned flip = SignFlip(mode, pass);
   int where = kBufIn;
   bool narrow = false;
   KeyT high = 0;
   if (pass > 0) {
-    const PassPlan plan = PlanPass(state, pass, passes, narrow_mode);
+    const PassPlan plan = PlanPass(state, pass, passes, mode);
     if (!plan.active) return;
     narrow = plan.narrow_keys;
     high = static_cast<KeyT>(plan.key_high);
@@ -206,22 +238,26 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
   const bool reduce_bits = pass == 0 && tile_bits != nullptr;
   if (reduce_bits) {
-    unsigned long long any = 0ull, all = ~0ull;
+    unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
-      if (base + static_cast<int64_t>(r) * kSortThreads < n) {
+      const int64_t i = base + static_cast<int64_t>(r) * kSortThreads;
+      if (i < n) {
         any |= static_cast<unsigned long long>(key[r]);
         all &= static_cast<unsigned long long>(key[r]);
+        if (payload64 != nullptr) pay |= payload64[i];
       }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
       any |= __shfl_xor(any, d);
       all &= __shfl_xor(all, d);
+      pay |= __shfl_xor(pay, d);
     }
     if ((tid & 63) == 0) {
       wave_bits[wave][0] = any;
       wave_bits[wave][1] = all;
+      wave_bits[wave][2] = pay;
     }
   }
   // From the second pass on, equal keys sit next to each other, and a power-law batch has runs
@@ -232,7 +268,7 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const bool in_range = base + static_cast<int64_t>(r) * kSortThreads < n;
-    const unsigned digit = in_range ? static_cast<unsigned>((key[r] >> shift) & 0xff) : 0xffffffffu;
+    const unsigned digit = in_range ? (static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip) : 0xffffffffu;
     const unsigned before = __shfl_up(digit, 1);
     const bool head = lane == 0 || before != digit;
     const unsigned long long heads = __ballot(head);
@@ -247,14 +283,16 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   for (int w = 0; w < kSortWaves; ++w) total += count[w][tid];
   tile_hist[static_cast<size_t>(tid) * num_tiles + blockIdx.x] = total;
   if (reduce_bits && tid == 0) {
-    unsigned long long any = 0ull, all = ~0ull;
+    unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) {
       any |= wave_bits[w][0];
       all &= wave_bits[w][1];
+      pay |= wave_bits[w][2];
     }
-    tile_bits[2 * blockIdx.x] = any;
-    tile_bits[2 * blockIdx.x + 1] = all;
+    tile_bits[kStateWords * blockIdx.x] = any;
+    tile_bits[kStateWords * blockIdx.x + 1] = all;
+    tile_bits[kStateWords * blockIdx.x + 2] = pay;
   }
 }
 
@@ -291,40 +329,46 @@ __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* tot
 //! that extra workgroup is launched (grid = 1), in pass 0.
 __global__ void __launch_bounds__(kSortThreads)
 RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
-                     unsigned* __restrict__ bin_total, const int pass, const int passes,
+                     unsigned* __restrict__ bin_total, const int pass, const int passes, const SortMode mode,
                      const unsigned long long* __restrict__ tile_bits,
                      unsigned long long* __restrict__ state) {
   if (blockIdx.x == gridDim.x - 1 && gridDim.x != kSortBins) {  // the extra workgroup of pass 0
-    __shared__ unsigned long long wave_bits[kSortWaves][2];
-    unsigned long long any = 0ull, all = ~0ull;
+    __shared__ unsigned long long wave_bits[kSortWaves][kStateWords];
+    unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
     for (int t = threadIdx.x; t < num_tiles; t += kSortThreads) {
-      any |= tile_bits[2 * t];
-      all &= tile_bits[2 * t + 1];
+      any |= tile_bits[kStateWords * t];
+      all &= tile_bits[kStateWords * t + 1];
+      pay |= tile_bits[kStateWords * t + 2];
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
       any |= __shfl_xor(any, d);
       all &= __shfl_xor(all, d);
+      pay |= __shfl_xor(pay, d);
     }
     if ((threadIdx.x & 63) == 0) {
       wave_bits[threadIdx.x >> 6][0] = any;
       wave_bits[threadIdx.x >> 6][1] = all;
+      wave_bits[threadIdx.x >> 6][2] = pay;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       any = 0ull;
       all = ~0ull;
+      pay = 0ull;
 #pragma unroll
       for (int w = 0; w < kSortWaves; ++w) {
         any |= wave_bits[w][0];
         all &= wave_bits[w][1];
+        pay |= wave_bits[w][2];
       }
-      state[0] = any & ~all;
-      state[1] = all;
+      state[kStateVarying] = any & ~all;
+      state[kStateAllBits] = all;
+      state[kStatePayloadBits] = pay;
     }
     return;
   }
-  if (pass > 0 && state != nullptr && !PlanPass(state, pass, passes, kNarrowNever).active) return;
+  if (pass > 0 && !PlanPass(state, pass, passes, mode).active) return;
   unsigned* row = tile_hist + static_cast<size_t>(blockIdx.x) * num_tiles;
   unsigned carry = 0;
   for (int base = 0; base < num_tiles; base += kSortThreads) {
@@ -347,7 +391,7 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
 //! the exclusive prefix over waves, `tile_start[d]` as the tile-local position of the first key
 //! with digit d.  Contains barriers: every thread of the workgroup must call it.
 template <typename KeyT>
-__device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const int shift,
+__device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const int shift, const unsigned flip,
                                          const int first_pos, const int n,
                                          unsigned (*wave_count)[kSortBins], unsigned* tile_start,
                                          unsigned (&slot)[kSortItems]) {
@@ -357,7 +401,7 @@ __device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const in
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const bool valid = first_pos + r * 64 < n;
-    const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
+    const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip;
     const unsigned long long peers = MatchDigit(digit, valid);
     // every peer reads the wave's running count of its digit (one LDS broadcast per digit), then
     // the lowest peer bumps it; a wavefront's LDS operations execute in program order
@@ -385,7 +429,7 @@ __device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const in
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     if (slot[r] != 0xffffffffu) {
-      const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff);
+      const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip;
       slot[r] += tile_start[digit] + wave_count[wave][digit];
     }
   }
@@ -434,19 +478,20 @@ __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T 
 template <typename KeyT, typename V1, typename V2>
 __global__ void __launch_bounds__(kSortThreads, 4)
 RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
-                   const int64_t n, const int pass, const int passes, const int narrow_mode,
+                   const int64_t n, const int pass, const int passes, const SortMode mode,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
                    const int num_tiles, const unsigned long long* __restrict__ state) {
   // which of (caller's input, caller's output, scratch) this pass reads and writes follows from
   // the passes that run at all and from how each array is stored in the scratch
-  const PassPlan plan = PlanPass(state, pass, passes, narrow_mode);
+  const PassPlan plan = PlanPass(state, pass, passes, mode);
   if (!plan.active) return;
   const int shift = 8 * pass;
+  const unsigned flip = SignFlip(mode, pass);
   constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
   constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
-  constexpr bool kNarrowV1 = kHasV1 && sizeof(V1) == 8;  // sample ids < nnz <= INT_MAX
+  const bool narrow_v1 = kHasV1 && sizeof(V1) == 8 && plan.narrow_v1;  // all values in [0, 2^32)
   const ArrayRoute key_route = RouteArray(plan, plan.narrow_keys);
-  const ArrayRoute v1_route = RouteArray(plan, kNarrowV1);
+  const ArrayRoute v1_route = RouteArray(plan, narrow_v1);
   const ArrayRoute v2_route = RouteArray(plan, false);
   constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
   __shared__ __attribute__((aligned(16))) unsigned char stage[kSortTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
@@ -492,9 +537,9 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   // i.e. a second round for a quarter of the 1024 tiles); it is loaded after the keys have left.
   constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
   V1 item1[kSortItems];
-  if constexpr (kEarlyV1) LoadRouted<V1>(v1, v1_route.src, kNarrowV1, n, wave_base + lane, 64, V1(0), item1);
+  if constexpr (kEarlyV1) LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
   unsigned slot[kSortItems];  // tile-local position in digit order
-  RankTile<KeyT>(key, shift, wave * (64 * kSortItems) + lane, count, wave_count, tile_start, slot);
+  RankTile<KeyT>(key, shift, flip, wave * (64 * kSortItems) + lane, count, wave_count, tile_start, slot);
 
   // ---- keys: through LDS into digit order, then out in runs ----
   KeyT* stage_keys = reinterpret_cast<KeyT*>(stage);
@@ -508,15 +553,15 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     const int q = r * kSortThreads + tid;
     if (q < count) {
       const KeyT k = stage_keys[q];
-      const unsigned digit = static_cast<unsigned>((k >> shift) & 0xff);
+      const unsigned digit = static_cast<unsigned>((k >> shift) & 0xff) ^ flip;
       dest[r] = digit_base[digit] + (static_cast<unsigned>(q) - tile_start[digit]);
       StoreRouted<KeyT>(keys, key_route.dst, plan.narrow_keys, n, dest[r], k);
     }
   }
   // ---- payloads take the same route ----
   if constexpr (kHasV1) {
-    if constexpr (!kEarlyV1) LoadRouted<V1>(v1, v1_route.src, kNarrowV1, n, wave_base + lane, 64, V1(0), item1);
-    StageAndStore<V1>(stage, item1, slot, dest, count, v1, v1_route.dst, kNarrowV1, n);
+    if constexpr (!kEarlyV1) LoadRouted<V1>(v1, v1_route.src, narrow_v1, n, wave_base + lane, 64, V1(0), item1);
+    StageAndStore<V1>(stage, item1, slot, dest, count, v1, v1_route.dst, narrow_v1, n);
   }
   if constexpr (kHasV2) {
     V2 item[kSortItems];
@@ -548,7 +593,8 @@ template <typename KeyT, typename V1, typename V2>
 __global__ void __launch_bounds__(kSortThreads)
 SingleTileSortKernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_out,
                      const V1* __restrict__ v1_in, V1* __restrict__ v1_out,
-                     const V2* __restrict__ v2_in, V2* __restrict__ v2_out, const int n, const int passes) {
+                     const V2* __restrict__ v2_in, V2* __restrict__ v2_out, const int n, const int passes,
+                     const int sign_pass) {
   constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
   constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
   constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
@@ -602,7 +648,7 @@ SingleTileSortKernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_o
     for (int w = 0; w < kSortWaves; ++w) wave_count[w][tid] = 0;
     __syncthreads();
     unsigned slot[kSortItems];
-    RankTile<KeyT>(key, shift, first_pos, n, wave_count, tile_start, slot);
+    RankTile<KeyT>(key, shift, pass == sign_pass ? 0x80u : 0u, first_pos, n, wave_count, tile_start, slot);
     PermuteThroughLds<KeyT>(stage, key, slot, first_pos, n);
     if constexpr (kHasV1) PermuteThroughLds<V1>(stage, item1, slot, first_pos, n);
     if constexpr (kHasV2) PermuteThroughLds<V2>(stage, item2, slot, first_pos, n);
@@ -642,26 +688,32 @@ struct RadixSortPlan {
     bin_total = off;
     off += SortAlign(kSortBins * sizeof(unsigned));
     tile_bits = off;
-    off += SortAlign(static_cast<size_t>(2) * num_tiles * sizeof(unsigned long long));
+    off += SortAlign(static_cast<size_t>(kStateWords) * num_tiles * sizeof(unsigned long long));
     varying = off;
-    off += SortAlign(2 * sizeof(unsigned long long));
+    off += SortAlign(kStateWords * sizeof(unsigned long long));
     total = off;
   }
 };
 
-//! Stable sort of n (key, v1[, v2]) by the low `key_bits` bits of the key (keys must be
-//! non-negative and < 2^key_bits).  Inputs are not modified; outputs and `work` (at least
-//! RadixSortPlan::total bytes) must not overlap the inputs.  A 64-bit v1 must hold values
-//! below 2^32 (it is kept as 32 bits between passes; here: sample ids < nnz <= INT_MAX).
+//! Stable sort of n (key, v1[, v2]) by the low `key_bits` bits of the key.  Inputs are not
+//! modified; outputs and `work` (at least RadixSortPlan::total bytes) must not overlap the inputs.
+//!   signed_keys: the keys are two's-complement numbers; with key_bits = all bits they are put in
+//!                signed order (negative keys first).  With key_bits < all bits the keys must lie in
+//!                [0, 2^key_bits).
+//!   v1_bits    : a 64-bit v1 whose values are known to lie in [0, 2^v1_bits), v1_bits <= 32, is
+//!                kept as 32 bits between passes without looking; 0 = unknown, decided on the
+//!                device from the values themselves (pass 0 reads them once more for that).
 template <typename KeyT, typename V1, typename V2>
 inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in, V1* v1_out,
                            const V2* v2_in, V2* v2_out, const size_t n, const int key_bits,
-                           char* work, hipStream_t stream) {
+                           char* work, hipStream_t stream, const bool signed_keys = false,
+                           const int v1_bits = 0) {
   if (n == 0) return;
   const RadixSortPlan<KeyT, V1, V2> plan(n, key_bits);
+  const int sign_pass = (signed_keys && key_bits >= static_cast<int>(8 * sizeof(KeyT))) ? plan.passes - 1 : -1;
   if (n <= static_cast<size_t>(kSortTile)) {
     SingleTileSortKernel<KeyT, V1, V2><<<1, kSortThreads, 0, stream>>>(
-        keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes);
+        keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes, sign_pass);
     return;
   }
   const SortArray<KeyT> keys{keys_in, keys_out, reinterpret_cast<KeyT*>(work + plan.keys_tmp)};
@@ -669,27 +721,35 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   const SortArray<V2> v2{v2_in, v2_out, reinterpret_cast<V2*>(work + plan.v2_tmp)};
   unsigned* tile_hist = reinterpret_cast<unsigned*>(work + plan.tile_hist);
   unsigned* bin_total = reinterpret_cast<unsigned*>(work + plan.bin_total);
-  const bool skip_on_device = plan.passes > kStaticRoutePasses;
-  unsigned long long* tile_bits =
-      skip_on_device ? reinterpret_cast<unsigned long long*>(work + plan.tile_bits) : nullptr;
-  unsigned long long* state =
-      skip_on_device ? reinterpret_cast<unsigned long long*>(work + plan.varying) : nullptr;
-  int narrow_mode = kNarrowNever;
+  constexpr bool kWideV1 = !std::is_same<V1, NoPayload>::value && sizeof(V1) == 8;
+  SortMode mode;
+  mode.use_varying = plan.passes > kStaticRoutePasses;
+  mode.sign_pass = sign_pass;
+  mode.narrow_keys = kNarrowNever;
   if (sizeof(KeyT) == 8) {
-    if (key_bits <= 32) narrow_mode = kNarrowAlways;            // the caller's bound says so
-    else if (skip_on_device) narrow_mode = kNarrowIfConstantHigh;  // decided from the keys themselves
+    if (key_bits <= 32) mode.narrow_keys = kNarrowAlways;                 // the caller's bound says so
+    else if (mode.use_varying) mode.narrow_keys = kNarrowIfConstantHigh;  // decided from the keys themselves
   }
+  mode.narrow_v1 = !kWideV1 ? kNarrowNever
+                            : (v1_bits > 0 && v1_bits <= 32 ? kNarrowAlways : kNarrowIfConstantHigh);
+  const bool device_state = mode.use_varying || mode.narrow_v1 == kNarrowIfConstantHigh;
+  unsigned long long* tile_bits =
+      device_state ? reinterpret_cast<unsigned long long*>(work + plan.tile_bits) : nullptr;
+  unsigned long long* state =
+      device_state ? reinterpret_cast<unsigned long long*>(work + plan.varying) : nullptr;
+  const unsigned long long* payload64 =
+      mode.narrow_v1 == kNarrowIfConstantHigh ? reinterpret_cast<const unsigned long long*>(v1_in) : nullptr;
   const int64_t count = static_cast<int64_t>(n);
   const bool fold_scan = plan.num_tiles <= kFoldScanTiles;  // launch-bound sizes: one launch less per pass
   for (int p = 0; p < plan.passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        keys, count, p, plan.passes, narrow_mode, tile_hist, plan.num_tiles, tile_bits, state);
-    const int scan_blocks = (fold_scan ? 0 : kSortBins) + (p == 0 && skip_on_device ? 1 : 0);
+        keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64);
+    const int scan_blocks = (fold_scan ? 0 : kSortBins) + (p == 0 && device_state ? 1 : 0);
     if (scan_blocks > 0)
       RadixScanTilesKernel<<<scan_blocks, kSortThreads, 0, stream>>>(
-          tile_hist, plan.num_tiles, bin_total, p, plan.passes, tile_bits, state);
+          tile_hist, plan.num_tiles, bin_total, p, plan.passes, mode, tile_bits, state);
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        keys, v1, v2, count, p, plan.passes, narrow_mode, tile_hist, fold_scan ? nullptr : bin_total,
+        keys, v1, v2, count, p, plan.passes, mode, tile_hist, fold_scan ? nullptr : bin_total,
         plan.num_tiles, state);
   }
 }
@@ -727,10 +787,26 @@ RunHeadCountKernel(const IndexT* __restrict__ indices, const int64_t n, unsigned
   }
 }
 
+//! Many tiles (> kSelfSumTiles): tile_count[t] becomes the number of run heads in tiles 0..t-1
+//! (one workgroup, in place), so that RunHeadScanKernel does not re-add O(tiles^2) words.
+__global__ void __launch_bounds__(kSortThreads)
+RunHeadTilePrefixKernel(unsigned* __restrict__ tile_count, const int num_tiles) {
+  unsigned carry = 0;
+  for (int base = 0; base < num_tiles; base += kSortThreads) {
+    const int t = base + threadIdx.x;
+    const unsigned v = t < num_tiles ? tile_count[t] : 0u;
+    unsigned total;
+    const unsigned excl = BlockExclusiveScan(v, &total);
+    if (t < num_tiles) tile_count[t] = carry + excl;
+    carry += total;
+  }
+}
+
 template <typename IndexT>
 __global__ void __launch_bounds__(kSortThreads)
 RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
                   const unsigned* __restrict__ tile_count /* run heads per tile; null: one tile */,
+                  const bool tile_count_is_prefix,
                   IndexT* __restrict__ remapped) {
   __shared__ unsigned wave_sum[kSortWaves];
   const int wave = threadIdx.x >> 6;
@@ -747,8 +823,13 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
   // most a few thousand words from L2) -- cheaper than a separate single-workgroup scan launch
   __shared__ unsigned wave_before[kSortWaves];
   unsigned before = 0;
-  if (tile_count != nullptr)
-    for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += kSortThreads) before += tile_count[t];
+  if (tile_count != nullptr) {
+    if (tile_count_is_prefix) {
+      if (threadIdx.x == 0) before = tile_count[blockIdx.x];
+    } else {
+      for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += kSortThreads) before += tile_count[t];
+    }
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
   if (lane == 0) {
@@ -781,12 +862,18 @@ inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped,
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
   unsigned* tile_sum = reinterpret_cast<unsigned*>(work);
   if (tiles == 1) {  // one launch instead of two
-    RunHeadScanKernel<IndexT><<<1, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), nullptr, remapped);
+    RunHeadScanKernel<IndexT><<<1, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), nullptr, false,
+                                                              remapped);
     return;
   }
   RunHeadCountKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum);
+  // every workgroup of the scan adds up the counts of the earlier tiles itself: tiles^2 / 2 words
+  // in total -- 2 MB at 1024 tiles, but 5e11 bytes at the API's limit of 2^31 lookups; beyond
+  // kSelfSumTiles a single-workgroup prefix pass (one more launch) replaces it
+  const bool prefix = tiles > kSelfSumTiles;
+  if (prefix) RunHeadTilePrefixKernel<<<1, kSortThreads, 0, stream>>>(tile_sum, tiles);
   RunHeadScanKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum,
-                                                               remapped);
+                                                               prefix, remapped);
 }
 
 }  // namespace detail

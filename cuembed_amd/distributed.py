@@ -11,9 +11,50 @@ fp16 table is 5.12 GB of 288 GB).  Therefore
               over xGMI -- dense, or "sparse" on the compressed rows only.
 
 Only plain torch.distributed calls are used, so the same code runs on gloo/CPU tensors in the
-tests (with the compute injected) and on RCCL in production.
+tests (with the compute injected) and on RCCL in production.  When the process group's backend
+cannot take device tensors (gloo; e.g. several ranks sharing one GPU, where RCCL refuses to build
+a communicator) device tensors are staged through host copies around each collective.
 """
 import torch
+
+
+def _stage_on_host(t, group):
+    """True when the collective has to run on a host copy of device tensor `t`."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t, group=None, async_op=False):
+    import torch.distributed as dist
+    if not _stage_on_host(t, group):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)
+    return None
+
+
+def _all_gather(t, group=None):
+    """List of every rank's `t` (same shape on all ranks)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if not _stage_on_host(t, group):
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        return out
+    h = t.cpu()
+    out = [torch.empty_like(h) for _ in range(world)]
+    dist.all_gather(out, h, group=group)
+    return [o.to(t.device) for o in out]
+
+
+def _all_to_all_single(t, recv_rows, send_rows, group=None):
+    """Rows of `t` cut by send_rows go to the ranks in order; returns the rows received."""
+    import torch.distributed as dist
+    src = t.cpu() if _stage_on_host(t, group) else t.contiguous()
+    got = torch.empty((sum(recv_rows),) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+    dist.all_to_all_single(got, src, output_split_sizes=recv_rows, input_split_sizes=send_rows, group=group)
+    return got.to(t.device)
 
 
 def shard_bounds(batch_size, rank, world):
@@ -43,8 +84,7 @@ def shard_csr(offsets, indices, weights, rank, world):
 
 def allreduce_dense_grad(grad_embedding, group=None, async_op=False):
     """Sum the per-rank partial table gradients in place (RCCL all-reduce over xGMI)."""
-    import torch.distributed as dist
-    return dist.all_reduce(grad_embedding, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return _all_reduce_sum(grad_embedding, group=group, async_op=async_op)
 
 
 def _merge_on_gpu(ids, vals, num_categories):
@@ -54,8 +94,10 @@ def _merge_on_gpu(ids, vals, num_categories):
     the rows of each run (fp32 partial sums) into the compressed result."""
     from . import ops
     m = ids.numel()
+    if m == 0:                       # every rank's compressed gradient was empty
+        return ids, vals
     pos = ops.extract_row_ids_for_concat(m, torch.int64, ids.device)
-    t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories)
+    t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories, num_rows=m)
     remap = ops.compute_compressed_grad_indices(t_ids)
     num_unique = int(remap[-1].item()) + 1
     merged, uniq = ops.embedding_backward(vals.contiguous(), num_unique, t_ids, t_pos, remap)
@@ -78,18 +120,14 @@ def _gather_ragged(ids, vals, group):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = [int(c.item()) for c in _all_gather(n, group)]
     cap = max(max(counts), 1)
     pad_vals = torch.zeros((cap, vals.shape[1]), dtype=vals.dtype, device=vals.device)
     pad_vals[: vals.shape[0]] = vals
     pad_ids = torch.full((cap,), -1, dtype=torch.int64, device=ids.device)
     pad_ids[: ids.shape[0]] = ids
-    all_vals = [torch.empty_like(pad_vals) for _ in range(world)]
-    all_ids = [torch.empty_like(pad_ids) for _ in range(world)]
-    dist.all_gather(all_vals, pad_vals, group=group)
-    dist.all_gather(all_ids, pad_ids, group=group)
+    all_vals = _all_gather(pad_vals, group)
+    all_ids = _all_gather(pad_ids, group)
     return (torch.cat([all_ids[r][: counts[r]] for r in range(world)]),
             torch.cat([all_vals[r][: counts[r]] for r in range(world)]))
 
@@ -135,15 +173,10 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     cuts = torch.tensor([b[0] for b in bounds] + [num_categories], dtype=torch.int64, device=ids.device)
     pos = torch.searchsorted(ids, cuts)                      # ids ascend: range r = [pos[r], pos[r+1])
     send = (pos[1:] - pos[:-1]).to(torch.int64)
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    send_l, recv_l = send.tolist(), recv.tolist()
-    got_ids = torch.empty((sum(recv_l),), dtype=torch.int64, device=ids.device)
-    got_vals = torch.empty((sum(recv_l), rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    dist.all_to_all_single(got_ids, ids.contiguous(), output_split_sizes=recv_l, input_split_sizes=send_l,
-                           group=group)
-    dist.all_to_all_single(got_vals, rows.contiguous(), output_split_sizes=recv_l, input_split_sizes=send_l,
-                           group=group)
+    send_l = send.tolist()
+    recv_l = _all_to_all_single(send, [1] * world, [1] * world, group).tolist()
+    got_ids = _all_to_all_single(ids, recv_l, send_l, group)
+    got_vals = _all_to_all_single(rows, recv_l, send_l, group)
     if got_ids.numel() > 0:
         mine_ids, mine_vals = _merge(got_ids, got_vals, num_categories)
     else:

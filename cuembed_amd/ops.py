@@ -134,9 +134,10 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
         if out.dtype != params.dtype or out.numel() != batch_size * (num_hots if m == CONCAT else 1) * width:
             raise ValueError("out has the wrong dtype or size")
     if batch_size > 0:
-        _lib.lib().cuembed_embedding_forward(
-            _ptr(params), et, width, _ptr(indices), it, _ptr(offsets), ot, _ptr(weights),
-            batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _stream(params))
+        with torch.cuda.device(params.device):   # the launch must happen on the tensors' device
+            _lib.lib().cuembed_embedding_forward(
+                _ptr(params), et, width, _ptr(indices), it, _ptr(offsets), ot, _ptr(weights),
+                batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _stream(params))
     return out
 
 
@@ -165,9 +166,10 @@ def embedding_weight_grad(params, indices, grad_y, offsets=None, batch_size=None
         raise ValueError("grad_y must have one row per sample")
     out = torch.empty((indices.numel(),), dtype=params.dtype, device=dev)
     if batch_size > 0 and indices.numel() > 0:
-        _lib.lib().cuembed_embedding_weight_grad(_ptr(params), et, params.shape[1], _ptr(indices), it,
-                                                 _ptr(offsets), ot, _ptr(grad_y), batch_size, num_hots,
-                                                 _ptr(out), _stream(params))
+        with torch.cuda.device(params.device):   # the launch must happen on the tensors' device
+            _lib.lib().cuembed_embedding_weight_grad(_ptr(params), et, params.shape[1], _ptr(indices), it,
+                                                     _ptr(offsets), ot, _ptr(grad_y), batch_size, num_hots,
+                                                     _ptr(out), _stream(params))
     return out
 
 
@@ -222,10 +224,11 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
                 raise TypeError("inverse_mapping must have the index dtype")
     else:
         inverse_mapping = None
-    _lib.lib().cuembed_embedding_backward(
-        _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices),
-        _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
-        int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), _stream(grad_y))
+    with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
+        _lib.lib().cuembed_embedding_backward(
+            _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices),
+            _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
+            int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), _stream(grad_y))
     return grad_embedding, inverse_mapping
 
 
@@ -240,11 +243,14 @@ def transpose_workspace_bytes(nnz, index_dtype, weight_dtype=None):
     return lwork.value
 
 
-def transpose(rows, cols, weights=None, workspace=None, num_categories=None):
+def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num_rows=None):
     """Stable sort of (rows[i][, weights[i]]) by key cols[i] (callers pass rows = sample ids,
     cols = lookup indices).  Returns (sorted cols, rows carried along, weights carried along).
-    num_categories (optional, this library's extension): an upper bound on the values in `cols`;
-    the sort then skips the key digits that are always zero (same result, fewer passes)."""
+    Generic like the reference's: `cols` are ordered as signed numbers, `rows` may hold anything.
+    num_categories (optional, this library's extension): every value in `cols` lies in
+    [0, num_categories); the sort then skips the key digits that are always zero (same result,
+    fewer passes).  num_rows (optional, extension): every value in `rows` lies in [0, num_rows)
+    -- int64 rows below 2^32 then travel as 32 bits without the library reading them to find out."""
     _check_dev("rows", rows)
     dev = rows.device
     _check_dev("cols", cols, dev)
@@ -269,10 +275,12 @@ def transpose(rows, cols, weights=None, workspace=None, num_categories=None):
         raise ValueError("workspace too small: need %d bytes" % need)
     lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
     bits = 0 if not num_categories else max(1, int(num_categories - 1).bit_length())
+    row_bits = 0 if not num_rows else max(1, int(num_rows - 1).bit_length())
     if nnz > 0:
-        _lib.lib().cuembed_transpose_bounded(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
-                                             _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(workspace),
-                                             ctypes.byref(lwork), bits, _stream(rows))
+        with torch.cuda.device(rows.device):   # the launch must happen on the tensors' device
+            _lib.lib().cuembed_transpose_hinted(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
+                                                _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(workspace),
+                                                ctypes.byref(lwork), bits, row_bits, _stream(rows))
     return t_rows, t_cols, t_w
 
 
@@ -296,16 +304,18 @@ def compute_compressed_grad_indices(indices, workspace=None):
         raise ValueError("workspace too small: need %d bytes" % need)
     lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
     if nnz > 0:
-        _lib.lib().cuembed_compute_compressed_grad_indices(_ptr(indices), nnz, it, _ptr(out),
-                                                           _ptr(workspace), ctypes.byref(lwork),
-                                                           _stream(indices))
+        with torch.cuda.device(indices.device):   # the launch must happen on the tensors' device
+            _lib.lib().cuembed_compute_compressed_grad_indices(_ptr(indices), nnz, it, _ptr(out),
+                                                               _ptr(workspace), ctypes.byref(lwork),
+                                                               _stream(indices))
     return out
 
 
 def extract_row_ids_from_fixed(batch_size, num_hots, dtype=torch.int32, device="cuda"):
     out = torch.empty((batch_size * num_hots,), dtype=dtype, device=device)
     _check_dev("row_ids", out)
-    _lib.lib().cuembed_extract_row_ids_from_fixed(batch_size, num_hots, _INDEX[dtype], _ptr(out), _stream(out))
+    with torch.cuda.device(out.device):   # the launch must happen on the tensors' device
+        _lib.lib().cuembed_extract_row_ids_from_fixed(batch_size, num_hots, _INDEX[dtype], _ptr(out), _stream(out))
     return out
 
 
@@ -320,15 +330,17 @@ def extract_row_ids_from_csr(offsets, nnz=None, dtype=None, batch_size=None):
     dtype = offsets.dtype if dtype is None else dtype
     out = torch.empty((nnz,), dtype=dtype, device=offsets.device)
     if batch_size > 0 and nnz > 0:
-        _lib.lib().cuembed_extract_row_ids_from_csr(_ptr(offsets), ot, batch_size, _INDEX[dtype],
-                                                    _ptr(out), _stream(offsets))
+        with torch.cuda.device(offsets.device):   # the launch must happen on the tensors' device
+            _lib.lib().cuembed_extract_row_ids_from_csr(_ptr(offsets), ot, batch_size, _INDEX[dtype],
+                                                        _ptr(out), _stream(offsets))
     return out
 
 
 def extract_row_ids_for_concat(nnz, dtype=torch.int32, device="cuda"):
     out = torch.empty((nnz,), dtype=dtype, device=device)
     _check_dev("row_ids", out)
-    _lib.lib().cuembed_extract_row_ids_for_concat(nnz, _INDEX[dtype], _ptr(out), _stream(out))
+    with torch.cuda.device(out.device):   # the launch must happen on the tensors' device
+        _lib.lib().cuembed_extract_row_ids_for_concat(nnz, _INDEX[dtype], _ptr(out), _stream(out))
     return out
 
 

@@ -91,7 +91,22 @@ CUEMBED_DECLARE_FORWARD(bf16_i64_o64, void, int64_t, int64_t)
  * = table rows.  Compressed: remapped indices given, grad_embedding has
  * num_unique rows and inverse_mapping[num_unique] is written.  The gradient
  * buffer must be zero before the scatter: skip_grad_init != 0 means the caller
- * already zeroed it, otherwise the call zeroes it first. */
+ * already zeroed it, otherwise the call zeroes it first.
+ *
+ * ARITHMETIC (deviation from the reference for 16-bit gradients).  The reference
+ * accumulates in GradT: with fp16 every product grad_y * weight and every partial sum
+ * is rounded to fp16 (embedding_lookup_ops.cuh:636-645, embedding_lookup_cpu.hpp:139-142).
+ * Here the products and the partial sum of a run are kept in fp32 and rounded to GradT
+ * once per flush: one flush for a run inside a workgroup; a run that crosses workgroups
+ * (>= 256 lookups each) is combined with one GradT hardware atomic per workgroup.
+ *   - fp32 gradients: same fp32 arithmetic in the same nz order, equal up to where a run
+ *     is cut into partial sums (a few ulps of the summed magnitudes);
+ *   - fp16/bf16 gradients: bit-identical to the reference whenever all partial sums are
+ *     exactly representable in GradT (the reference's own test data: integer grad_y,
+ *     weights 0.5/0.25); otherwise within 1e-2 (fp16) of the reference relative to
+ *     sum_j |grad_y_j * w_j|, and never further from the exact sum than the reference is.
+ *     Runs longer than ~2^11 lookups are where the two part for good: the reference's fp16
+ *     running sum stalls, this one does not.  Measured in tests/test_gpu_backward_tolerance.py. */
 #define CUEMBED_DECLARE_BACKWARD(SUFFIX, ELEM, INDEX)                                     \
   void cuembed_embedding_backward_##SUFFIX(                                               \
       const ELEM* grad_y, int embed_width, int num_grad_embedding_rows, int nnz,          \
@@ -112,7 +127,12 @@ CUEMBED_DECLARE_BACKWARD(bf16_i64, void, int64_t)
  * rows = sample ids, cols = lookup indices.  transpose_rows receives the sorted
  * lookup indices, transpose_cols the sample ids, transpose_weights the weights
  * (untouched when weights == NULL).  The suffix names the index type and the
- * WEIGHT type. */
+ * WEIGHT type.
+ * Generic like the reference's (cub::DeviceRadixSort::SortPairs over all key bits,
+ * index_transforms.cuh:108-136): `cols` may hold any value of the index type, keys are
+ * ordered as SIGNED numbers (negative keys first); `rows` may hold any value of the
+ * index type (int64 rows that are negative or >= 2^32 are carried at full width; the
+ * library finds that out on the device).  nnz <= INT_MAX. */
 #define CUEMBED_DECLARE_TRANSPOSE(SUFFIX, INDEX, WEIGHT)                                   \
   void cuembed_transpose_##SUFFIX(const INDEX* rows, const INDEX* cols,                    \
                                   const WEIGHT* weights, int nnz, INDEX* transpose_rows,   \
@@ -178,6 +198,14 @@ void cuembed_transpose_bounded(const void* rows, const void* cols, const void* w
                                int index_type, int weight_type, void* transpose_rows,
                                void* transpose_cols, void* transpose_weights, char* work,
                                size_t* lwork, int index_bits, cuembed_stream_t stream);
+/* Extension: as cuembed_transpose_bounded, plus a bound on the values in `rows`: int64 rows
+ * known to lie in [0, 2^row_bits), row_bits <= 32 (sample ids always do), are moved as 32 bits
+ * between the radix passes without the library reading them once more to find out.
+ * row_bits <= 0 means "unknown" (= cuembed_transpose_bounded). */
+void cuembed_transpose_hinted(const void* rows, const void* cols, const void* weights, int nnz,
+                              int index_type, int weight_type, void* transpose_rows,
+                              void* transpose_cols, void* transpose_weights, char* work,
+                              size_t* lwork, int index_bits, int row_bits, cuembed_stream_t stream);
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream);

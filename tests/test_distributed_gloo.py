@@ -73,6 +73,11 @@ def _worker(rank, world, port, csr, ret):
             rebuilt = np.zeros_like(want)
             rebuilt[ids.numpy()] = rows.numpy()
             assert np.array_equal(rebuilt, want), algorithm
+        # nothing to exchange on any rank (a batch without lookups)
+        for algorithm in ("allgather", "owner"):
+            ids, rows = D.allreduce_sparse_grad(torch.empty((0, W)), torch.empty((0,), dtype=torch.int64), ncat,
+                                                algorithm=algorithm)
+            assert ids.numel() == 0 and rows.shape[0] == 0, algorithm
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

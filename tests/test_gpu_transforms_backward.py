@@ -377,3 +377,61 @@ def test_very_wide_rows_forward_weight_grad_backward(ce, oracle, elem):
                         gy[np.repeat(np.arange(B), H)].astype(np.float64))
         tol = 2e-2 if es == 2 else 1e-4
         assert np.allclose(host(gw).astype(np.float64), ref, rtol=tol, atol=tol * np.abs(ref).max()), W
+
+
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_is_a_generic_coo_transpose(ce, oracle, idx):
+    """The reference's Transpose is cub::DeviceRadixSort::SortPairs over all bits of a SIGNED key
+    type with arbitrary IndexT payloads (index_transforms.cuh:108-136, :224-250): negative keys sort
+    first, payloads are carried verbatim.  Sizes cover the single-tile sort, the folded scan and the
+    three-launch pass; keys cover constant / varying sign digits; payloads cover the narrow (all
+    values in [0, 2^32)) and the wide route (>= 2^32, negative), decided on the device."""
+    rng = np.random.default_rng(31)
+    info = np.iinfo(idx[0])
+    key_sets = {
+        "mixed_sign_small": lambda n: rng.integers(-1000, 1000, n),
+        "mixed_sign_full": lambda n: rng.integers(info.min, info.max, n, endpoint=True),
+        "all_negative": lambda n: rng.integers(info.min, -1, n, endpoint=True),
+        "minus_one_and_zero": lambda n: rng.integers(-1, 0, n, endpoint=True),
+        "extremes": lambda n: rng.choice(np.array([info.min, -1, 0, 1, info.max]), n),
+    }
+    row_sets = {"sample_ids": lambda n: rng.integers(0, 1 << 20, n)}
+    if idx[0] == np.int64:
+        row_sets["beyond_2^32"] = lambda n: rng.integers(0, 1 << 40, n)
+        row_sets["exactly_2^32"] = lambda n: np.where(np.arange(n) == n // 2, 1 << 32, rng.integers(0, 100, n))
+        row_sets["negative"] = lambda n: rng.integers(-5, 5, n)
+        row_sets["int64_extremes"] = lambda n: rng.choice(np.array([info.min, -1, 0, (1 << 32) - 1, info.max]), n)
+    else:
+        row_sets["negative"] = lambda n: rng.integers(info.min, info.max, n, endpoint=True)
+    for nnz in (5, 4096, 4097, 40000, 200003):
+        for kname, kf in key_sets.items():
+            for rname, rf in row_sets.items():
+                cols = kf(nnz).astype(idx[0])
+                rows = rf(nnz).astype(idx[0])
+                w = rng.uniform(0, 1, nnz).astype(np.float32)
+                oi, os_, ow = oracle.transpose(rows, cols, w, stable=True)
+                for weights in (None, w):
+                    ti, ts, tw = ce.transpose(dev(rows), dev(cols), dev(weights))
+                    assert np.array_equal(host(ti), oi), (nnz, kname, rname)
+                    assert np.array_equal(host(ts), os_), (nnz, kname, rname)
+                    if weights is not None:
+                        assert np.array_equal(host(tw), ow), (nnz, kname, rname)
+    # the hints: bounded non-negative keys, rows known to be sample ids
+    nnz = 150001
+    cols = rng.integers(0, 10_000_000, nnz).astype(idx[0])
+    rows = rng.integers(0, nnz, nnz).astype(idx[0])
+    oi, os_, _ = oracle.transpose(rows, cols, None, stable=True)
+    for kw in (dict(num_categories=10_000_000), dict(num_rows=nnz), dict(num_categories=10_000_000, num_rows=nnz)):
+        ti, ts, _ = ce.transpose(dev(rows), dev(cols), **kw)
+        assert np.array_equal(host(ti), oi) and np.array_equal(host(ts), os_), kw
+
+
+def test_compressed_indices_many_tiles(ce, oracle):
+    """More than kSelfSumTiles = 4096 tiles (16.7M lookups): the run-head scan takes the route with
+    the single-workgroup prefix pass over the tile counts."""
+    rng = np.random.default_rng(5)
+    nnz = 4097 * 4096 + 77
+    keys = np.sort(rng.integers(0, 3_000_000, nnz).astype(np.int32))
+    got = host(ce.compute_compressed_grad_indices(dev(keys)))
+    want = oracle.compute_compressed_grad_indices(keys)
+    assert np.array_equal(got, want)
