@@ -29,4 +29,29 @@ cd "$R"
 python tools/rocprof_summary.py "$O/prof_bench" > "$O/bench_c2_kernel_trace_stats.txt" 2>/dev/null
 python tools/rocprof_summary.py "$O/prof_pipeline" > "$O/pipeline_c2_kernel_trace_stats.txt" 2>/dev/null
 rm -rf "$O/prof_bench" "$O/prof_pipeline"   # raw traces are large; the summaries stay
+# ---- counter passes (each counter set in its OWN run, never with another trace domain) -> traffic json
+cd /tmp
+N=8
+PF="python3 $R/tools/profile_forward.py --pattern all --iters $N"
+PP="$R/benchmarks/manual_benchmark $C2 --iterations 6 --clear_caches=false"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fwd_fetch" -- $PF > "$O/pmc_fwd.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_fwd_write" -- $PF >> "$O/pmc_fwd.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_fwd_tcc" -- $PF >> "$O/pmc_fwd.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_pipe_fetch" -- $PP > "$O/pmc_pipe.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_pipe_write" -- $PP >> "$O/pmc_pipe.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_pipe_tcc" -- $PP >> "$O/pmc_pipe.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$O/pmc_pipe.log" 2>&1
+cd "$R"
+python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
+  --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
+  --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" --out "$O/traffic_c2.json" > /dev/null
+{
+  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc; do
+    echo "#### $d"; python tools/rocprof_summary.py "$O/$d" 2>/dev/null
+  done
+} > "$O/pmc_passes.txt"
+rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_*
+# the bench line again, now with roofline.traffic from the traffic file measured above
+cp "$O/traffic_c2.json" "$R/profiles/traffic_c2.json"
+python bench.py > "$O/bench_c2_line.json" 2>> "$O/bench.err"
 ls -la "$O"
