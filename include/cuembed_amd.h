@@ -187,6 +187,22 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
                                 const void* transpose_weights, int skip_grad_init,
                                 void* grad_embedding, void* inverse_mapping,
                                 cuembed_stream_t stream);
+/* Extension (cuembed::EmbeddingBackwardRunAware): cuembed_embedding_backward with a scratch
+ * buffer and the number of grad_y rows (the batch size for sum / mean).  Two-phase like
+ * cuembed_transpose: work == NULL => *lwork receives the bytes needed (never 0), nothing runs.
+ * The few very long runs of a skewed batch (rows that almost every sample looks up) are then
+ * summed chunk-major out of LDS -- each chunk of grad_y rows is read once for all of them --
+ * instead of every such run streaming most of grad_y through the fabric again; everything else
+ * runs exactly as in cuembed_embedding_backward.  Same results up to where a run is cut into
+ * fp32 partial sums.  Shapes that cannot profit fall back to cuembed_embedding_backward. */
+void cuembed_embedding_backward_run_aware(const void* grad_y, int elem_type, int embed_width,
+                                          int num_grad_embedding_rows, int nnz,
+                                          const void* transpose_indices, const void* transpose_sample_ids,
+                                          const void* transpose_remapped_indices, int index_type,
+                                          const void* transpose_weights, int skip_grad_init,
+                                          void* grad_embedding, void* inverse_mapping,
+                                          int num_grad_y_rows, char* work, size_t* lwork,
+                                          cuembed_stream_t stream);
 void cuembed_transpose(const void* rows, const void* cols, const void* weights, int nnz,
                        int index_type, int weight_type, void* transpose_rows,
                        void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
@@ -231,6 +247,13 @@ void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_
  *     partial rows through LDS (same result up to fp rounding, much faster for small batches). */
 void cuembed_set_forward_reduction_order(int order);
 int cuembed_get_forward_reduction_order(void);
+/* cuembed::SetBackwardTuning / GetBackwardTuning (tuning and tests; 0 = built-in heuristic):
+ * lookups per nz-segment, XCD column slices of the gather (1, 2, 4, 8), hot-run detection stride
+ * of the run-aware backward (power of two >= 256; -1 disables its hot path).  Process-wide;
+ * initial values from CUEMBED_BWD_SEGMENT_LEN / CUEMBED_BWD_SLICES / CUEMBED_BWD_HOT_STRIDE, read
+ * once.  Results never depend on these. */
+void cuembed_set_backward_tuning(int segment_len, int column_slices, int hot_stride);
+void cuembed_get_backward_tuning(int* out3);
 
 /* ---- introspection ------------------------------------------------------- */
 /* Launch shape the forward would use (no launch): out[0] = elements per lane,

@@ -29,6 +29,13 @@ def ce():
     return cuembed_amd
 
 
+@pytest.fixture
+def tuning(ce):
+    """cuembed::SetBackwardTuning for one test; the heuristics are restored afterwards."""
+    yield ce.set_backward_tuning
+    ce.set_backward_tuning(0, 0, 0)
+
+
 @pytest.fixture(scope="module")
 def kats(golden_dir):
     with open(os.path.join(golden_dir, "reference_kats.json")) as f:
@@ -239,10 +246,10 @@ def test_transpose_bounded_keys_extension(ce, oracle, idx):
 
 
 @pytest.mark.parametrize("slices", ["2", "4"])
-def test_backward_column_slices_small_shapes(ce, oracle, slices, monkeypatch):
+def test_backward_column_slices_small_shapes(ce, oracle, slices, tuning):
     """Forces the XCD column-slice mapping (normally only used for >= 1M lookups) on small, odd
     shapes: partial grids of 8-workgroup rounds, segments shorter than the unroll, long runs."""
-    monkeypatch.setenv("CUEMBED_BWD_SLICES", slices)
+    tuning(column_slices=int(slices))
     for (W, B, H, ncat, alpha) in [(128, 1023, 26, 20480, 0.0), (256, 300, 63, 500, 1.15), (64, 5, 3, 50, 0.0),
                                    (512, 2000, 16, 600, 1.15)]:
         for elem in ELEMS:
