@@ -31,7 +31,7 @@ def test_header_is_plain_c():
 
 def test_every_declared_symbol_is_exported(lib_path):
     names = declared_symbols()
-    assert len(names) == 48
+    assert len(names) >= 52
     for must in ["cuembed_embedding_forward_f16_i32_o32", "cuembed_embedding_backward_f32_i64",
                  "cuembed_transpose_i64_f32", "cuembed_compute_compressed_grad_indices_i32",
                  "cuembed_extract_row_ids_from_csr_i64_o64", "cuembed_embedding_forward"]:

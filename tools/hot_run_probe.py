@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--threshold", type=int, nargs="+", default=[2048, 4096, 8192, 16384])
+    p.add_argument("--stride", type=int, nargs="+", default=[-1, 1024, 2048, 4096, 8192, 16384],
+                   help="hot-run detection strides to time the run-aware backward with (-1: hot path off)")
     p.add_argument("--alpha", type=float, default=1.15)
     p.add_argument("--batch", type=int, default=65536)
     p.add_argument("--hotness", type=int, default=64)
@@ -62,6 +64,31 @@ def main():
                                   "hot_lookups": int((~keep).sum()),
                                   "hot_lookup_fraction": round(float((~keep).float().mean()), 4),
                                   "backward_ms_without_hot_runs": round(ms, 5)})
+    # the run-aware entry point itself, per detection stride
+    remap = ce.compute_compressed_grad_indices(ti)
+    grad = torch.empty((nu, W), dtype=torch.float16, device=dev)
+    inv = torch.empty((nu,), dtype=torch.int32, device=dev)
+    ws = torch.empty((ce.backward_workspace_bytes(torch.float16, torch.int32, W, ti.numel(), B),), dtype=torch.uint8,
+                     device=dev)
+    want, _ = ce.embedding_backward(gy, nu, ti, ts, remap)
+    out["run_aware"] = []
+    for stride in a.stride:
+        ce.set_backward_tuning(hot_stride=stride)
+
+        def call():
+            ce.embedding_backward(gy, nu, ti, ts, remap, grad_embedding=grad, inverse_mapping=inv, run_aware=True,
+                                  workspace=ws)
+        for _ in range(5):
+            call()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(30):
+            call()
+        e.record()
+        e.synchronize()
+        out["run_aware"].append({"hot_stride": stride, "ms": round(s.elapsed_time(e) / 30, 5),
+                                 "max_abs_diff_vs_plain": float((grad.float() - want.float()).abs().max())})
+    ce.set_backward_tuning()
     print(json.dumps(out))
 
 
