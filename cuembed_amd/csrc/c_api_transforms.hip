@@ -98,6 +98,26 @@ void cuembed_transpose_hinted(const void* rows, const void* cols, const void* we
 #undef TR
 }
 
+void cuembed_transpose_fixed_hotness(const void* indices, const void* weights, int batch_size,
+                                     int num_hots, int index_type, int weight_type,
+                                     void* transpose_indices, void* transpose_sample_ids,
+                                     void* transpose_weights, char* work, size_t* lwork, int index_bits,
+                                     cuembed_stream_t stream) {
+#define TR(I, W)                                                                              \
+  cuembed::TransposeFixedHotness<I, W>(static_cast<const I*>(indices), static_cast<const W*>(weights), \
+                                       batch_size, num_hots, static_cast<I*>(transpose_indices), \
+                                       static_cast<I*>(transpose_sample_ids),                  \
+                                       static_cast<W*>(transpose_weights), work, lwork, Stream(stream), index_bits)
+  switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {
+    case 0: TR(int32_t, float); break;
+    case 1: TR(int32_t, __half); break;
+    case 2: TR(int64_t, float); break;
+    case 3: TR(int64_t, __half); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef TR
+}
+
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream) {

@@ -111,9 +111,20 @@ inline ScatterShape PlanScatter(const int width, const int64_t nnz, const RowSpl
 struct HotPlan {
   bool enabled;
   int stride, samples_per_fill, fills_per_chunk, chunks, lanes_per_row;
-  size_t table_bytes, partial_bytes, lds_bytes;
-  size_t work_bytes() const { return enabled ? table_bytes + partial_bytes : 0; }
+  size_t table_bytes, bounds_bytes, partial_bytes, lds_bytes;
+  int num_fills() const { return chunks * fills_per_chunk; }
+  size_t work_bytes() const { return enabled ? table_bytes + bounds_bytes + partial_bytes : 0; }
 };
+
+//! The detection stride must be a multiple of the segmented kernel's nz-block (both are powers
+//! of two whenever the hot path applies); false when the shape leaves no room for that.
+inline bool FitHotStride(HotPlan* h, const int64_t nnz, const int block_len) {
+  if (!h->enabled) return false;
+  while (h->stride < block_len) h->stride *= 2;
+  if (h->stride % block_len != 0 || (nnz + h->stride - 1) / h->stride > kHotMaxMultiples || nnz < 2 * int64_t{h->stride})
+    h->enabled = false;
+  return h->enabled;
+}
 
 template <typename GradT>
 inline HotPlan PlanHot(const int width, const int64_t nnz, const int64_t num_grad_y_rows, const RowSplit split) {
@@ -134,6 +145,7 @@ inline HotPlan PlanHot(const int width, const int64_t nnz, const int64_t num_gra
   const int64_t per_chunk = static_cast<int64_t>(h.samples_per_fill) * h.fills_per_chunk;
   h.chunks = static_cast<int>((num_grad_y_rows + per_chunk - 1) / per_chunk);
   h.table_bytes = (sizeof(HotRunTable) + 255) / 256 * 256;
+  h.bounds_bytes = (static_cast<size_t>(kHotMaxRuns) * (h.num_fills() + 1) * sizeof(int) + 255) / 256 * 256;
   h.partial_bytes = static_cast<size_t>(h.chunks) * kHotMaxRuns * kHotPieces * width * sizeof(float);
   h.lds_bytes = static_cast<size_t>(h.samples_per_fill) * row_bytes;
   return h;
@@ -145,10 +157,11 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              GradT* grad_out, RowSplit split, hipStream_t stream,
                              const int64_t zero_rows /* > 0: zero only what needs it, see below */,
                              const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */,
-                             const HotPlan& hot, const int64_t num_grad_y_rows, char* work) {
+                             HotPlan hot, const int64_t num_grad_y_rows, char* work) {
   const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr);
   const dim3 block(s.lanes, s.segments_per_block, 1);
   const int block_len = s.segments_per_block * s.segment_len;
+  FitHotStride(&hot, nnz, block_len);
   if (zero_rows > 0) {
     const int64_t tail_blocks = (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock;
     ZeroSharedAndTailRowsKernel<GradT, IndexT><<<static_cast<unsigned>(s.nz_blocks + tail_blocks), 256, 0, stream>>>(
@@ -159,10 +172,12 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
   if constexpr (N * sizeof(GradT) == 16) {
    if (hot.enabled) {
     table = reinterpret_cast<HotRunTable*>(work);
-    partial = reinterpret_cast<float*>(work + hot.table_bytes);
+    int* bounds = reinterpret_cast<int*>(work + hot.table_bytes);
+    partial = reinterpret_cast<float*>(work + hot.table_bytes + hot.bounds_bytes);
     const int multiples = static_cast<int>((nnz - 1) / hot.stride + 1);
     HotRunDetectKernel<IndexT><<<multiples, kHotDetectThreads, 0, stream>>>(
-        rows, static_cast<int>(nnz), hot.stride, block_len, table);
+        rows, sample_ids, static_cast<int>(nnz), hot.stride, block_len, hot.samples_per_fill, hot.num_fills(),
+        table, bounds);
     auto chunk_kernel = weights != nullptr ? HotRowChunkSumKernel<GradT, IndexT, N, true>
                                            : HotRowChunkSumKernel<GradT, IndexT, N, false>;
     static const bool lds_ok = [&] {  // > 64 KiB of dynamic LDS has to be asked for, once per kernel
@@ -174,8 +189,8 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
     }();
     (void)lds_ok;
     chunk_kernel<<<hot.chunks, kHotThreads, hot.lds_bytes, stream>>>(
-        grad_y, width, static_cast<int>(num_grad_y_rows), sample_ids, weights, table, partial,
-        hot.samples_per_fill, hot.fills_per_chunk, hot.lanes_per_row);
+        grad_y, width, static_cast<int>(num_grad_y_rows), sample_ids, weights, table, bounds, partial,
+        hot.samples_per_fill, hot.fills_per_chunk, hot.num_fills(), hot.lanes_per_row);
    }
   }
   const int samples_per_chunk = hot.samples_per_fill * hot.fills_per_chunk;

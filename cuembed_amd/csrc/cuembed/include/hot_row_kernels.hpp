@@ -14,11 +14,12 @@
 //   HotRunDetectKernel    finds the runs that contain two consecutive multiples of `stride`
 //                         positions (>= stride + 1 lookups, certainly every run of 2 * stride - 1)
 //                         -- at most kHotMaxRuns of them -- and records for each the part that
-//                         covers whole nz-blocks of the segmented kernel;
+//                         covers whole nz-blocks of the segmented kernel, and where every sample
+//                         chunk begins inside it;
 //   HotRowChunkSumKernel  one workgroup per chunk of consecutive samples: the chunk's grad_y rows
 //                         (128 KiB) are read ONCE into LDS, then for every hot run the lookups whose
-//                         sample lies in the chunk (a contiguous piece of the run, found by binary
-//                         search) are summed out of LDS into an fp32 partial row in the workspace;
+//                         sample lies in the chunk (a contiguous piece of the run; the detection
+//                         pass recorded where) are summed out of LDS into an fp32 partial row;
 //   SegmentedScatterAddKernel (scatter_add_kernels.hpp) skips the nz-blocks that lie inside a hot
 //                         run, and kHotMaxRuns extra workgroups at the front of its grid add up
 //                         the partial rows of one hot run each (in chunk order) and add the total
@@ -43,6 +44,7 @@ constexpr int kHotThreads = 1024;
 constexpr int kHotWaves = kHotThreads / 64;
 constexpr int kHotMaxChunks = 1024;        //!< bounds the workspace; more samples -> several chunks per workgroup
 constexpr int kHotDetectThreads = 256;
+constexpr int kHotBatch = 8;               //!< LDS row reads a wavefront keeps in flight
 
 struct HotRun {
   int row;          //!< output row (dense id in a compressed gradient, table row otherwise)
@@ -73,49 +75,38 @@ __host__ __device__ inline int HotPiecesOf(const HotRun& r, const int block_len,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Detection.  grid = number of multiples of `stride` below nnz; block = kHotDetectThreads.
-// Workgroup k looks at the row ids at ALL multiples (a few KB, L2-resident after the first
-// workgroup), decides whether a hot run STARTS at multiple k, and if so finds the run's first
-// and last position with two cooperative 256-ary searches (2 dependent loads each).  The slot of
-// a run is its rank among the hot runs (counted from the same multiples), so nothing has to be
-// zeroed or allocated atomically and the table is the same whatever the scheduling.
+// Detection.  grid = number of multiples of `stride` below nnz; block = kHotDetectThreads;
+// `stride` is a multiple of `block_len`.
+// Workgroup k reads the row ids at multiples k - 1, k, k + 1 and leaves at once unless a hot run
+// STARTS at multiple k (workgroup 0 stays to write the table header).  A starting workgroup then
+//   1. reads the ids at all multiples (a few KB): its slot is its rank among the starting
+//      multiples -- nothing is zeroed or allocated atomically, the table does not depend on
+//      scheduling -- and the run's last multiple follows from the same array;
+//   2. finds the nz-blocks that lie inside the run: the first one starts in the stride before
+//      multiple k, the last one ends in the stride after the run's last multiple -- stride /
+//      block_len candidates each, probed in one step;
+//   3. walks the sample ids of those blocks once and records, for every LDS fill of
+//      HotRowChunkSumKernel (samples [f * samples_per_fill, (f + 1) * samples_per_fill)), where the
+//      fill's lookups begin: ids ascend inside a run, so that is where sid / samples_per_fill
+//      changes.  bounds[slot * (num_fills + 1) + f] = first position of fill f (.. + num_fills = end).
 // ---------------------------------------------------------------------------------------------
-
-//! Smallest p in [lo, hi) with pred(p), else hi; pred is monotone (false ... false true ... true).
-//! Cooperative over the workgroup's kHotDetectThreads threads; contains barriers.
-template <typename Pred>
-__device__ __forceinline__ int CoopFirstTrue(int lo, int hi, int* scratch, Pred pred) {
-  // invariant: pred is false below lo; hi is the end of the range or a position known to satisfy pred
-  const int tid = threadIdx.x;
-  while (true) {
-    const int n = hi - lo;
-    if (n <= 0) return hi;
-    const int step = (n + kHotDetectThreads - 1) / kHotDetectThreads;
-    const int p = lo + tid * step;
-    if (tid == 0) *scratch = kHotDetectThreads;
-    __syncthreads();
-    if (p < hi && pred(p)) atomicMin(scratch, tid);
-    __syncthreads();
-    const int f = *scratch;  // first probe that is true, kHotDetectThreads if none
-    __syncthreads();
-    const int probes = (n - 1) / step + 1;  // probes that lie below hi
-    const int last_false = (f < kHotDetectThreads ? f : probes) - 1;
-    if (f < kHotDetectThreads) hi = lo + f * step;
-    if (last_false >= 0) lo = lo + last_false * step + 1;
-    if (step == 1) return hi;  // every position of the range was probed
-  }
-}
-
 template <typename IndexT>
 __global__ void __launch_bounds__(kHotDetectThreads)
-HotRunDetectKernel(const IndexT* __restrict__ rows, const int nnz, const int stride, const int block_len,
-                   HotRunTable* __restrict__ table) {
+HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ sample_ids, const int nnz,
+                   const int stride, const int block_len, const int samples_per_fill, const int num_fills,
+                   HotRunTable* __restrict__ table, int* __restrict__ bounds) {
   __shared__ int mult[kHotMaxMultiples + 1];
-  __shared__ int scratch;
   __shared__ int red[kHotDetectThreads / 64];
+  __shared__ int first_last[2];
   const int tid = threadIdx.x;
   const int k = blockIdx.x;
   const int num_mult = (nnz - 1) / stride + 1;  // multiples k * stride < nnz
+  {
+    const int v = static_cast<int>(rows[static_cast<int64_t>(k) * stride]);
+    const bool same_next = k + 1 < num_mult && static_cast<int>(rows[static_cast<int64_t>(k + 1) * stride]) == v;
+    const bool same_prev = k > 0 && static_cast<int>(rows[static_cast<int64_t>(k - 1) * stride]) == v;
+    if (k != 0 && !(same_next && !same_prev)) return;
+  }
   for (int j = tid; j < num_mult; j += kHotDetectThreads)
     mult[j] = static_cast<int>(rows[static_cast<int64_t>(j) * stride]);
   __syncthreads();
@@ -141,8 +132,8 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const int nnz, const int str
       table->count = total < kHotMaxRuns ? total : kHotMaxRuns;
       table->block_len = block_len;
     }
+    if (!is_start(0)) return;
   }
-  if (!is_start(k)) return;
   int c = 0;
   for (int j = tid; j < k; j += kHotDetectThreads) c += is_start(j) ? 1 : 0;
   const int slot = block_sum(c);
@@ -163,23 +154,78 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const int nnz, const int str
   int m = k;
 #pragma unroll
   for (int w = 0; w < kHotDetectThreads / 64; ++w) m = red[w] > m ? red[w] : m;
-  // first lookup of the run: in ((k - 1) * stride, k * stride]; first lookup after it: in
-  // (m * stride, (m + 1) * stride] (or the end of the arrays)
-  const int lo_b = k == 0 ? 0 : (k - 1) * stride + 1;
-  const int begin = CoopFirstTrue(lo_b, k * stride, &scratch,
-                                  [&](int p) { return static_cast<int>(rows[p]) == v; });
-  const int64_t next_mult = static_cast<int64_t>(m + 1) * stride;
-  const int hi_e = next_mult < nnz ? static_cast<int>(next_mult) : nnz;
-  const int end = CoopFirstTrue(m * stride + 1, hi_e, &scratch,
-                                [&](int p) { return static_cast<int>(rows[p]) != v; });
+  if (tid == 0) {
+    first_last[0] = k * (stride / block_len);  // the block that starts AT multiple k is inside the run ...
+    first_last[1] = m * (stride / block_len);  // ... and so is the one that ends just before multiple m
+  }
+  __syncthreads();
+  // nz-block j covers [j * block_len, (j + 1) * block_len); it lies inside the run when it starts
+  // and ends on v.  Blocks between multiples k and m do; the candidates are the blocks of the
+  // stride before multiple k and of the stride after multiple m.
+  const int ratio = stride / block_len;
+  for (int i = tid; i < ratio; i += kHotDetectThreads) {
+    if (k > 0) {
+      const int j = (k - 1) * ratio + 1 + i;                     // starts in ((k-1) stride, k stride]
+      if (static_cast<int>(rows[static_cast<int64_t>(j) * block_len]) == v) atomicMin(&first_last[0], j);
+    }
+    const int64_t j = static_cast<int64_t>(m) * ratio + i;       // ends in (m stride, (m+1) stride]
+    const int64_t last = (j + 1) * block_len - 1;
+    if (last < nnz && static_cast<int>(rows[last]) == v) atomicMax(&first_last[1], static_cast<int>(j + 1));
+  }
+  __syncthreads();
+  const int first_block = first_last[0];
+  const int end_block = first_last[1] > first_block ? first_last[1] : first_block;
   if (tid == 0) {
     HotRun r;
     r.row = v;
-    r.begin = begin;
-    r.first_block = (begin + block_len - 1) / block_len;
-    r.end_block = end / block_len;
-    if (r.end_block < r.first_block) r.end_block = r.first_block;
+    r.begin = first_block * block_len;  // some lookup of the run; its first one when that sits in a skipped block
+    r.first_block = first_block;
+    r.end_block = end_block;
     table->run[slot] = r;
+  }
+  // where every LDS fill's samples begin inside [lo, hi)
+  const int lo = first_block * block_len, hi = end_block * block_len;
+  int* my_bounds = bounds + static_cast<size_t>(slot) * (num_fills + 1);
+  if (hi <= lo) {
+    for (int f = tid; f <= num_fills; f += kHotDetectThreads) my_bounds[f] = lo;
+    return;
+  }
+  for (int p = lo + tid; p < hi; p += kHotDetectThreads) {
+    const int f1 = static_cast<int>(static_cast<int64_t>(sample_ids[p]) / samples_per_fill);
+    const int f0 = p == lo ? -1 : static_cast<int>(static_cast<int64_t>(sample_ids[p - 1]) / samples_per_fill);
+    for (int f = f0 + 1; f <= f1; ++f) my_bounds[f] = p;
+    if (p == hi - 1)
+      for (int f = f1 + 1; f <= num_fills; ++f) my_bounds[f] = hi;
+  }
+}
+
+//! acc[e] += float(row.v[e]) [* wf] -- one IEEE fp32 add (and one multiply) per element, as
+//! everywhere in this library.  For fp16 rows the conversion, the multiply and the add are ONE
+//! v_fma_mix_f32 per element instead of v_cvt + (v_mul +) v_add: the product of two fp16 values
+//! is exact in fp32 (22 significand bits), so the fused form rounds exactly once, to the same
+//! value as the separate operations.  The chunk kernel is bound by VALU issue, not by LDS.
+template <typename GradT, int N, bool kWeighted>
+__device__ __forceinline__ void AccumulateRow(float (&acc)[N], const Pack<GradT, N>& row, const float wf) {
+  using A = Arith<float>;
+  if constexpr (std::is_same<GradT, _Float16>::value) {
+    static_assert(N % 2 == 0, "fp16 rows move in multiples of 4 bytes");
+    const unsigned* pair = reinterpret_cast<const unsigned*>(&row);
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+      if constexpr (kWeighted) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[e]) : "v"(pair[e / 2]), "v"(wf));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[e + 1]) : "v"(pair[e / 2]), "v"(wf));
+      } else {
+        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(acc[e]) : "v"(pair[e / 2]));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[e + 1]) : "v"(pair[e / 2]));
+      }
+    }
+  } else if constexpr (kWeighted) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(row.v[e]), wf));
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(row.v[e]));
   }
 }
 
@@ -192,15 +238,14 @@ template <typename GradT, typename IndexT, int N, bool kWeighted>
 __global__ void __launch_bounds__(kHotThreads)
 HotRowChunkSumKernel(const GradT* __restrict__ grad_y, const int width, const int num_samples,
                      const IndexT* __restrict__ sample_ids, const GradT* __restrict__ weights,
-                     const HotRunTable* __restrict__ table, float* __restrict__ partial,
-                     const int samples_per_fill, const int fills_per_chunk, const int lanes_per_row) {
+                     const HotRunTable* __restrict__ table, const int* __restrict__ bounds,
+                     float* __restrict__ partial, const int samples_per_fill, const int fills_per_chunk,
+                     const int num_fills, const int lanes_per_row) {
   using A = Arith<float>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  GradT* staged = reinterpret_cast<GradT*>(lds_raw);
   __shared__ int piece_lo[kHotMaxRuns * kHotPieces];   // per item: lookups [lo, hi) of this fill
   __shared__ int piece_hi[kHotMaxRuns * kHotPieces];
   __shared__ int order[kHotMaxRuns * kHotPieces];      // items by decreasing length
-  __shared__ int bound[kHotMaxRuns][2];
   __shared__ HotRun run[kHotMaxRuns];
   __shared__ int next_item;
   const int tid = threadIdx.x;
@@ -213,46 +258,37 @@ HotRowChunkSumKernel(const GradT* __restrict__ grad_y, const int width, const in
   const int groups = 64 / lanes_per_row;   // lookups a wavefront handles at a time
   const int g = lane / lanes_per_row;      // this lane's sub-group and position in the row
   const int l = lane - g * lanes_per_row;
+  const int row_bytes = width * static_cast<int>(sizeof(GradT));
+  const unsigned char* lane_src = lds_raw + l * N * static_cast<int>(sizeof(GradT));
+  const int items = count * kHotPieces;
   float acc[N];
 
   for (int fill = 0; fill < fills_per_chunk; ++fill) {
-    const int64_t s0 = static_cast<int64_t>(blockIdx.x) * samples_per_chunk + static_cast<int64_t>(fill) * samples_per_fill;
+    const int f = blockIdx.x * fills_per_chunk + fill;
+    const int64_t s0 = static_cast<int64_t>(f) * samples_per_fill;
     if (s0 >= num_samples) break;
     const int64_t s1 = s0 + samples_per_fill < num_samples ? s0 + samples_per_fill : num_samples;
     __syncthreads();  // the previous fill's rows and item lists are no longer in use (and run[] is visible)
-    {  // ---- the chunk's grad_y rows: one contiguous range, 16 bytes per lane ----
-      typedef unsigned __attribute__((ext_vector_type(4))) raw16_t;
-      const raw16_t* src = reinterpret_cast<const raw16_t*>(grad_y + s0 * width);
-      raw16_t* dst = reinterpret_cast<raw16_t*>(staged);
-      const int64_t n16 = (s1 - s0) * width * static_cast<int64_t>(sizeof(GradT)) / 16;
-      for (int64_t i = tid; i < n16; i += kHotThreads) dst[i] = __builtin_nontemporal_load(src + i);
-    }
-    // ---- where the chunk's samples sit inside every hot run (ids ascend inside a run) ----
-    if (tid < 2 * count) {
-      const HotRun r = run[tid >> 1];
-      const int64_t target = (tid & 1) ? s1 : s0;
-      int lo = r.first_block * block_len, hi = r.end_block * block_len;
-      while (lo < hi) {
-        const int mid = lo + ((hi - lo) >> 1);
-        if (static_cast<int64_t>(sample_ids[mid]) < target) lo = mid + 1;
-        else hi = mid;
-      }
-      bound[tid >> 1][tid & 1] = lo;
-    }
-    if (tid == 0) next_item = 0;
-    __syncthreads();
-    // ---- work items: (run, piece); longest first, taken by the wavefronts as they finish ----
-    const int items = count * kHotPieces;
+    // ---- work items of this fill: (run, piece), from the positions the detection pass recorded ----
     if (tid < items) {
       const int h = tid / kHotPieces, p = tid - h * kHotPieces;
       const int pieces = HotPiecesOf(run[h], block_len, samples_per_chunk, num_samples);
-      const int lo = bound[h][0], hi = bound[h][1];
+      const int* b = bounds + static_cast<size_t>(h) * (num_fills + 1) + f;
+      const int lo = b[0], hi = b[1];
       const int cut = pieces == 2 ? lo + ((hi - lo + 1) >> 1) : hi;
       piece_lo[tid] = p == 0 ? lo : cut;
       piece_hi[tid] = p == 0 ? cut : (pieces == 2 ? hi : cut);   // an unused second piece is empty
     }
+    if (tid == 0) next_item = 0;
+    {  // ---- the fill's grad_y rows: one contiguous range, 16 bytes per lane ----
+      typedef unsigned __attribute__((ext_vector_type(4))) raw16_t;
+      const raw16_t* src = reinterpret_cast<const raw16_t*>(grad_y + s0 * width);
+      raw16_t* dst = reinterpret_cast<raw16_t*>(lds_raw);
+      const int64_t n16 = (s1 - s0) * width * static_cast<int64_t>(sizeof(GradT)) / 16;
+      for (int64_t i = tid; i < n16; i += kHotThreads) dst[i] = __builtin_nontemporal_load(src + i);
+    }
     __syncthreads();
-    if (tid < items) {
+    if (tid < items) {  // longest first, taken by the wavefronts as they finish
       const int len = piece_hi[tid] - piece_lo[tid];
       int rank = 0;
       for (int u = 0; u < items; ++u) {
@@ -275,31 +311,47 @@ HotRowChunkSumKernel(const GradT* __restrict__ grad_y, const int width, const in
 #pragma unroll
       for (int e = 0; e < N; ++e) acc[e] = 0.f;
       for (int base = a; base < b; base += 64) {
+        // 64 lookups per round: every lane fetches one (sample offset, weight) pair, coalesced;
+        // the sub-groups then take them `groups` at a time through cross-lane reads
         const int pos = base + lane;
-        int sid_l = 0;
-        GradT w_l = static_cast<GradT>(0);
+        int off_l = 0;
+        float wf_l = 0.f;
         if (pos < b) {
-          sid_l = static_cast<int>(static_cast<int64_t>(sample_ids[pos]) - s0);
-          if constexpr (kWeighted) w_l = weights[pos];
+          off_l = static_cast<int>(static_cast<int64_t>(sample_ids[pos]) - s0) * row_bytes;
+          if constexpr (kWeighted) wf_l = static_cast<float>(weights[pos]);
         }
         const int cnt = b - base < 64 ? b - base : 64;
-#pragma unroll 4
-        for (int u = 0; u < cnt; u += groups) {
+        const int full = cnt / groups * groups;  // steps in which every sub-group has a lookup
+        int u = 0;
+        // kHotBatch steps at a time: all cross-lane reads, then all LDS row reads, then the adds --
+        // so that a wavefront has several LDS reads in flight instead of one dependent chain per step
+        for (; u + kHotBatch * groups <= full; u += kHotBatch * groups) {
+          int off[kHotBatch];
+          float wf[kHotBatch];
+          Pack<GradT, N> row[kHotBatch];
+#pragma unroll
+          for (int t = 0; t < kHotBatch; ++t) {
+            off[t] = __shfl(off_l, u + t * groups + g);
+            wf[t] = kWeighted ? __shfl(wf_l, u + t * groups + g) : 1.f;
+          }
+#pragma unroll
+          for (int t = 0; t < kHotBatch; ++t) row[t] = *reinterpret_cast<const Pack<GradT, N>*>(lane_src + off[t]);
+#pragma unroll
+          for (int t = 0; t < kHotBatch; ++t) AccumulateRow<GradT, N, kWeighted>(acc, row[t], wf[t]);
+        }
+        for (; u < full; u += groups) {
+          const int off = __shfl(off_l, u + g);
+          const float wf = kWeighted ? __shfl(wf_l, u + g) : 1.f;
+          const Pack<GradT, N> row = *reinterpret_cast<const Pack<GradT, N>*>(lane_src + off);
+          AccumulateRow<GradT, N, kWeighted>(acc, row, wf);
+        }
+        if (u < cnt) {
           const int j = u + g;
-          const int sid = __shfl(sid_l, j < 64 ? j : 63);
-          const Pack<GradT, N> row = *reinterpret_cast<const Pack<GradT, N>*>(
-              staged + static_cast<size_t>(sid) * width + l * N);
-          if constexpr (kWeighted) {
-            const float wf = static_cast<float>(ShuffleElem(w_l, j < 64 ? j : 63, 64));
-            if (j < cnt) {
-#pragma unroll
-              for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(row.v[e]), wf));
-            }
-          } else {
-            if (j < cnt) {
-#pragma unroll
-              for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(row.v[e]));
-            }
+          const int off = __shfl(off_l, j < 64 ? j : 63);
+          const float wf = kWeighted ? __shfl(wf_l, j < 64 ? j : 63) : 1.f;
+          if (j < cnt) {
+            const Pack<GradT, N> row = *reinterpret_cast<const Pack<GradT, N>*>(lane_src + off);
+            AccumulateRow<GradT, N, kWeighted>(acc, row, wf);
           }
         }
       }

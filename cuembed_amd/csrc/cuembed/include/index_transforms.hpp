@@ -154,6 +154,58 @@ void Transpose(const IndexT* rows,
 }
 
 /**
+ * @brief Transpose() of a FIXED-HOTNESS batch without materialising the sample ids (extension):
+ * the same result as ExtractRowIdsFromFixed(batch_size, num_hots, row_ids) followed by
+ * Transpose(row_ids, indices, weights, batch_size * num_hots, ...), but the first radix pass
+ * derives the sample id of lookup i as i / num_hots instead of reading an array that a kernel
+ * would have had to write first (16.8 MB written and read back at the north-star shape, and one
+ * launch).  num_hots = 1 gives the concat layout (ExtractRowIdsForConcat: row id = position).
+ * Two-phase workspace query and `index_bits` as for Transpose().
+ */
+template <typename IndexT, typename WeightT>
+void TransposeFixedHotness(const IndexT* indices,
+                           const WeightT* weights,
+                           const int batch_size,
+                           const int num_hots,
+                           IndexT* transpose_indices,
+                           IndexT* transpose_sample_ids,
+                           WeightT* transpose_weights,
+                           char* work,
+                           size_t* lwork,
+                           const hipStream_t stream = 0,
+                           const int index_bits = static_cast<int>(sizeof(IndexT) * 8)) {
+  using KeyT = typename std::make_unsigned<IndexT>::type;
+  const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
+                           ? index_bits
+                           : static_cast<int>(sizeof(IndexT) * 8);
+  const int64_t nnz = static_cast<int64_t>(batch_size) * num_hots;
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
+  const KeyT* keys_in = reinterpret_cast<const KeyT*>(indices);
+  KeyT* keys_out = reinterpret_cast<KeyT*>(transpose_indices);
+  if (weights == nullptr) {
+    const detail::RadixSortPlan<KeyT, IndexT, detail::NoPayload> plan(n, key_bits);
+    if (work == nullptr) {
+      *lwork = plan.total;
+      return;
+    }
+    assert(*lwork >= plan.total && num_hots > 0 && nnz <= INT32_MAX);
+    detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
+        keys_in, keys_out, nullptr, transpose_sample_ids, nullptr, nullptr, n, key_bits, work, stream,
+        /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots);
+    return;
+  }
+  const detail::RadixSortPlan<KeyT, IndexT, WeightT> plan(n, key_bits);
+  if (work == nullptr) {
+    *lwork = plan.total;
+    return;
+  }
+  assert(*lwork >= plan.total && num_hots > 0 && nnz <= INT32_MAX);
+  detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, nullptr, transpose_sample_ids, weights,
+                                                transpose_weights, n, key_bits, work, stream,
+                                                /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots);
+}
+
+/**
  * @brief Map sorted lookup indices to dense ids 0..num_unique-1:
  * indices = [4, 4, 7, 8, 8, 8, 18] -> remapped_indices = [0, 0, 1, 2, 2, 2, 3].
  * (num_unique = remapped_indices[nnz - 1] + 1, read back by the caller.)

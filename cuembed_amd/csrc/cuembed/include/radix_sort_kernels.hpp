@@ -109,7 +109,29 @@ struct SortMode {
   int narrow_v1;     //!< NarrowKeys: 64-bit first payload stored as 32 bits (IfConstantHigh: if all values < 2^32)
   int use_varying;   //!< passes whose digit is the same for every key are skipped on the device
   int sign_pass;     //!< pass whose digit holds the sign bit of the keys, or -1
+  // Implicit first payload: v1_div > 0 means "the first payload of input element i is i / v1_div"
+  // (the sample id of lookup i of a fixed-hotness batch) -- pass 0 computes it instead of loading an
+  // array that somebody would have had to write first.  i / d = (i * magic) >> shift for i < 2^31.
+  int v1_div;
+  unsigned v1_magic;
+  int v1_shift;
 };
+
+//! magic / shift with (uint64(i) * magic) >> shift == i / d for every 0 <= i < 2^31, d >= 1:
+//! s = ceil(log2 d), magic = ceil(2^(31+s) / d) < 2^32; the error term i * e / (d * 2^(31+s)) with
+//! e < d <= 2^s stays below 1 / d.
+inline void ImplicitPayloadDivisor(const int d, SortMode* mode) {
+  int s = 0;
+  while ((int64_t{1} << s) < d) ++s;
+  const unsigned __int128 one = static_cast<unsigned __int128>(1) << (31 + s);
+  mode->v1_div = d;
+  mode->v1_magic = static_cast<unsigned>((one + d - 1) / d);
+  mode->v1_shift = 31 + s;
+}
+
+__device__ __forceinline__ unsigned ImplicitPayload(const SortMode& mode, const int64_t i) {
+  return static_cast<unsigned>((static_cast<unsigned long long>(static_cast<unsigned>(i)) * mode.v1_magic) >> mode.v1_shift);
+}
 
 __device__ __forceinline__ unsigned SignFlip(const SortMode& mode, const int pass) {
   return pass == mode.sign_pass ? 0x80u : 0u;
@@ -537,7 +559,10 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   // i.e. a second round for a quarter of the 1024 tiles); it is loaded after the keys have left.
   constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
   V1 item1[kSortItems];
-  if constexpr (kEarlyV1) LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
+  const bool implicit_v1 = kHasV1 && plan.first && mode.v1_div > 0;
+  if constexpr (kEarlyV1) {
+    if (!implicit_v1) LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
+  }
   unsigned slot[kSortItems];  // tile-local position in digit order
   RankTile<KeyT>(key, shift, flip, wave * (64 * kSortItems) + lane, count, wave_count, tile_start, slot);
 
@@ -560,7 +585,15 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   }
   // ---- payloads take the same route ----
   if constexpr (kHasV1) {
-    if constexpr (!kEarlyV1) LoadRouted<V1>(v1, v1_route.src, narrow_v1, n, wave_base + lane, 64, V1(0), item1);
+    if (implicit_v1) {
+      if constexpr (!std::is_same<V1, NoPayload>::value) {
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r)
+          item1[r] = static_cast<V1>(ImplicitPayload(mode, wave_base + lane + r * 64));
+      }
+    } else {
+      if constexpr (!kEarlyV1) LoadRouted<V1>(v1, v1_route.src, narrow_v1, n, wave_base + lane, 64, V1(0), item1);
+    }
     StageAndStore<V1>(stage, item1, slot, dest, count, v1, v1_route.dst, narrow_v1, n);
   }
   if constexpr (kHasV2) {
@@ -594,7 +627,7 @@ __global__ void __launch_bounds__(kSortThreads)
 SingleTileSortKernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_out,
                      const V1* __restrict__ v1_in, V1* __restrict__ v1_out,
                      const V2* __restrict__ v2_in, V2* __restrict__ v2_out, const int n, const int passes,
-                     const int sign_pass) {
+                     const int sign_pass, const int v1_div) {
   constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
   constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
   constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
@@ -616,7 +649,7 @@ SingleTileSortKernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_o
     key[r] = KeyT(0);
     if (i < n) {
       key[r] = keys_in[i];
-      if constexpr (kHasV1) item1[r] = v1_in[i];
+      if constexpr (kHasV1) item1[r] = v1_div > 0 ? static_cast<V1>(i / v1_div) : v1_in[i];
       if constexpr (kHasV2) item2[r] = v2_in[i];
       any |= static_cast<unsigned long long>(key[r]);
       all &= static_cast<unsigned long long>(key[r]);
@@ -703,17 +736,18 @@ struct RadixSortPlan {
 //!   v1_bits    : a 64-bit v1 whose values are known to lie in [0, 2^v1_bits), v1_bits <= 32, is
 //!                kept as 32 bits between passes without looking; 0 = unknown, decided on the
 //!                device from the values themselves (pass 0 reads them once more for that).
+//!   v1_div     : > 0: v1_in is not read; the first payload of element i is i / v1_div.
 template <typename KeyT, typename V1, typename V2>
 inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in, V1* v1_out,
                            const V2* v2_in, V2* v2_out, const size_t n, const int key_bits,
                            char* work, hipStream_t stream, const bool signed_keys = false,
-                           const int v1_bits = 0) {
+                           const int v1_bits = 0, const int v1_div = 0) {
   if (n == 0) return;
   const RadixSortPlan<KeyT, V1, V2> plan(n, key_bits);
   const int sign_pass = (signed_keys && key_bits >= static_cast<int>(8 * sizeof(KeyT))) ? plan.passes - 1 : -1;
   if (n <= static_cast<size_t>(kSortTile)) {
     SingleTileSortKernel<KeyT, V1, V2><<<1, kSortThreads, 0, stream>>>(
-        keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes, sign_pass);
+        keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes, sign_pass, v1_div);
     return;
   }
   const SortArray<KeyT> keys{keys_in, keys_out, reinterpret_cast<KeyT*>(work + plan.keys_tmp)};
@@ -722,7 +756,8 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   unsigned* tile_hist = reinterpret_cast<unsigned*>(work + plan.tile_hist);
   unsigned* bin_total = reinterpret_cast<unsigned*>(work + plan.bin_total);
   constexpr bool kWideV1 = !std::is_same<V1, NoPayload>::value && sizeof(V1) == 8;
-  SortMode mode;
+  SortMode mode{};
+  if (v1_div > 0) ImplicitPayloadDivisor(v1_div, &mode);
   mode.use_varying = plan.passes > kStaticRoutePasses;
   mode.sign_pass = sign_pass;
   mode.narrow_keys = kNarrowNever;
@@ -731,7 +766,7 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     else if (mode.use_varying) mode.narrow_keys = kNarrowIfConstantHigh;  // decided from the keys themselves
   }
   mode.narrow_v1 = !kWideV1 ? kNarrowNever
-                            : (v1_bits > 0 && v1_bits <= 32 ? kNarrowAlways : kNarrowIfConstantHigh);
+                            : ((v1_bits > 0 && v1_bits <= 32) || v1_div > 0 ? kNarrowAlways : kNarrowIfConstantHigh);
   const bool device_state = mode.use_varying || mode.narrow_v1 == kNarrowIfConstantHigh;
   unsigned long long* tile_bits =
       device_state ? reinterpret_cast<unsigned long long*>(work + plan.tile_bits) : nullptr;

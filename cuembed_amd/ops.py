@@ -325,6 +325,41 @@ def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num
     return t_rows, t_cols, t_w
 
 
+def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspace=None, num_categories=None):
+    """extract_row_ids_from_fixed + transpose in one call without materialising the sample ids
+    (cuembed::TransposeFixedHotness, extension): returns (sorted indices, sample ids, weights).
+    num_hots=1 is the concat layout."""
+    _check_dev("indices", indices)
+    dev = indices.device
+    it = _index_code("indices", indices)
+    nnz = batch_size * num_hots
+    if num_hots <= 0 or indices.numel() < nnz:
+        raise ValueError("indices must hold batch_size * num_hots entries, num_hots > 0")
+    wt = 0
+    t_w = None
+    if weights is not None:
+        _check_dev("weights", weights, dev)
+        wt = _elem_code("weights", weights)
+        if weights.numel() < nnz:
+            raise ValueError("weights must have one entry per index")
+        t_w = torch.empty((nnz,), dtype=weights.dtype, device=dev)
+    t_idx = torch.empty((nnz,), dtype=indices.dtype, device=dev)
+    t_sid = torch.empty((nnz,), dtype=indices.dtype, device=dev)
+    need = transpose_workspace_bytes(nnz, indices.dtype, None if weights is None else weights.dtype)
+    if workspace is None:
+        workspace = torch.empty((max(need, 1),), dtype=torch.uint8, device=dev)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("workspace too small: need %d bytes" % need)
+    lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
+    bits = 0 if not num_categories else max(1, int(num_categories - 1).bit_length())
+    if nnz > 0:
+        with torch.cuda.device(dev):
+            _lib.lib().cuembed_transpose_fixed_hotness(_ptr(indices), _ptr(weights), batch_size, num_hots, it, wt,
+                                                       _ptr(t_idx), _ptr(t_sid), _ptr(t_w), _ptr(workspace),
+                                                       ctypes.byref(lwork), bits, _stream(indices))
+    return t_idx, t_sid, t_w
+
+
 def compressed_grad_workspace_bytes(nnz, index_dtype):
     lwork = ctypes.c_size_t(0)
     _lib.lib().cuembed_compute_compressed_grad_indices(None, nnz, _INDEX[index_dtype], None, None,

@@ -222,6 +222,15 @@ void cuembed_transpose_hinted(const void* rows, const void* cols, const void* we
                               int index_type, int weight_type, void* transpose_rows,
                               void* transpose_cols, void* transpose_weights, char* work,
                               size_t* lwork, int index_bits, int row_bits, cuembed_stream_t stream);
+/* Extension (cuembed::TransposeFixedHotness): cuembed_extract_row_ids_from_fixed +
+ * cuembed_transpose_bounded in one call, without materialising the sample ids -- the first radix
+ * pass derives the sample id of lookup i as i / num_hots.  Same outputs.  num_hots = 1 is the
+ * concat layout (row id = position).  index_bits <= 0: all bits. */
+void cuembed_transpose_fixed_hotness(const void* indices, const void* weights, int batch_size,
+                                     int num_hots, int index_type, int weight_type,
+                                     void* transpose_indices, void* transpose_sample_ids,
+                                     void* transpose_weights, char* work, size_t* lwork, int index_bits,
+                                     cuembed_stream_t stream);
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream);

@@ -64,6 +64,12 @@ def main():
                                   "hot_lookups": int((~keep).sum()),
                                   "hot_lookup_fraction": round(float((~keep).float().mean()), 4),
                                   "backward_ms_without_hot_runs": round(ms, 5)})
+    out["plain_by_column_slices"] = []
+    for sl in (1, 2, 4, 8):
+        ce.set_backward_tuning(column_slices=sl)
+        ms, _ = timed(ti, ts)
+        out["plain_by_column_slices"].append({"slices": sl, "ms": round(ms, 5)})
+    ce.set_backward_tuning()
     # the run-aware entry point itself, per detection stride
     remap = ce.compute_compressed_grad_indices(ti)
     grad = torch.empty((nu, W), dtype=torch.float16, device=dev)
