@@ -132,7 +132,38 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout)
+    build_torch_binding(force=force)
     return LIB_PATH
+
+
+TORCH_BINDING_PATH = os.path.join(LIB_DIR, "libcuembed_pyt.so")
+
+
+def build_torch_binding(force=False):
+    """Compiles cuembed_amd/csrc/torch_binding.cpp (TORCH_LIBRARY / TORCH_LIBRARY_IMPL, no device code) with
+    the host compiler against the installed torch and links it to libcuembed_amd.so.  Needs build() first."""
+    import torch
+    from torch.utils import cpp_extension
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    stamp = os.path.join(LIB_DIR, "libcuembed_pyt.stamp")
+    digest = _digest_files([src, os.path.join(ROOT, "include", "cuembed_amd.h")], torch.__version__)
+    if not force and os.path.exists(TORCH_BINDING_PATH) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return TORCH_BINDING_PATH
+    torch_lib = cpp_extension.library_paths()[0]
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",      # what torch's own headers key on under ROCm
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in cpp_extension.include_paths()] + ["-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include")]
+    cmd += [src, "-o", TORCH_BINDING_PATH, "-L" + torch_lib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+            "-ltorch_hip", "-L" + LIB_DIR, "-lcuembed_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed for the torch binding:\n" + r.stdout)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return TORCH_BINDING_PATH
 
 
 def build_header_api_test(force=False):

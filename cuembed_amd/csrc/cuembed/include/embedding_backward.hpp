@@ -175,9 +175,12 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
     int* bounds = reinterpret_cast<int*>(work + hot.table_bytes);
     partial = reinterpret_cast<float*>(work + hot.table_bytes + hot.bounds_bytes);
     const int multiples = static_cast<int>((nnz - 1) / hot.stride + 1);
+    unsigned fill_magic;
+    int fill_shift;
+    HotFillDivisor(hot.samples_per_fill, &fill_magic, &fill_shift);
     HotRunDetectKernel<IndexT><<<multiples, kHotDetectThreads, 0, stream>>>(
-        rows, sample_ids, static_cast<int>(nnz), hot.stride, block_len, hot.samples_per_fill, hot.num_fills(),
-        table, bounds);
+        rows, sample_ids, static_cast<int>(nnz), hot.stride, block_len, hot.samples_per_fill, fill_magic, fill_shift,
+        hot.num_fills(), table, bounds);
     auto chunk_kernel = weights != nullptr ? HotRowChunkSumKernel<GradT, IndexT, N, true>
                                            : HotRowChunkSumKernel<GradT, IndexT, N, false>;
     static const bool lds_ok = [&] {  // > 64 KiB of dynamic LDS has to be asked for, once per kernel

@@ -43,7 +43,7 @@ constexpr int kHotChunkBytes = 128 * 1024; //!< grad_y bytes staged in LDS per w
 constexpr int kHotThreads = 1024;
 constexpr int kHotWaves = kHotThreads / 64;
 constexpr int kHotMaxChunks = 1024;        //!< bounds the workspace; more samples -> several chunks per workgroup
-constexpr int kHotDetectThreads = 256;
+constexpr int kHotDetectThreads = 1024;    //!< only the few workgroups that find a hot run use them all
 constexpr int kHotBatch = 8;               //!< LDS row reads a wavefront keeps in flight
 
 struct HotRun {
@@ -64,6 +64,16 @@ inline int HotStride(const int64_t nnz) {
   int64_t s = kHotMinStride;
   while ((nnz + s - 1) / s > kHotMaxMultiples) s *= 2;
   return static_cast<int>(s);
+}
+
+//! magic / shift with (uint64(i) * magic) >> shift == i / d for 0 <= i < 2^31, d >= 1
+//! (s = ceil(log2 d), magic = ceil(2^(31+s) / d) < 2^32; the error stays below 1 / d).
+inline void HotFillDivisor(const int d, unsigned* magic, int* shift) {
+  int s = 0;
+  while ((int64_t{1} << s) < d) ++s;
+  const unsigned __int128 one = static_cast<unsigned __int128>(1) << (31 + s);
+  *magic = static_cast<unsigned>((one + d - 1) / d);
+  *shift = 31 + s;
 }
 
 //! Pieces a hot run's per-chunk work is cut into: a pure function of the table entry, so that
@@ -93,8 +103,9 @@ __host__ __device__ inline int HotPiecesOf(const HotRun& r, const int block_len,
 template <typename IndexT>
 __global__ void __launch_bounds__(kHotDetectThreads)
 HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ sample_ids, const int nnz,
-                   const int stride, const int block_len, const int samples_per_fill, const int num_fills,
-                   HotRunTable* __restrict__ table, int* __restrict__ bounds) {
+                   const int stride, const int block_len, const int samples_per_fill, const unsigned fill_magic,
+                   const int fill_shift, const int num_fills, HotRunTable* __restrict__ table,
+                   int* __restrict__ bounds) {
   __shared__ int mult[kHotMaxMultiples + 1];
   __shared__ int red[kHotDetectThreads / 64];
   __shared__ int first_last[2];
@@ -190,9 +201,14 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ s
     for (int f = tid; f <= num_fills; f += kHotDetectThreads) my_bounds[f] = lo;
     return;
   }
+  // sid / samples_per_fill as a multiply-shift (sample ids are below 2^31): see HotFillDivisor
+  auto fill_of = [&](const IndexT sid) {
+    return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(sid)) * fill_magic) >> fill_shift);
+  };
+  (void)samples_per_fill;
   for (int p = lo + tid; p < hi; p += kHotDetectThreads) {
-    const int f1 = static_cast<int>(static_cast<int64_t>(sample_ids[p]) / samples_per_fill);
-    const int f0 = p == lo ? -1 : static_cast<int>(static_cast<int64_t>(sample_ids[p - 1]) / samples_per_fill);
+    const int f1 = fill_of(sample_ids[p]);
+    const int f0 = p == lo ? -1 : fill_of(sample_ids[p - 1]);
     for (int f = f0 + 1; f <= f1; ++f) my_bounds[f] = p;
     if (p == hi - 1)
       for (int f = f1 + 1; f <= num_fills; ++f) my_bounds[f] = hi;

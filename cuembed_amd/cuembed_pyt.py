@@ -7,36 +7,84 @@ examples/pytorch/cuembed_pyt.py:48-51:
     from cuembed_amd.cuembed_pyt import cuemb_embedding
     out = cuemb_embedding(weight, indices, offsets, per_sample_weights)   # like nn.EmbeddingBag(sum)
 
-The ops run the HIP kernels through the C ABI on torch's current stream.  Relative to the
-reference binding (fp32 / int64 / sum only, cuembed_embedding.cu:15-32) they also accept fp16
-tables, int32 indices/offsets and mode="mean" in the forward op.
+The ops live in a native extension, cuembed_amd/lib/libcuembed_pyt.so (TORCH_LIBRARY +
+TORCH_LIBRARY_IMPL in cuembed_amd/csrc/torch_binding.cpp, built by cuembed_amd/build.py), loaded
+here with torch.ops.load_library exactly like the reference loads its own (cuembed_pyt.py:8-10).
+They run the HIP kernels on torch's current stream.  Relative to the reference binding (fp32 /
+int64 / sum only, cuembed_embedding.cu:15-32) they also accept fp16 / bf16 tables, int32 indices
+and offsets and mode="mean".
+
+CUEMBED_PYT_BACKEND=python registers the same ops from Python instead (torch.library + ctypes
+calls into the same HIP library): kept for A/B timing of the binding overhead
+(tools/torch_op_step_probe.py), not a fallback -- a missing native library is an error.
 """
+import os
+
 import torch
 
 from . import ops as _ops
 
-_lib = torch.library.Library("cuembed_pyt", "DEF")
-_lib.define("cuembed_extract_row_ids_from_csr(Tensor offsets, int nnz) ->Tensor")
-_lib.define("cuembed_transpose(Tensor rows, Tensor cols, Tensor weights) -> (Tensor, Tensor, Tensor)")
-# This library's extension: the same transpose when the caller knows indices < num_categories.
-_lib.define("cuembed_transpose_bounded(Tensor rows, Tensor cols, Tensor weights, int num_categories)"
-            " -> (Tensor, Tensor, Tensor)")
-# This library's extensions for a compressed (sparse) table gradient: only the rows that were
-# looked up are materialised (293 MB instead of a zero-filled 5.12 GB at the north-star shape).
-_lib.define("cuembed_compute_compressed_grad_indices(Tensor transpose_indices) -> Tensor")
-_lib.define("cuembed_embedding_backward_compressed(Tensor y_grad, int num_unique, Tensor transpose_indices,"
-            " Tensor transpose_sample_ids, Tensor transpose_remapped_indices, Tensor transpose_weights)"
-            " -> (Tensor, Tensor)")
-# Fixed-hotness (2-D index tensor) forward with every combine mode of the C++ API
-# (the reference binding only exposes CSR + sum, cuembed_embedding.cu:29-32).
-_lib.define("cuembed_embedding_forward_fixed(Tensor params, Tensor indices, Tensor weights, str mode)"
-            " -> Tensor")
-_lib.define("cuembed_embedding_weight_grad(Tensor params, Tensor indices, Tensor offsets, Tensor y_grad)"
-            " -> Tensor")
-_lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor offsets, Tensor weights,"
-            " str mode) -> Tensor")
-_lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
-            " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
+BACKEND = os.environ.get("CUEMBED_PYT_BACKEND", "native")
+NATIVE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcuembed_pyt.so")
+
+
+def _load_native():
+    from . import _lib as _clib
+    _clib.lib()                                   # libcuembed_amd.so first: fail loudly if it is absent
+    if not os.path.exists(NATIVE_LIB):
+        raise _clib.CuembedLibraryError(
+            "cuembed_amd: %s not found. Build it with `python -m cuembed_amd.build` (needs g++ and the "
+            "torch headers); there is no fallback." % NATIVE_LIB)
+    torch.ops.load_library(NATIVE_LIB)
+
+
+def _define_python_ops():
+    global _lib
+    _lib = torch.library.Library("cuembed_pyt", "DEF")
+    _lib.define("cuembed_extract_row_ids_from_csr(Tensor offsets, int nnz) ->Tensor")
+    _lib.define("cuembed_transpose(Tensor rows, Tensor cols, Tensor weights) -> (Tensor, Tensor, Tensor)")
+    _lib.define("cuembed_transpose_bounded(Tensor rows, Tensor cols, Tensor weights, int num_categories)"
+                " -> (Tensor, Tensor, Tensor)")
+    _lib.define("cuembed_transpose_sample_ids(Tensor sample_ids, Tensor indices, Tensor weights, int num_categories)"
+                " -> (Tensor, Tensor, Tensor)")
+    _lib.define("cuembed_transpose_fixed_hotness(Tensor indices, Tensor weights, int num_categories, bool compressed)"
+                " -> (Tensor, Tensor, Tensor, Tensor)")
+    _lib.define("cuembed_compute_compressed_grad_indices(Tensor transpose_indices) -> Tensor")
+    _lib.define("cuembed_embedding_backward_compressed(Tensor y_grad, int num_unique, Tensor transpose_indices,"
+                " Tensor transpose_sample_ids, Tensor transpose_remapped_indices, Tensor transpose_weights)"
+                " -> (Tensor, Tensor)")
+    _lib.define("cuembed_embedding_forward_fixed(Tensor params, Tensor indices, Tensor weights, str mode)"
+                " -> Tensor")
+    _lib.define("cuembed_embedding_weight_grad(Tensor params, Tensor indices, Tensor offsets, Tensor y_grad)"
+                " -> Tensor")
+    _lib.define("cuembed_embedding_forward(Tensor params, Tensor indices, Tensor offsets, Tensor weights,"
+                " str mode) -> Tensor")
+    _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
+                " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
+    _lib.impl("cuembed_transpose_sample_ids", _transpose_sample_ids_impl, "CUDA")
+    _lib.impl("cuembed_transpose_fixed_hotness", _transpose_fixed_impl, "CUDA")
+    _lib.impl("cuembed_embedding_weight_grad", _weight_grad_impl, "CUDA")
+    _lib.impl("cuembed_embedding_forward_fixed", _forward_fixed_impl, "CUDA")
+    _lib.impl("cuembed_compute_compressed_grad_indices", _compress_impl, "CUDA")
+    _lib.impl("cuembed_embedding_backward_compressed", _backward_compressed_impl, "CUDA")
+    _lib.impl("cuembed_embedding_forward", _forward_impl, "CUDA")
+    _lib.impl("cuembed_extract_row_ids_from_csr", _extract_impl, "CUDA")
+    _lib.impl("cuembed_transpose", _transpose_impl, "CUDA")
+    _lib.impl("cuembed_transpose_bounded", _transpose_bounded_impl, "CUDA")
+    _lib.impl("cuembed_embedding_backward", _backward_impl, "CUDA")
+
+
+# Extension ops beyond the reference's four (same list in torch_binding.cpp):
+#   cuembed_transpose_bounded / _sample_ids   the transpose when the caller knows indices < num_categories
+#                                             (and that `rows` are sample ids)
+#   cuembed_transpose_fixed_hotness           row ids + transpose (+ dense ids) of a [batch, hotness] index
+#                                             tensor in one call, sample ids never materialised
+#   cuembed_compute_compressed_grad_indices,  compressed (sparse) table gradient: only the rows that were looked
+#   cuembed_embedding_backward_compressed     up are materialised (293 MB instead of a zero-filled 5.12 GB at
+#                                             the north-star shape)
+#   cuembed_embedding_forward_fixed           fixed-hotness forward with every combine mode of the C++ API (the
+#                                             reference binding only exposes CSR + sum, cuembed_embedding.cu:29-32)
+#   cuembed_embedding_weight_grad             gradient w.r.t. the per-lookup weights
 
 _FLOATS = (torch.float32, torch.float16, torch.bfloat16)
 _INTS = (torch.int64, torch.int32)
@@ -74,14 +122,31 @@ def _transpose_bounded_impl(rows, cols, weights, num_categories):
     return _transpose_impl(rows, cols, weights, num_categories)
 
 
-def _transpose_impl(rows, cols, weights, num_categories=None):
+def _transpose_sample_ids_impl(sample_ids, indices, weights, num_categories):
+    return _transpose_impl(sample_ids, indices, weights, num_categories, num_rows=1 << 31)
+
+
+def _transpose_fixed_impl(indices, weights, num_categories, compressed):
+    _require(indices.is_cuda and indices.dim() == 2, "indices must be [batch, hotness] on the GPU")
+    batch, hot = indices.shape
+    w = None if weights is None else weights.contiguous().view(-1)
+    t_idx, t_sid, t_w = _ops.transpose_fixed_hotness(indices.contiguous().view(-1), batch, hot, w,
+                                                     num_categories=num_categories if num_categories > 0 else None)
+    if t_w is None:
+        t_w = torch.empty(0, dtype=torch.float32, device=indices.device)
+    remap = _ops.compute_compressed_grad_indices(t_idx) if compressed else \
+        torch.empty(0, dtype=indices.dtype, device=indices.device)
+    return t_idx, t_sid, t_w, remap
+
+
+def _transpose_impl(rows, cols, weights, num_categories=None, num_rows=None):
     _require(rows.is_cuda and cols.is_cuda, "tensors must be on the GPU")
     _require(rows.dtype in _INTS and cols.dtype == rows.dtype, "rows/cols must both be int64 or int32")
     if weights is not None:
         _require(weights.dtype in _FLOATS, "weights must be float32 or float16")
         weights = weights.contiguous()
     t_rows, t_cols, t_w = _ops.transpose(rows.contiguous(), cols.contiguous(), weights,
-                                         num_categories=num_categories)
+                                         num_categories=num_categories, num_rows=num_rows)
     if t_w is None:  # the reference returns a 0-length float tensor (cuembed_embedding.cu:90-93)
         t_w = torch.empty(0, dtype=torch.float32, device=rows.device)
     return t_rows, t_cols, t_w
@@ -136,23 +201,24 @@ def _backward_compressed_impl(y_grad, num_unique, transpose_indices, transpose_s
     grad, inv = _ops.embedding_backward(y_grad.contiguous(), num_unique, transpose_indices.contiguous(),
                                         transpose_sample_ids.contiguous(),
                                         transpose_remapped_indices.contiguous(), transpose_weights,
-                                        skip_grad_init=False)
+                                        skip_grad_init=False, run_aware=True)
     return grad, inv
 
 
-_lib.impl("cuembed_embedding_weight_grad", _weight_grad_impl, "CUDA")
-_lib.impl("cuembed_embedding_forward_fixed", _forward_fixed_impl, "CUDA")
-_lib.impl("cuembed_compute_compressed_grad_indices", _compress_impl, "CUDA")
-_lib.impl("cuembed_embedding_backward_compressed", _backward_compressed_impl, "CUDA")
-_lib.impl("cuembed_embedding_forward", _forward_impl, "CUDA")
-_lib.impl("cuembed_extract_row_ids_from_csr", _extract_impl, "CUDA")
-_lib.impl("cuembed_transpose", _transpose_impl, "CUDA")
-_lib.impl("cuembed_transpose_bounded", _transpose_bounded_impl, "CUDA")
-_lib.impl("cuembed_embedding_backward", _backward_impl, "CUDA")
+
+
+if BACKEND == "python":
+    _define_python_ops()
+elif BACKEND == "native":
+    _load_native()
+else:
+    raise ValueError("CUEMBED_PYT_BACKEND must be 'native' or 'python'")
 
 cuembed_extract_row_ids_from_csr = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_csr
 cuembed_transpose = torch.ops.cuembed_pyt.cuembed_transpose
 cuembed_transpose_bounded = torch.ops.cuembed_pyt.cuembed_transpose_bounded
+cuembed_transpose_sample_ids = torch.ops.cuembed_pyt.cuembed_transpose_sample_ids
+cuembed_transpose_fixed_hotness = torch.ops.cuembed_pyt.cuembed_transpose_fixed_hotness
 cuembed_embedding_forward = torch.ops.cuembed_pyt.cuembed_embedding_forward
 cuembed_embedding_backward = torch.ops.cuembed_pyt.cuembed_embedding_backward
 
@@ -168,7 +234,7 @@ def cuembed_backward(ctx, out_grad):
         return _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz)
     # equivalent of nn.EmbeddingBag(include_last_offset=True)
     sample_ids = cuembed_extract_row_ids_from_csr(offsets[:-1], nnz)
-    transpose_indices, transpose_sample_ids, transpose_weights = cuembed_transpose_bounded(
+    transpose_indices, transpose_sample_ids, transpose_weights = cuembed_transpose_sample_ids(
         sample_ids, idx, weights, ctx.num_categories)
     if transpose_weights.numel() == 0:  # forward ran without weights
         transpose_weights = None
@@ -187,7 +253,7 @@ def _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz):
                                         torch.empty((0, width), dtype=out_grad.dtype, device=out_grad.device),
                                         size=(ctx.num_categories, width)), None, None, None)
     sample_ids = cuembed_extract_row_ids_from_csr(offsets[:-1], nnz)
-    t_idx, t_sid, t_w = cuembed_transpose_bounded(sample_ids, idx, weights, ctx.num_categories)
+    t_idx, t_sid, t_w = cuembed_transpose_sample_ids(sample_ids, idx, weights, ctx.num_categories)
     if t_w.numel() == 0:
         t_w = None
     remap = torch.ops.cuembed_pyt.cuembed_compute_compressed_grad_indices(t_idx)
@@ -247,17 +313,16 @@ class _CuEmbFixed(torch.autograd.Function):
     def backward(ctx, out_grad):
         idx, weights = ctx.saved_tensors
         batch, hot = idx.shape
-        flat = idx.contiguous().view(-1)
-        if ctx.mode == "concat":   # every lookup has its own gradient row
+        if ctx.mode == "concat":   # every lookup has its own gradient row: sample id = position
             y = out_grad.reshape(batch * hot, -1)
-            sample_ids = _ops.extract_row_ids_for_concat(batch * hot, flat.dtype, flat.device)
+            layout = idx.contiguous().view(batch * hot, 1)
         else:
             y = out_grad if ctx.mode == "sum" else out_grad * (1.0 / hot)
-            sample_ids = _ops.extract_row_ids_from_fixed(batch, hot, flat.dtype, flat.device)
-        w = None if weights is None else weights.contiguous().view(-1)
-        if ctx.mode == "mean" and w is not None:      # out = sum(w x) / sum(w)
+            layout = idx
+        if ctx.mode == "mean" and weights is not None:      # out = sum(w x) / sum(w)
             y = out_grad / weights.sum(1, keepdim=True).to(out_grad.dtype)
-        t_idx, t_sid, t_w = cuembed_transpose_bounded(sample_ids, flat, w, ctx.num_categories)
+        # row ids + transpose in one call; the sample ids are never materialised
+        t_idx, t_sid, t_w, _ = cuembed_transpose_fixed_hotness(layout, weights, ctx.num_categories, False)
         if t_w.numel() == 0:
             t_w = None
         grad = cuembed_embedding_backward(y.contiguous(), ctx.num_categories, t_idx, t_sid, t_w)
@@ -302,6 +367,34 @@ def _(rows, cols, weights=None, num_categories=0):
     n = 0 if weights is None else cols.shape[0]
     return (torch.empty_like(cols), torch.empty_like(rows),
             torch.empty((n,), device=rows.device, dtype=torch.float32 if weights is None else weights.dtype))
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_transpose_sample_ids")
+def _(sample_ids, indices, weights=None, num_categories=0):
+    n = 0 if weights is None else indices.shape[0]
+    return (torch.empty_like(indices), torch.empty_like(sample_ids),
+            torch.empty((n,), device=indices.device, dtype=torch.float32 if weights is None else weights.dtype))
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_transpose_fixed_hotness")
+def _(indices, weights=None, num_categories=0, compressed=False):
+    nnz = indices.shape[0] * indices.shape[1]
+    flat = dict(device=indices.device, dtype=indices.dtype)
+    return (torch.empty((nnz,), **flat), torch.empty((nnz,), **flat),
+            torch.empty((0 if weights is None else nnz,), device=indices.device,
+                        dtype=torch.float32 if weights is None else weights.dtype),
+            torch.empty((nnz if compressed else 0,), **flat))
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_compute_compressed_grad_indices")
+def _(transpose_indices):
+    return torch.empty_like(transpose_indices)
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_embedding_backward_compressed")
+def _(y_grad, num_unique, transpose_indices, transpose_sample_ids, transpose_remapped_indices, transpose_weights=None):
+    return (torch.empty((num_unique, y_grad.shape[1]), device=y_grad.device, dtype=y_grad.dtype),
+            torch.empty((num_unique,), device=y_grad.device, dtype=transpose_indices.dtype))
 
 
 @torch.library.register_fake("cuembed_pyt::cuembed_embedding_forward")

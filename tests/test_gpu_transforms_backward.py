@@ -442,3 +442,28 @@ def test_compressed_indices_many_tiles(ce, oracle):
     got = host(ce.compute_compressed_grad_indices(dev(keys)))
     want = oracle.compute_compressed_grad_indices(keys)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_fixed_hotness_without_sample_id_array(ce, oracle, idx):
+    """cuembed::TransposeFixedHotness (extension) == ExtractRowIdsFromFixed + Transpose: the first
+    radix pass derives the sample id of lookup i as i / num_hots (a multiply-shift; checked here for
+    hotness values that are not powers of two, up to the largest positions) instead of loading it."""
+    rng = np.random.default_rng(41)
+    for B, H in [(1, 1), (3, 4), (100, 1), (157, 26), (65, 63), (1023, 7), (4096, 1), (9000, 5), (70001, 3),
+                 (65536, 64), (1, 70000), (3, 99991)]:
+        nnz = B * H
+        cols = rng.integers(0, 1 << 22, nnz).astype(idx[0])
+        w = rng.uniform(0, 1, nnz).astype(np.float32)
+        sid = ce.extract_row_ids_from_fixed(B, H, idx[1])
+        for weights in (None, w):
+            for ncat in (None, 1 << 22):
+                want = ce.transpose(sid, dev(cols), dev(weights), num_categories=ncat)
+                got = ce.transpose_fixed_hotness(dev(cols), B, H, dev(weights), num_categories=ncat)
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (B, H, ncat)
+                if weights is not None:
+                    assert torch.equal(got[2], want[2])
+        if nnz <= 300000:
+            oi, os_, _ = oracle.transpose(oracle.extract_row_ids_from_fixed(B, H, idx[0]), cols, None, stable=True)
+            got = ce.transpose_fixed_hotness(dev(cols), B, H)
+            assert np.array_equal(host(got[0]), oi) and np.array_equal(host(got[1]), os_), (B, H)
