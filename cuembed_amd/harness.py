@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_PKG, "lib", "libcuembed_harness.so")
+# CUEMBED_HARNESS_LIB: load another build of the same source (the ASan/UBSan one, `make -C oracle asan`)
+_PATH = os.environ.get("CUEMBED_HARNESS_LIB") or os.path.join(_PKG, "lib", "libcuembed_harness.so")
 _h = None
 
 

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libcuembed_oracle.so")
+# CUEMBED_ORACLE_LIB: load another build of the same source (the ASan/UBSan one, `make -C oracle asan`)
+_LIB_PATH = os.environ.get("CUEMBED_ORACLE_LIB") or os.path.join(_HERE, "libcuembed_oracle.so")
 _REF_PATH = os.path.join(_HERE, "_ref", "libref_datagen.so")
 
 SUM, MEAN, CONCAT = 0, 1, 2
