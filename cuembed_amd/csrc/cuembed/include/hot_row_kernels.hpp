@@ -206,12 +206,27 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ s
     return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(sid)) * fill_magic) >> fill_shift);
   };
   (void)samples_per_fill;
-  for (int p = lo + tid; p < hi; p += kHotDetectThreads) {
-    const int f1 = fill_of(sample_ids[p]);
-    const int f0 = p == lo ? -1 : fill_of(sample_ids[p - 1]);
-    for (int f = f0 + 1; f <= f1; ++f) my_bounds[f] = p;
-    if (p == hi - 1)
-      for (int f = f1 + 1; f <= num_fills; ++f) my_bounds[f] = hi;
+  // kScanBatch loads per thread are issued before the first is used: the walk is a dependent
+  // chain of memory round trips otherwise (the stores below keep the compiler from overlapping them)
+  constexpr int kScanBatch = 8;
+  for (int base = lo + tid; base < hi; base += kScanBatch * kHotDetectThreads) {
+    IndexT cur[kScanBatch], prev[kScanBatch];
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      const int p = base + u * kHotDetectThreads;
+      cur[u] = p < hi ? sample_ids[p] : IndexT(0);
+      prev[u] = (p < hi && p > lo) ? sample_ids[p - 1] : IndexT(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      const int p = base + u * kHotDetectThreads;
+      if (p >= hi) break;
+      const int f1 = fill_of(cur[u]);
+      const int f0 = p == lo ? -1 : fill_of(prev[u]);
+      for (int f = f0 + 1; f <= f1; ++f) my_bounds[f] = p;
+      if (p == hi - 1)
+        for (int f = f1 + 1; f <= num_fills; ++f) my_bounds[f] = hi;
+    }
   }
 }
 
@@ -261,7 +276,6 @@ HotRowChunkSumKernel(const GradT* __restrict__ grad_y, const int width, const in
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int piece_lo[kHotMaxRuns * kHotPieces];   // per item: lookups [lo, hi) of this fill
   __shared__ int piece_hi[kHotMaxRuns * kHotPieces];
-  __shared__ int order[kHotMaxRuns * kHotPieces];      // items by decreasing length
   __shared__ HotRun run[kHotMaxRuns];
   __shared__ int next_item;
   const int tid = threadIdx.x;
@@ -304,22 +318,12 @@ HotRowChunkSumKernel(const GradT* __restrict__ grad_y, const int width, const in
       for (int64_t i = tid; i < n16; i += kHotThreads) dst[i] = __builtin_nontemporal_load(src + i);
     }
     __syncthreads();
-    if (tid < items) {  // longest first, taken by the wavefronts as they finish
-      const int len = piece_hi[tid] - piece_lo[tid];
-      int rank = 0;
-      for (int u = 0; u < items; ++u) {
-        const int lu = piece_hi[u] - piece_lo[u];
-        rank += (lu > len || (lu == len && u < tid)) ? 1 : 0;
-      }
-      order[rank] = tid;
-    }
-    __syncthreads();
     while (true) {
       int it = 0;
       if (lane == 0) it = atomicAdd(&next_item, 1);
       it = __builtin_amdgcn_readfirstlane(it);
       if (it >= items) break;
-      const int item = order[it];
+      const int item = it;   // table order: ~7 items per wavefront even out without sorting them by length
       const int h = item / kHotPieces, p = item - h * kHotPieces;
       const int pieces = HotPiecesOf(run[h], block_len, samples_per_chunk, num_samples);
       if (p >= pieces) continue;   // never written, never read
