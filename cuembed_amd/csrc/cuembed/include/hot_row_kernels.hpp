@@ -60,9 +60,12 @@ struct HotRunTable {
   HotRun run[kHotMaxRuns];
 };
 
+//! Detection stride: about nnz / 512 (a run has to hold ~0.2-0.4 % of all lookups to be worth a
+//! slot: at the north-star shape 8192, which selects 58 runs = 32 % of the lookups; 4096 would
+//! select 109 and fill the 64 slots with the first ones in row order rather than the longest).
 inline int HotStride(const int64_t nnz) {
   int64_t s = kHotMinStride;
-  while ((nnz + s - 1) / s > kHotMaxMultiples) s *= 2;
+  while ((nnz + s - 1) / s > 512) s *= 2;
   return static_cast<int>(s);
 }
 
@@ -227,36 +230,6 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ s
       if (p == hi - 1)
         for (int f = f1 + 1; f <= num_fills; ++f) my_bounds[f] = hi;
     }
-  }
-}
-
-//! acc[e] += float(row.v[e]) [* wf] -- one IEEE fp32 add (and one multiply) per element, as
-//! everywhere in this library.  For fp16 rows the conversion, the multiply and the add are ONE
-//! v_fma_mix_f32 per element instead of v_cvt + (v_mul +) v_add: the product of two fp16 values
-//! is exact in fp32 (22 significand bits), so the fused form rounds exactly once, to the same
-//! value as the separate operations.  The chunk kernel is bound by VALU issue, not by LDS.
-template <typename GradT, int N, bool kWeighted>
-__device__ __forceinline__ void AccumulateRow(float (&acc)[N], const Pack<GradT, N>& row, const float wf) {
-  using A = Arith<float>;
-  if constexpr (std::is_same<GradT, _Float16>::value) {
-    static_assert(N % 2 == 0, "fp16 rows move in multiples of 4 bytes");
-    const unsigned* pair = reinterpret_cast<const unsigned*>(&row);
-#pragma unroll
-    for (int e = 0; e < N; e += 2) {
-      if constexpr (kWeighted) {
-        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[e]) : "v"(pair[e / 2]), "v"(wf));
-        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[e + 1]) : "v"(pair[e / 2]), "v"(wf));
-      } else {
-        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(acc[e]) : "v"(pair[e / 2]));
-        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[e + 1]) : "v"(pair[e / 2]));
-      }
-    }
-  } else if constexpr (kWeighted) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(row.v[e]), wf));
-  } else {
-#pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(row.v[e]));
   }
 }
 

@@ -301,15 +301,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
       }
 #pragma unroll
       for (int u = 0; u < kBackwardUnroll; ++u) {
-        if constexpr (kWeighted) {
-          const float wf = static_cast<float>(w[u]);
-#pragma unroll
-          for (int e = 0; e < N; ++e)
-            acc[e] = A::add(acc[e], A::mul(static_cast<float>(g[u].v[e]), wf));
-        } else {
-#pragma unroll
-          for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g[u].v[e]));
-        }
+        AccumulateRow<GradT, N, kWeighted>(acc, g[u], kWeighted ? static_cast<float>(w[u]) : 1.f);
         const bool last = (i + u + 1 == count);
         if (last || row_next[u] != row_cur) end_of_run(row_cur, last);
         row_cur = row_next[u];
@@ -319,14 +311,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
       const int64_t sid = static_cast<int64_t>(my_sids[i]);
       const Pack<GradT, N> g = LoadPack<GradT, N>(lane_src + sid * width);
       const int64_t row_next = static_cast<int64_t>(my_rows[i + 1]);
-      if constexpr (kWeighted) {
-        const float wf = static_cast<float>(my_w[i]);
-#pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(g.v[e]), wf));
-      } else {
-#pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], static_cast<float>(g.v[e]));
-      }
+      float wf = 1.f;
+      if constexpr (kWeighted) wf = static_cast<float>(my_w[i]);
+      AccumulateRow<GradT, N, kWeighted>(acc, g, wf);
       const bool last = (i + 1 == count);
       if (last || row_next != row_cur) end_of_run(row_cur, last);
       row_cur = row_next;
