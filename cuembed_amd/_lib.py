@@ -43,6 +43,8 @@ def _declare(L):
     L.cuembed_transpose_fixed_hotness.restype = None
     L.cuembed_transpose_fixed_hotness.argtypes = [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP,
                                                   ctypes.POINTER(ctypes.c_size_t), _I, _VP]
+    L.cuembed_translate_indices_for_row_cache.restype = None
+    L.cuembed_translate_indices_for_row_cache.argtypes = [_VP, _I, ctypes.c_int64, _VP, ctypes.c_int64, _VP, _VP]
     L.cuembed_compute_compressed_grad_indices.restype = None
     L.cuembed_compute_compressed_grad_indices.argtypes = [_VP, _I, _I, _VP, _VP,
                                                           ctypes.POINTER(ctypes.c_size_t), _VP]

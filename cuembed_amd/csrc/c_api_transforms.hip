@@ -118,6 +118,19 @@ void cuembed_transpose_fixed_hotness(const void* indices, const void* weights, i
 #undef TR
 }
 
+void cuembed_translate_indices_for_row_cache(const void* indices, int index_type, int64_t nnz,
+                                             const int32_t* slot_of_row, int64_t cache_row_offset,
+                                             int64_t* translated, cuembed_stream_t stream) {
+  if (index_type == CUEMBED_I32)
+    cuembed::TranslateIndicesForRowCache<int32_t>(static_cast<const int32_t*>(indices), nnz, slot_of_row,
+                                                  cache_row_offset, translated, Stream(stream));
+  else if (index_type == CUEMBED_I64)
+    cuembed::TranslateIndicesForRowCache<int64_t>(static_cast<const int64_t*>(indices), nnz, slot_of_row,
+                                                  cache_row_offset, translated, Stream(stream));
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream) {

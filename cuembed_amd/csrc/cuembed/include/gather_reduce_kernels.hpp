@@ -110,28 +110,15 @@ __device__ __forceinline__ void StorePackStreaming(ElemT* p, const Pack<ElemT, N
 }
 
 //! acc[e] += float(row.v[e]) [* wf] -- one IEEE fp32 add (and one multiply) per element, as
-//! everywhere in this library.  For fp16 rows the conversion, the multiply and the add are ONE
-//! v_fma_mix_f32 per element instead of v_cvt + (v_mul +) v_add: the product of two fp16 values
-//! is exact in fp32 (22 significand bits), so the fused form rounds exactly once, to the same
-//! value as the separate operations.  Half the VALU issue slots of every gather kernel; the LDS-fed
-//! hot-row kernel is bound by them.
+//! everywhere in this library.
+//! (Measured and rejected for fp16 rows: v_fma_mix_f32, which converts, multiplies and adds in one
+//! instruction and is bit-identical because the product of two fp16 values is exact in fp32.  It
+//! halves the instruction count but not the time: C2 forward 0.139 -> 0.185 ms, i.e. the mixed-
+//! precision FMA issues well below the rate of v_cvt_f32_f16 + v_add_f32 on gfx950.)
 template <typename GradT, int N, bool kWeighted>
 __device__ __forceinline__ void AccumulateRow(float (&acc)[N], const Pack<GradT, N>& row, const float wf) {
   using A = Arith<float>;
-  if constexpr (std::is_same<GradT, _Float16>::value) {
-    static_assert(N % 2 == 0, "fp16 rows move in multiples of 4 bytes");
-    const unsigned* pair = reinterpret_cast<const unsigned*>(&row);
-#pragma unroll
-    for (int e = 0; e < N; e += 2) {
-      if constexpr (kWeighted) {
-        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[e]) : "v"(pair[e / 2]), "v"(wf));
-        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[e + 1]) : "v"(pair[e / 2]), "v"(wf));
-      } else {
-        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(acc[e]) : "v"(pair[e / 2]));
-        asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[e + 1]) : "v"(pair[e / 2]));
-      }
-    }
-  } else if constexpr (kWeighted) {
+  if constexpr (kWeighted) {
 #pragma unroll
     for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], A::mul(static_cast<float>(row.v[e]), wf));
   } else {
@@ -153,15 +140,7 @@ struct RowPool {
   }
 
   __device__ __forceinline__ void Add(const Pack<ElemT, N>& row, ElemT w) {
-    if constexpr (std::is_same<AccT, float>::value && std::is_same<ElemT, _Float16>::value) {
-      // fp16 rows, fp32 accumulation: convert (+ multiply) + add in one v_fma_mix_f32, same bits
-      float wf = 1.f;
-      if constexpr (kWeighted) {
-        wf = static_cast<float>(w);
-        weight_sum += wf;
-      }
-      AccumulateRow<ElemT, N, kWeighted>(acc, row, wf);
-    } else if constexpr (kWeighted) {
+    if constexpr (kWeighted) {
       const AccT wa = A::widen(w);
       weight_sum += static_cast<float>(w);
 #pragma unroll

@@ -80,6 +80,41 @@ void ExtractRowIdsForConcat(const int nnz, IndexT* row_ids, const hipStream_t st
 }
 
 /**
+ * @brief Table-row caching hook (extension; the reference lists an embedding cache as future work,
+ * README.md:111-112, embedding_lookup_kernels.cuh:114-115) for tables that do NOT live in this
+ * GPU's HBM -- pinned host memory read over PCIe, or a peer's memory -- with the most frequently
+ * used rows copied into a device buffer.
+ *
+ * EmbeddingForward addresses a row as `params + int64(index) * embed_width`; nothing requires
+ * the row to lie inside the table's own allocation.  With
+ *     cache_row_offset = (cache_rows - params) / embed_width     (elements; the two buffers must
+ *                                                                  differ by a whole number of rows)
+ * the index `cache_row_offset + slot` reaches row `slot` of the device cache through the SAME
+ * base pointer.  This helper rewrites the indices of a batch accordingly:
+ *     translated[i] = slot_of_row[indices[i]] >= 0 ? cache_row_offset + slot_of_row[indices[i]]
+ *                                                   : indices[i]                        (int64)
+ * and EmbeddingForward<..., int64_t, ...>(params, ..., translated, ...) then reads cached rows
+ * from HBM and only the others from wherever `params` lives -- unmodified kernel, bit-identical
+ * results as long as the cached copies equal the table rows.  slot_of_row has one int32 per table
+ * row (-1: not cached); which rows to cache (e.g. the most frequent ones of recent batches) is the
+ * caller's policy -- cuembed_amd/row_cache.py has a simple one.
+ */
+template <typename IndexT>
+void TranslateIndicesForRowCache(const IndexT* indices,
+                                 const int64_t nnz,
+                                 const int32_t* slot_of_row,
+                                 const int64_t cache_row_offset,
+                                 int64_t* translated,
+                                 const hipStream_t stream = 0) {
+  if (nnz <= 0) return;
+  const int threads = detail::kIndexBlockThreads;
+  const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
+  detail::TranslateForRowCacheKernel<IndexT>
+      <<<static_cast<unsigned>((nnz + per_block - 1) / per_block), threads, 0, stream>>>(
+          indices, nnz, slot_of_row, cache_row_offset, translated);
+}
+
+/**
  * @brief Reorder sample-major COO lookups into index-major order: a STABLE sort
  * of (rows[i] [, weights[i]]) by the key cols[i].
  *

@@ -241,6 +241,18 @@ void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int 
 void cuembed_extract_row_ids_for_concat(int nnz, int index_type, void* row_ids,
                                         cuembed_stream_t stream);
 
+/* ---- extension: table-row caching hook (cuembed::TranslateIndicesForRowCache) ------------ */
+/* For tables that live outside this GPU's HBM (pinned host memory, a peer) with hot rows copied
+ * to a device buffer `cache_rows`: translated[i] = slot_of_row[indices[i]] >= 0 ?
+ * cache_row_offset + slot : indices[i], with cache_row_offset = (cache_rows - params) / embed_width
+ * in elements (the buffers must differ by a whole number of rows).  cuembed_embedding_forward with
+ * index_type = CUEMBED_I64 on `translated` and the table's own `params` pointer then reads cached
+ * rows from HBM and the rest from the table -- same kernel, same bits.  slot_of_row: one int32 per
+ * table row, -1 = not cached. */
+void cuembed_translate_indices_for_row_cache(const void* indices, int index_type, int64_t nnz,
+                                             const int32_t* slot_of_row, int64_t cache_row_offset,
+                                             int64_t* translated, cuembed_stream_t stream);
+
 /* ---- extension: gradient w.r.t. the per-lookup weights ---------------------- */
 /* grad_weights[s, j] = dot(params[indices[s, j], :], grad_y[s, :]); one entry per lookup;
  * index layouts as in cuembed_embedding_forward (cuembed::EmbeddingWeightGrad). */
