@@ -55,7 +55,9 @@ struct Flags {
   bool use_int64_indices = false, check_result = false, half_embedding_type = false, csr_input = false,
        weighted_sum = false, fp16_math = false, compressed_grad = true, skip_grad_init = true,
        forward_only = false, enable_csv = false, enable_stderr = true, clear_caches = true,
-       bounded_sort = false;
+       bounded_sort = false,      // extension: Transpose sorts ceil(log2(num_categories)) key bits only
+       fused_row_ids = false,     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
+       run_aware = false;         // extension: EmbeddingBackwardRunAware (scratch buffer, hot runs chunk-major)
 };
 
 bool ParseBool(const std::string& v) { return v.empty() || v == "1" || v == "true" || v == "True" || v == "yes"; }
@@ -87,6 +89,8 @@ Flags ParseFlags(int argc, char** argv) {
   getb("forward_only", &f.forward_only); getb("enable_csv", &f.enable_csv);
   getb("enable_stderr", &f.enable_stderr); getb("clear_caches", &f.clear_caches);
   getb("bounded_sort", &f.bounded_sort);
+  getb("fused_row_ids", &f.fused_row_ids);
+  getb("run_aware", &f.run_aware);
   for (auto& e : kv) {
     std::fprintf(stderr, "unknown flag --%s\n", e.first.c_str());
     std::exit(1);
@@ -147,7 +151,7 @@ struct Workload {
   DeviceBuffer<IndexT> indices, sample_ids, transpose_indices, transpose_remapped_indices,
       transpose_sample_ids, inverse_mapping;
   DeviceBuffer<OffsetT> offsets;
-  DeviceBuffer<char> workspace;
+  DeviceBuffer<char> workspace, backward_work;
   size_t lwork = 0;
 };
 
@@ -164,9 +168,10 @@ void RunForward(Workload<ElemT, IndexT, OffsetT>& w) {
 template <typename ElemT, typename IndexT, typename OffsetT>
 void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
   const int nnz = static_cast<int>(w.nnz);
+  const bool fused = w.f.fused_row_ids && !w.f.csr_input;
   if (w.f.csr_input)
     cuembed::ExtractRowIdsFromCSR<IndexT, OffsetT>(w.offsets.ptr, w.f.batch_size, w.sample_ids.ptr);
-  else
+  else if (!fused)
     cuembed::ExtractRowIdsFromFixed<IndexT>(w.f.batch_size, w.f.hotness, w.sample_ids.ptr);
   const ElemT* weights = w.f.weighted_sum ? w.weights.ptr : nullptr;
   ElemT* t_weights = w.f.weighted_sum ? w.transpose_weights.ptr : nullptr;
@@ -176,8 +181,13 @@ void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
     bits = 1;
     while ((int64_t{1} << bits) < w.f.num_categories) ++bits;
   }
-  cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, weights, nnz, w.transpose_indices.ptr,
-                                    w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits);
+  if (fused)
+    cuembed::TransposeFixedHotness<IndexT, ElemT>(w.indices.ptr, weights, w.f.batch_size, w.f.hotness,
+                                                  w.transpose_indices.ptr, w.transpose_sample_ids.ptr, t_weights,
+                                                  w.workspace.ptr, &lwork, 0, bits);
+  else
+    cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, weights, nnz, w.transpose_indices.ptr,
+                                      w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits);
   if (w.f.compressed_grad)
     cuembed::ComputeCompressedGradIndices<IndexT>(w.transpose_indices.ptr, nnz,
                                                   w.transpose_remapped_indices.ptr, w.workspace.ptr, &lwork);
@@ -185,6 +195,16 @@ void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
 
 template <typename ElemT, typename IndexT, typename OffsetT>
 void RunBackward(Workload<ElemT, IndexT, OffsetT>& w, int num_unique) {
+  if (w.f.run_aware) {
+    size_t lwork = w.backward_work.n;
+    cuembed::EmbeddingBackwardRunAware<ElemT, IndexT>(
+        w.grad_y.ptr, w.f.embed_width, w.f.compressed_grad ? num_unique : w.f.num_categories,
+        static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
+        w.f.compressed_grad ? w.transpose_remapped_indices.ptr : nullptr,
+        w.f.weighted_sum ? w.transpose_weights.ptr : nullptr, w.f.skip_grad_init, w.grad_embedding.ptr,
+        w.f.compressed_grad ? w.inverse_mapping.ptr : nullptr, w.f.batch_size, w.backward_work.ptr, &lwork);
+    return;
+  }
   cuembed::EmbeddingBackward<ElemT, IndexT>(
       w.grad_y.ptr, w.f.embed_width, w.f.compressed_grad ? num_unique : w.f.num_categories,
       static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
@@ -334,6 +354,13 @@ void EmbeddingLookupBenchmark(const Flags& f) {
   w.grad_embedding.Resize(static_cast<size_t>(grad_rows) * f.embed_width);
   HIP_OK(hipMemset(w.grad_embedding.ptr, 0, w.grad_embedding.n * sizeof(ElemT)));
   w.inverse_mapping.Resize(f.compressed_grad ? num_unique : 0);
+  if (f.run_aware) {
+    size_t lw_b = 0;
+    cuembed::EmbeddingBackwardRunAware<ElemT, IndexT>(nullptr, f.embed_width, 0, static_cast<int>(w.nnz), nullptr,
+                                                      nullptr, nullptr, nullptr, false, nullptr, nullptr,
+                                                      f.batch_size, nullptr, &lw_b);
+    w.backward_work.Resize(lw_b);
+  }
   ms = timer.Run(f.iterations, [&] { RunBackward<ElemT, IndexT, OffsetT>(w, num_unique); });
   // unique rows actually touched (the reference counts them with thrust::unique_count)
   std::vector<IndexT> h_t(w.nnz);

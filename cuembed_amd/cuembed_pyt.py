@@ -201,7 +201,7 @@ def _backward_compressed_impl(y_grad, num_unique, transpose_indices, transpose_s
     grad, inv = _ops.embedding_backward(y_grad.contiguous(), num_unique, transpose_indices.contiguous(),
                                         transpose_sample_ids.contiguous(),
                                         transpose_remapped_indices.contiguous(), transpose_weights,
-                                        skip_grad_init=False, run_aware=True)
+                                        skip_grad_init=False)
     return grad, inv
 
 

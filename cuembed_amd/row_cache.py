@@ -28,6 +28,8 @@ class CachedHostTable:
             raise TypeError("table must be float32, float16 or bfloat16")
         self.table = host_table
         self.device = torch.device(device)
+        if self.device.index is None:   # "cuda" -> the current device, so that it compares equal to tensor.device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.rows, self.width = host_table.shape
         self.capacity = int(capacity_rows)
         row_bytes = self.width * host_table.element_size()

@@ -11,7 +11,7 @@ python bench.py > "$O/bench_c2_line.json" 2> "$O/bench.err"
 C2="--num_categories 10000000 --embed_width 256 --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true"
 C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 --hotness 128 --csr_input=true --weighted_sum=true"
 {
-  for ex in "" "--bounded_sort" "--use_int64_indices" "--use_int64_indices --bounded_sort"; do
+  for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--run_aware" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
     echo "== C2/C4 $ex"; benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
   for ex in "" "--bounded_sort"; do
@@ -20,6 +20,11 @@ C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 
 } > "$O/manual_benchmark_c2_c3.txt"
 python tools/secondary_kernels.py > "$O/secondary_kernels.txt" 2>&1
 python benchmarks/train_step_benchmark.py --exchange none > "$O/train_step_none.json" 2> "$O/train_step.err"
+python benchmarks/train_step_benchmark.py --exchange none --reference_api >> "$O/train_step_none.json" 2>> "$O/train_step.err"
+python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_native_binding.jsonl" 2> "$O/torch_probe.err"
+CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_python_ctypes_ops.jsonl" 2>> "$O/torch_probe.err"
+python tools/hot_run_probe.py > "$O/hot_run_probe.json" 2> "$O/hot_run_probe.err"
+python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
 python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
 # profiler passes last (they clock lower); the program goes directly after `--`
 cd /tmp && export TMPDIR=/tmp
