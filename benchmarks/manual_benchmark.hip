@@ -47,7 +47,6 @@ extern "C" void cuembed_harness_allocate_grad_y(int64_t count, int elem_is_half,
 
 namespace {
 
-constexpr double kHbmPeakGBps = 8000.0;
 
 struct Flags {
   int num_categories = 1048576, embed_width = 128, batch_size = 1024, hotness = 1, iterations = 1;
@@ -310,8 +309,9 @@ void EmbeddingLookupBenchmark(const Flags& f) {
   double bytes = f.csr_input ? es * (nnz - 1 + B) * W : es * B * (H + 1) * W;
   double bw = bytes * it / 1e6 / ms;
   std::fprintf(stderr, "Embedding forward. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
-                       "Application BW [GB/s]: %.2f (%.1f%% of HBM peak)\n",
-               f.iterations, ms, ms / it, bw, 100.0 * bw / kHbmPeakGBps);
+                       "Application BW [GB/s]: %.2f (algorithmic bytes / time: cache hits count, NOT an HBM "
+                       "rate -- bench.py's roofline block has the measured fabric traffic)\n",
+               f.iterations, ms, ms / it, bw);
   CsvLine(f, "forward", ms, bw, 0.0);
   if (f.check_result)
     std::fprintf(stderr, "check_result: results are checked against the CPU oracle by `pytest -m gpu` and "

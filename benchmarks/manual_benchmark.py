@@ -136,8 +136,8 @@ def run(a, table_cache=None, quiet=False):
     else:
         nbytes = es * B * (H + 1) * W
     bw = nbytes * a.iterations / 1e6 / ms
-    report("Embedding forward", ms, bw, 0.0, "Application BW [GB/s]: %.2f (%.1f%% of HBM peak)"
-           % (bw, 100 * bw / HBM_PEAK_GBPS))
+    report("Embedding forward", ms, bw, 0.0, "Application BW [GB/s]: %.2f (algorithmic bytes / time: cache hits "
+           "count, NOT an HBM rate)" % bw)
     if a.check_result:
         from oracle import oracle as O   # checker only
         want = O.embedding_forward(w["table"], w["indices"], w["offsets"] if a.csr_input else None,
