@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Randomised differential test of the whole path against the CPU oracle (test infrastructure):
 random table shapes, batch sizes, hotness, index distributions and types, fixed / CSR layouts,
-weights -- forward (bit-exact), row-id extraction, Transpose (bit-exact, stable), compressed-index
-remap, EmbeddingBackward dense and compressed (exact on small-integer gradients).
+weights -- forward (bit-exact), row-id extraction, Transpose (bit-exact, stable; with and without the
+key / row bounds; the fused fixed-hotness variant; signed keys and arbitrary payloads), compressed-index
+remap, EmbeddingBackward dense and compressed and the run-aware variant with a random detection stride
+(exact on small-integer gradients).
 
     python tools/fuzz_parity.py [--seconds 300] [--seed 0]
 
@@ -67,8 +69,22 @@ def one_case(rng, ce, O, np, torch, verbose=False):
     assert np.array_equal(d_sid.cpu().numpy(), sid), ("extract", desc)
     ti, ts, tw = O.transpose(sid, indices, weights, stable=True)
     bound = ncat if rng.integers(0, 2) else None
-    d_ti, d_ts, d_tw = ce.transpose(d_sid, dev(indices), dev(weights), num_categories=bound)
+    rows_bound = nnz if rng.integers(0, 2) else None
+    d_ti, d_ts, d_tw = ce.transpose(d_sid, dev(indices), dev(weights), num_categories=bound, num_rows=rows_bound)
     assert np.array_equal(d_ti.cpu().numpy(), ti) and np.array_equal(d_ts.cpu().numpy(), ts), ("transpose", desc)
+    if not csr:   # the fused fixed-hotness entry point must give the same three arrays
+        f_ti, f_ts, f_tw = ce.transpose_fixed_hotness(dev(indices), B, H, dev(weights), num_categories=bound)
+        assert torch.equal(f_ti, d_ti) and torch.equal(f_ts, d_ts), ("transpose_fixed_hotness", desc)
+        if weighted:
+            assert torch.equal(f_tw, d_tw), ("transpose_fixed_hotness weights", desc)
+    if rng.integers(0, 4) == 0:   # Transpose as a generic COO transpose: signed keys, arbitrary payloads
+        info = np.iinfo(idx_t)
+        g_cols = rng.integers(info.min, info.max, nnz, endpoint=True).astype(idx_t) if rng.integers(0, 2) else \
+            rng.integers(-5, 5, nnz).astype(idx_t)
+        g_rows = rng.integers(info.min, info.max, nnz, endpoint=True).astype(idx_t)
+        o = O.transpose(g_rows, g_cols, None, stable=True)
+        g = ce.transpose(dev(g_rows), dev(g_cols))
+        assert np.array_equal(g[0].cpu().numpy(), o[0]) and np.array_equal(g[1].cpu().numpy(), o[1]), ("generic transpose", desc)
     if weighted:
         assert np.array_equal(d_tw.cpu().numpy().view(np.uint16 if es == 2 else np.uint32),
                               tw.view(np.uint16 if es == 2 else np.uint32)), ("transpose weights", desc)
@@ -89,6 +105,15 @@ def one_case(rng, ce, O, np, torch, verbose=False):
         got_c, got_inv = ce.embedding_backward(dev(gy), nu, d_ti, d_ts, d_remap, d_tw if use_w else None)
         assert np.array_equal(got_c.float().cpu().numpy(), want_c), ("backward compressed", desc)
         assert np.array_equal(got_inv.cpu().numpy(), want_inv), ("inverse mapping", desc)
+        # the run-aware entry point, with the hot path forced on for a random detection stride
+        stride = int(2 ** rng.integers(8, 12))
+        ce.set_backward_tuning(hot_stride=stride)
+        try:
+            ra_c, ra_inv = ce.embedding_backward(dev(gy), nu, d_ti, d_ts, d_remap, d_tw if use_w else None,
+                                                 run_aware=True)
+        finally:
+            ce.set_backward_tuning()
+        assert torch.equal(ra_c, got_c) and torch.equal(ra_inv, got_inv), ("backward run-aware", stride, desc)
         if ncat * W <= 40_000_000:
             want_d, _ = O.embedding_backward(gy.astype(np.float32), W, ncat, ti, ts, None, w32)
             got_d, _ = ce.embedding_backward(dev(gy), ncat, d_ti, d_ts, None, d_tw if use_w else None)
