@@ -120,7 +120,7 @@ def _gather_ragged(ids, vals, group):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
-    counts = [int(c.item()) for c in _all_gather(n, group)]
+    counts = torch.cat(_all_gather(n, group)).tolist()          # one host read-back for all ranks' counts
     cap = max(max(counts), 1)
     pad_vals = torch.zeros((cap, vals.shape[1]), dtype=vals.dtype, device=vals.device)
     pad_vals[: vals.shape[0]] = vals
@@ -173,8 +173,11 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     cuts = torch.tensor([b[0] for b in bounds] + [num_categories], dtype=torch.int64, device=ids.device)
     pos = torch.searchsorted(ids, cuts)                      # ids ascend: range r = [pos[r], pos[r+1])
     send = (pos[1:] - pos[:-1]).to(torch.int64)
-    send_l = send.tolist()
-    recv_l = _all_to_all_single(send, [1] * world, [1] * world, group).tolist()
+    # every rank learns the whole world x world split matrix with ONE collective and ONE host read-back
+    # (an all-to-all of the counts plus two .tolist() calls before)
+    splits = torch.stack(_all_gather(send, group)).tolist()
+    rank = dist.get_rank(group)
+    send_l, recv_l = splits[rank], [splits[r][rank] for r in range(world)]
     got_ids = _all_to_all_single(ids, recv_l, send_l, group)
     got_vals = _all_to_all_single(rows, recv_l, send_l, group)
     if got_ids.numel() > 0:

@@ -175,6 +175,65 @@ void BackwardKat(hipStream_t stream) {
   ExpectInt("bwd inverse mapping", inv.host(), {0, 1, 3});
 }
 
+// ---- this library's extensions of the header-only API (same known answers through other doors) ----
+template <typename IndexT, typename WeightT>
+void ExtensionTransposeKat(hipStream_t stream) {
+  // TransposeFixedHotness == ExtractRowIdsFromFixed + Transpose: batch 2, hotness 2 (the transpose KAT)
+  DeviceArray<IndexT> idx(std::vector<IndexT>{1, 3, 0, 4});
+  DeviceArray<WeightT> w(Vec<WeightT>({1.f, .5f, 1.f, .5f}));
+  DeviceArray<IndexT> t_idx(4), t_sid(4);
+  DeviceArray<WeightT> t_w(4);
+  size_t lwork = 0;
+  cuembed::TransposeFixedHotness<IndexT, WeightT>(idx.ptr, w.ptr, 2, 2, t_idx.ptr, t_sid.ptr, t_w.ptr, nullptr, &lwork,
+                                                  stream, /*index_bits=*/3);
+  DeviceArray<char> work(lwork);
+  cuembed::TransposeFixedHotness<IndexT, WeightT>(idx.ptr, w.ptr, 2, 2, t_idx.ptr, t_sid.ptr, t_w.ptr, work.ptr, &lwork,
+                                                  stream, /*index_bits=*/3);
+  HIP_OK(hipStreamSynchronize(stream));
+  ExpectInt("fixed-hotness transpose indices", t_idx.host(), {0, 1, 3, 4});
+  ExpectInt("fixed-hotness transpose sample ids", t_sid.host(), {1, 0, 0, 1});
+  Expect("fixed-hotness transpose weights", t_w.host(), {1, 1, .5, .5});
+  // Transpose is a generic COO transpose: signed keys (negative first), arbitrary payloads
+  DeviceArray<IndexT> cols(std::vector<IndexT>{3, -2, 0, -2, 7});
+  DeviceArray<IndexT> rows(std::vector<IndexT>{-9, 5, static_cast<IndexT>(sizeof(IndexT) == 8 ? (1ll << 40) : 70000), 6, 0});
+  DeviceArray<IndexT> t_rows(5), t_cols(5);
+  const WeightT* no_w = nullptr;
+  lwork = 0;
+  cuembed::Transpose<IndexT, WeightT>(rows.ptr, cols.ptr, no_w, 5, t_rows.ptr, t_cols.ptr, nullptr, nullptr, &lwork, stream);
+  DeviceArray<char> work2(lwork);
+  cuembed::Transpose<IndexT, WeightT>(rows.ptr, cols.ptr, no_w, 5, t_rows.ptr, t_cols.ptr, nullptr, work2.ptr, &lwork, stream);
+  HIP_OK(hipStreamSynchronize(stream));
+  ExpectInt("signed keys", t_rows.host(), {-2, -2, 0, 3, 7});
+  ExpectInt("wide payloads", t_cols.host(), {5, 6, sizeof(IndexT) == 8 ? (1ll << 40) : 70000, -9, 0});
+  // row-cache index translation: rows 3 and 0 are cached in slots 0 and 1, cache 1000 rows above the table
+  DeviceArray<int32_t> slot_of_row(std::vector<int32_t>{1, -1, -1, 0, -1});
+  DeviceArray<int64_t> translated(4);
+  cuembed::TranslateIndicesForRowCache<IndexT>(idx.ptr, 4, slot_of_row.ptr, 1000, translated.ptr, stream);
+  HIP_OK(hipStreamSynchronize(stream));
+  ExpectInt("row cache translation", translated.host(), {1, 1000, 1001, 4});
+}
+
+template <typename GradT, typename IndexT>
+void ExtensionBackwardKat(hipStream_t stream) {
+  // EmbeddingBackwardRunAware on the backward KAT (too small for the hot path: must equal EmbeddingBackward)
+  DeviceArray<IndexT> t_idx(std::vector<IndexT>{0, 1, 3, 3});
+  DeviceArray<IndexT> remap(std::vector<IndexT>{0, 1, 2, 2});
+  DeviceArray<IndexT> t_sid(std::vector<IndexT>{1, 0, 0, 1});
+  DeviceArray<GradT> gy(Vec<GradT>({1, 2, 3, 4, 5, 6, 7, 8}));
+  DeviceArray<GradT> cgrad(12);
+  DeviceArray<IndexT> inv(3);
+  const GradT* no_w = nullptr;
+  size_t lwork = 0;
+  cuembed::EmbeddingBackwardRunAware<GradT, IndexT>(gy.ptr, 4, 3, 4, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false,
+                                                    cgrad.ptr, inv.ptr, /*num_grad_y_rows=*/2, nullptr, &lwork, stream);
+  DeviceArray<char> work(lwork);
+  cuembed::EmbeddingBackwardRunAware<GradT, IndexT>(gy.ptr, 4, 3, 4, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false,
+                                                    cgrad.ptr, inv.ptr, 2, work.ptr, &lwork, stream);
+  HIP_OK(hipStreamSynchronize(stream));
+  Expect("run-aware bwd compressed", cgrad.host(), {5, 6, 7, 8, 1, 2, 3, 4, 6, 8, 10, 12});
+  ExpectInt("run-aware bwd inverse mapping", inv.host(), {0, 1, 3});
+}
+
 int main() {
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
@@ -201,6 +260,12 @@ int main() {
   BackwardKat<float, int64_t>(stream);
   BackwardKat<__half, int32_t>(stream);
   BackwardKat<__half, int64_t>(stream);
+  // extensions
+  ExtensionTransposeKat<int32_t, float>(stream);
+  ExtensionTransposeKat<int64_t, __half>(stream);
+  ExtensionBackwardKat<float, int32_t>(stream);
+  ExtensionBackwardKat<__half, int64_t>(stream);
+  cuembed::SetBackwardTuning(cuembed::BackwardTuning{0, 0, 0});
   HIP_OK(hipStreamDestroy(stream));
   if (g_failures) {
     std::fprintf(stderr, "%d known-answer checks failed\n", g_failures);

@@ -246,3 +246,93 @@ def test_per_sample_weights_gradient_extension(pyt, d):
     w3 = w1.detach().clone().requires_grad_(True)
     (pyt.cuemb_embedding(bag.weight.detach(), indices, offsets, w3) * up).sum().backward()
     assert torch.allclose(w3.grad, w2.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_ops_are_the_native_extension(pyt):
+    """The ops come from cuembed_amd/lib/libcuembed_pyt.so (TORCH_LIBRARY / TORCH_LIBRARY_IMPL in
+    cuembed_amd/csrc/torch_binding.cpp), like the reference's (cuembed_embedding.cu:169-190), not from
+    Python registrations; the shared object is mapped into this process."""
+    assert pyt.BACKEND == "native"
+    with open("/proc/self/maps") as f:
+        maps = f.read()
+    assert "libcuembed_pyt.so" in maps and "libcuembed_amd.so" in maps
+    for name in ("cuembed_embedding_forward", "cuembed_extract_row_ids_from_csr", "cuembed_transpose",
+                 "cuembed_embedding_backward", "cuembed_transpose_fixed_hotness", "cuembed_transpose_sample_ids"):
+        op = getattr(torch.ops.cuembed_pyt, name).default
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(op.name(), "CUDA")
+
+
+def test_ops_validate_like_the_reference_binding(pyt):
+    """AT_ASSERT in the reference (cuembed_embedding.cu:15-32) -> TORCH_CHECK here: Python exceptions,
+    never an abort, for CPU tensors, wrong dtypes and unsupported modes."""
+    table = torch.randn(50, 8, device="cuda")
+    idx = torch.randint(0, 50, (12,), device="cuda")
+    off = torch.arange(0, 13, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        torch.ops.cuembed_pyt.cuembed_embedding_forward(table, idx, off, None, "max")
+    with pytest.raises(RuntimeError):
+        torch.ops.cuembed_pyt.cuembed_embedding_forward(table.double(), idx, off, None, "sum")
+    with pytest.raises(RuntimeError):
+        torch.ops.cuembed_pyt.cuembed_embedding_forward(table, idx.float(), off, None, "sum")
+    with pytest.raises(RuntimeError):
+        torch.ops.cuembed_pyt.cuembed_embedding_forward(table, idx, off, torch.ones(12, device="cuda", dtype=torch.half), "sum")
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.cuembed_pyt.cuembed_embedding_forward(table.cpu(), idx.cpu(), off.cpu(), None, "sum")
+    with pytest.raises(RuntimeError):
+        torch.ops.cuembed_pyt.cuembed_transpose(idx, idx[:5], None)
+
+
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_fused_index_ops(pyt, idx_dtype):
+    """cuembed_transpose_fixed_hotness == extract + transpose (+ remap); cuembed_transpose_sample_ids ==
+    cuembed_transpose_bounded."""
+    B, H, k = 700, 9, 5000
+    idx = torch.randint(0, k, (B, H), device="cuda", dtype=idx_dtype)
+    w = torch.rand(B, H, device="cuda")
+    sid = (torch.arange(B * H, device="cuda") // H).to(idx_dtype)
+    for weights in (None, w):
+        flat_w = None if weights is None else weights.reshape(-1)
+        want = torch.ops.cuembed_pyt.cuembed_transpose_bounded(sid, idx.reshape(-1), flat_w, k)
+        got = torch.ops.cuembed_pyt.cuembed_transpose_fixed_hotness(idx, weights, k, True)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        assert torch.equal(got[3], torch.ops.cuembed_pyt.cuembed_compute_compressed_grad_indices(want[0]))
+        got2 = torch.ops.cuembed_pyt.cuembed_transpose_sample_ids(sid, idx.reshape(-1), flat_w, k)
+        assert all(torch.equal(a, b) for a, b in zip(got2, want))
+        none = torch.ops.cuembed_pyt.cuembed_transpose_fixed_hotness(idx, weights, k, False)
+        assert none[3].numel() == 0 and torch.equal(none[0], want[0])
+    # stable order == torch's stable sort
+    order = torch.sort(idx.reshape(-1), stable=True)
+    assert torch.equal(want[0], order.values) and torch.equal(want[1], sid[order.indices])
+
+
+def test_opcheck_schemas_and_fake_kernels(pyt):
+    """torch.library.opcheck: the registered schema, the fake (meta) kernel and the real kernel of every op
+    agree on output metadata -- what torch.compile relies on (reference: cuembed_pyt.py:55-77)."""
+    B, H, k, d = 64, 4, 300, 16
+    table = torch.randn(k, d, device="cuda")
+    idx = torch.randint(0, k, (B * H,), device="cuda")
+    off = torch.arange(0, B * H + 1, H, device="cuda")
+    w = torch.rand(B * H, device="cuda")
+    gy = torch.randn(B, d, device="cuda")
+    sid = torch.arange(B * H, device="cuda") // H
+    ops = torch.ops.cuembed_pyt
+    t_idx, t_sid, t_w = ops.cuembed_transpose_bounded(sid, idx, w, k)
+    remap = ops.cuembed_compute_compressed_grad_indices(t_idx)
+    nu = int(remap[-1].item()) + 1
+    checks = ["test_schema", "test_faketensor"]
+    for op, args in [
+            (ops.cuembed_embedding_forward, (table, idx, off, w, "sum")),
+            (ops.cuembed_embedding_forward, (table, idx, off, None, "mean")),
+            (ops.cuembed_extract_row_ids_from_csr, (off[:-1], B * H)),
+            (ops.cuembed_transpose, (sid, idx, w)),
+            (ops.cuembed_transpose, (sid, idx, None)),
+            (ops.cuembed_transpose_bounded, (sid, idx, None, k)),
+            (ops.cuembed_transpose_sample_ids, (sid, idx, w, k)),
+            (ops.cuembed_transpose_fixed_hotness, (idx.view(B, H), w.view(B, H), k, True)),
+            (ops.cuembed_transpose_fixed_hotness, (idx.view(B, H), None, k, False)),
+            (ops.cuembed_compute_compressed_grad_indices, (t_idx,)),
+            (ops.cuembed_embedding_backward, (gy, k, t_idx, t_sid, t_w)),
+            (ops.cuembed_embedding_backward_compressed, (gy, nu, t_idx, t_sid, remap, None)),
+            (ops.cuembed_embedding_forward_fixed, (table, idx.view(B, H), None, "concat")),
+            (ops.cuembed_embedding_weight_grad, (table, idx, off, gy))]:
+        torch.library.opcheck(op, args, test_utils=checks)
