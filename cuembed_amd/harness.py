@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# CUEMBED_HARNESS_LIB: load another build of the same source (the ASan/UBSan one, `make -C oracle asan`)
+# CUEMBED_HARNESS_LIB: load another build of the same source (the ASan/UBSan build of the host sanitizer target)
 _PATH = os.environ.get("CUEMBED_HARNESS_LIB") or os.path.join(_PKG, "lib", "libcuembed_harness.so")
 _h = None
 
