@@ -211,7 +211,7 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ s
   (void)samples_per_fill;
   // kScanBatch loads per thread are issued before the first is used: the walk is a dependent
   // chain of memory round trips otherwise (the stores below keep the compiler from overlapping them)
-  constexpr int kScanBatch = 8;
+  constexpr int kScanBatch = 32;   // a 65,536-lookup run is two batches per thread
   for (int base = lo + tid; base < hi; base += kScanBatch * kHotDetectThreads) {
     IndexT cur[kScanBatch], prev[kScanBatch];
 #pragma unroll

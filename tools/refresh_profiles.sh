@@ -46,16 +46,22 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_pipe_fetch" -- $PP > "
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_pipe_write" -- $PP >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_pipe_tcc" -- $PP >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$O/pmc_pipe.log" 2>&1
+# the run-aware backward (extension) through the same passes: its traffic is reported next to the plain one
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_ra_fetch" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_ra_write" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/pmc_ra_trace" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
+python tools/rocprof_summary.py "$O/pmc_ra_trace" > "$O/pipeline_c2_run_aware_kernel_trace_stats.txt" 2>/dev/null
 cd "$R"
 python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
   --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
-  --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" --out "$O/traffic_c2.json" > /dev/null
+  --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" \
+  --run-aware-fetch "$O/pmc_ra_fetch" --run-aware-write "$O/pmc_ra_write" --out "$O/traffic_c2.json" > /dev/null
 {
-  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc; do
+  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc pmc_ra_fetch pmc_ra_write; do
     echo "#### $d"; python tools/rocprof_summary.py "$O/$d" 2>/dev/null
   done
 } > "$O/pmc_passes.txt"
-rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_*
+rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_ra_*
 # the bench line again, now with roofline.traffic from the traffic file measured above
 cp "$O/traffic_c2.json" "$R/profiles/traffic_c2.json"
 python bench.py > "$O/bench_c2_line.json" 2>> "$O/bench.err"

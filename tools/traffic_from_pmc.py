@@ -72,7 +72,7 @@ def entry(fetch_kb, write_kb, launches, kernel):
 def main():
     p = argparse.ArgumentParser()
     for k in ("forward-fetch", "forward-write", "forward-tcc", "pipeline-fetch", "pipeline-write",
-              "pipeline-tcc", "pipeline-trace"):
+              "pipeline-tcc", "pipeline-trace", "run-aware-fetch", "run-aware-write"):
         p.add_argument("--" + k)
     p.add_argument("--iters", type=int, required=True, help="launches per pattern in the forward passes")
     p.add_argument("--expected-unique-read-bytes", type=int, default=65536 * 64 * 512)
@@ -132,6 +132,19 @@ def main():
             for name, v in tr.items():
                 if "SegmentedScatterAddKernel" in name:
                     K["backward_c4"]["kernel_ms_profiled"] = round(avg(v) / 1e6, 5)
+    if a.run_aware_fetch and a.run_aware_write:
+        # EmbeddingBackwardRunAware: detection + chunk sums + the segmented kernel without the hot blocks
+        rf, rw = read_counters(a.run_aware_fetch), read_counters(a.run_aware_write)
+        calls = max(len(pick(rf, "SegmentedScatterAddKernel", "FETCH_SIZE")), 1)
+        parts = {}
+        total_f = total_w = 0.0
+        for tag in ("HotRunDetect", "HotRowChunkSum", "SegmentedScatterAdd", "ZeroSharedAndTailRows"):
+            f_, w_ = sum(pick(rf, tag, "FETCH_SIZE")) / calls, sum(pick(rw, tag, "WRITE_SIZE")) / calls
+            parts[tag] = entry(f_, w_, calls, tag + "Kernel")
+            total_f += f_
+            total_w += w_
+        K["backward_c4_run_aware"] = entry(total_f, total_w, calls, "all kernels of one EmbeddingBackwardRunAware call")
+        K["backward_c4_run_aware"]["parts"] = parts
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
         f.write("\n")
