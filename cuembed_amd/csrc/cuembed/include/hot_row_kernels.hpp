@@ -211,7 +211,9 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ s
   (void)samples_per_fill;
   // kScanBatch loads per thread are issued before the first is used: the walk is a dependent
   // chain of memory round trips otherwise (the stores below keep the compiler from overlapping them)
-  constexpr int kScanBatch = 32;   // a 65,536-lookup run is two batches per thread
+  // (8, not more: with 32 the detection itself is no faster, and the SEGMENTED kernel of the same
+  // translation unit measured 0.194 -> 0.220 ms -- same source, different code placement)
+  constexpr int kScanBatch = 8;
   for (int base = lo + tid; base < hi; base += kScanBatch * kHotDetectThreads) {
     IndexT cur[kScanBatch], prev[kScanBatch];
 #pragma unroll

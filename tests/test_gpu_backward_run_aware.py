@@ -165,3 +165,21 @@ def test_default_heuristics_at_a_million_lookups(ce, oracle):
     assert (np.bincount(ti) > 8192).sum() >= 3
     _check(ce, oracle, ELEMS[1], ti, ts, tw, B, W, ncat, compressed=True, weighted=False)
     _check(ce, oracle, ELEMS[0], ti, ts, tw, B, W, ncat, compressed=False, weighted=True)
+
+
+def test_run_aware_bf16(ce, oracle, tuning):
+    """bfloat16 gradients through the hot path (fp32 partial sums, bf16 flush atomics): equal to the plain
+    entry point and, as fp32 values, to an fp32 oracle run on the same exactly-representable data."""
+    tuning(hot_stride=256)
+    W, B, H, ncat = 128, 3000, 12, 250
+    ti, ts, tw = _coo(oracle, ncat, W, B, H, 1.15, np.int32)
+    gy32 = (np.mod(oracle.allocate_grad_y(B * W).reshape(B, W), 3) - 1).astype(np.float32)
+    gy = torch.from_numpy(gy32).cuda().bfloat16()
+    remap = oracle.compute_compressed_grad_indices(ti)
+    nu = int(remap[-1]) + 1
+    want, winv = oracle.embedding_backward(gy32, W, nu, ti, ts, remap)
+    assert np.abs(want).max() < 256                      # integers below 2^8 are exact in bf16
+    plain, _ = ce.embedding_backward(gy, nu, dev(ti), dev(ts), dev(remap))
+    got, ginv = ce.embedding_backward(gy, nu, dev(ti), dev(ts), dev(remap), run_aware=True)
+    assert torch.equal(got, plain)
+    assert np.array_equal(got.float().cpu().numpy(), want) and np.array_equal(host(ginv), winv)
