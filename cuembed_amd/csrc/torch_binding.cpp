@@ -123,6 +123,21 @@ at::Tensor cuembed_extract_row_ids_from_csr_op(const at::Tensor& offsets, const 
   return row_ids;
 }
 
+// Extension: the same for an offsets tensor that already holds batch + 1 entries (what callers of
+// cuembed_embedding_forward have anyway): no copy, one launch.
+at::Tensor cuembed_extract_row_ids_from_offsets_op(const at::Tensor& offsets, const int64_t nnz) {
+  CheckGpu(offsets, "offsets");
+  const int off = IndexCode(offsets, "offsets");
+  TORCH_CHECK(offsets.numel() >= 1, "cuembed_pyt: offsets must hold batch_size + 1 entries");
+  const at::DeviceGuard guard(offsets.device());
+  const at::Tensor o = offsets.contiguous();
+  const int64_t batch = o.numel() - 1;
+  at::Tensor row_ids = at::empty({nnz}, o.options());
+  if (batch > 0 && nnz > 0)
+    ::cuembed_extract_row_ids_from_csr(Ptr(o), off, static_cast<int>(batch), off, MutPtr(row_ids), CurrentStream(o));
+  return row_ids;
+}
+
 std::tuple<at::Tensor, at::Tensor, at::Tensor> TransposeImpl(const at::Tensor& rows, const at::Tensor& cols,
                                                              const at::Tensor& weights, const int index_bits,
                                                              const int row_bits) {
@@ -349,6 +364,7 @@ TORCH_LIBRARY(cuembed_pyt, m) {
       "cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices, Tensor "
       "transpose_sample_ids, Tensor transpose_weights) -> Tensor");
   // this library's extensions
+  m.def("cuembed_extract_row_ids_from_offsets(Tensor offsets, int nnz) -> Tensor");
   m.def("cuembed_transpose_bounded(Tensor rows, Tensor cols, Tensor weights, int num_categories) -> (Tensor, Tensor, Tensor)");
   m.def(
       "cuembed_transpose_sample_ids(Tensor sample_ids, Tensor indices, Tensor weights, int num_categories) -> "
@@ -369,6 +385,7 @@ TORCH_LIBRARY_IMPL(cuembed_pyt, CUDA, m) {  // HIP tensors use the CUDA dispatch
   m.impl("cuembed_transpose", cuembed_transpose_op);
   m.impl("cuembed_embedding_forward", cuembed_embedding_forward_op);
   m.impl("cuembed_embedding_backward", cuembed_embedding_backward_op);
+  m.impl("cuembed_extract_row_ids_from_offsets", cuembed_extract_row_ids_from_offsets_op);
   m.impl("cuembed_transpose_bounded", cuembed_transpose_bounded_op);
   m.impl("cuembed_transpose_sample_ids", cuembed_transpose_sample_ids_op);
   m.impl("cuembed_transpose_fixed_hotness", cuembed_transpose_fixed_hotness_op);

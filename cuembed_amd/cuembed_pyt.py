@@ -43,6 +43,7 @@ def _define_python_ops():
     _lib = torch.library.Library("cuembed_pyt", "DEF")
     _lib.define("cuembed_extract_row_ids_from_csr(Tensor offsets, int nnz) ->Tensor")
     _lib.define("cuembed_transpose(Tensor rows, Tensor cols, Tensor weights) -> (Tensor, Tensor, Tensor)")
+    _lib.define("cuembed_extract_row_ids_from_offsets(Tensor offsets, int nnz) -> Tensor")
     _lib.define("cuembed_transpose_bounded(Tensor rows, Tensor cols, Tensor weights, int num_categories)"
                 " -> (Tensor, Tensor, Tensor)")
     _lib.define("cuembed_transpose_sample_ids(Tensor sample_ids, Tensor indices, Tensor weights, int num_categories)"
@@ -61,6 +62,7 @@ def _define_python_ops():
                 " str mode) -> Tensor")
     _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
                 " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
+    _lib.impl("cuembed_extract_row_ids_from_offsets", _extract_closed_impl, "CUDA")
     _lib.impl("cuembed_transpose_sample_ids", _transpose_sample_ids_impl, "CUDA")
     _lib.impl("cuembed_transpose_fixed_hotness", _transpose_fixed_impl, "CUDA")
     _lib.impl("cuembed_embedding_weight_grad", _weight_grad_impl, "CUDA")
@@ -116,6 +118,12 @@ def _extract_impl(offsets, nnz):
     # explicit from `nnz`, which is correct for the sliced AND the full offsets tensor.
     closed = torch.cat([offsets.reshape(-1), torch.tensor([nnz], dtype=offsets.dtype, device=offsets.device)])
     return _ops.extract_row_ids_from_csr(closed, nnz=nnz, dtype=offsets.dtype, batch_size=offsets.numel())
+
+
+def _extract_closed_impl(offsets, nnz):
+    _require(offsets.is_cuda and offsets.dtype in _INTS, "offsets must be int tensors on the GPU")
+    return _ops.extract_row_ids_from_csr(offsets.contiguous(), nnz=nnz, dtype=offsets.dtype,
+                                         batch_size=offsets.numel() - 1)
 
 
 def _transpose_bounded_impl(rows, cols, weights, num_categories):
@@ -232,8 +240,9 @@ def cuembed_backward(ctx, out_grad):
     nnz = idx.size(0)
     if getattr(ctx, "sparse_grad", False):
         return _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz)
-    # equivalent of nn.EmbeddingBag(include_last_offset=True)
-    sample_ids = cuembed_extract_row_ids_from_csr(offsets[:-1], nnz)
+    # equivalent of nn.EmbeddingBag(include_last_offset=True).  (The reference slices offsets[:-1] for its
+    # op, cuembed_pyt.py:23; the saved tensor already has the closing entry, so no copy is needed.)
+    sample_ids = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_offsets(offsets, nnz)
     transpose_indices, transpose_sample_ids, transpose_weights = cuembed_transpose_sample_ids(
         sample_ids, idx, weights, ctx.num_categories)
     if transpose_weights.numel() == 0:  # forward ran without weights
@@ -252,7 +261,7 @@ def _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz):
         return (torch.sparse_coo_tensor(torch.empty((1, 0), dtype=torch.int64, device=out_grad.device),
                                         torch.empty((0, width), dtype=out_grad.dtype, device=out_grad.device),
                                         size=(ctx.num_categories, width)), None, None, None)
-    sample_ids = cuembed_extract_row_ids_from_csr(offsets[:-1], nnz)
+    sample_ids = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_offsets(offsets, nnz)
     t_idx, t_sid, t_w = cuembed_transpose_sample_ids(sample_ids, idx, weights, ctx.num_categories)
     if t_w.numel() == 0:
         t_w = None
@@ -346,6 +355,11 @@ def _(params, indices, weights=None, mode="sum"):
 
 
 @torch.library.register_fake("cuembed_pyt::cuembed_extract_row_ids_from_csr")
+def _(offsets, nnz):
+    return torch.empty((nnz,), device=offsets.device, dtype=offsets.dtype)
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_extract_row_ids_from_offsets")
 def _(offsets, nnz):
     return torch.empty((nnz,), device=offsets.device, dtype=offsets.dtype)
 

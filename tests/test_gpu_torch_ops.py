@@ -300,6 +300,10 @@ def test_fused_index_ops(pyt, idx_dtype):
         assert all(torch.equal(a, b) for a, b in zip(got2, want))
         none = torch.ops.cuembed_pyt.cuembed_transpose_fixed_hotness(idx, weights, k, False)
         assert none[3].numel() == 0 and torch.equal(none[0], want[0])
+    # the closed-offsets row-id op == the reference-shaped one on the slice
+    off = torch.arange(0, B * H + 1, H, device="cuda", dtype=idx_dtype)
+    assert torch.equal(torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_offsets(off, B * H), sid)
+    assert torch.equal(torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_csr(off[:-1], B * H), sid)
     # stable order == torch's stable sort
     order = torch.sort(idx.reshape(-1), stable=True)
     assert torch.equal(want[0], order.values) and torch.equal(want[1], sid[order.indices])
@@ -324,6 +328,7 @@ def test_opcheck_schemas_and_fake_kernels(pyt):
             (ops.cuembed_embedding_forward, (table, idx, off, w, "sum")),
             (ops.cuembed_embedding_forward, (table, idx, off, None, "mean")),
             (ops.cuembed_extract_row_ids_from_csr, (off[:-1], B * H)),
+            (ops.cuembed_extract_row_ids_from_offsets, (off, B * H)),
             (ops.cuembed_transpose, (sid, idx, w)),
             (ops.cuembed_transpose, (sid, idx, None)),
             (ops.cuembed_transpose_bounded, (sid, idx, None, k)),
