@@ -64,6 +64,14 @@ def main():
                                   "hot_lookups": int((~keep).sum()),
                                   "hot_lookup_fraction": round(float((~keep).float().mean()), 4),
                                   "backward_ms_without_hot_runs": round(ms, 5)})
+    # What would perfect L2 locality of the gathers buy?  The same COO with every sample id folded into
+    # the first 2048 grad_y rows (1 MB: always L2-resident): everything but the gather misses stays.
+    folded = (ts % 2048).contiguous()
+    ms, _ = timed(ti, folded)
+    out["full_with_l2_resident_grad_y_ms"] = round(ms, 5)
+    keep = per_lookup <= 8192
+    ms, _ = timed(ti[keep].contiguous(), folded[keep].contiguous())
+    out["cold_part_with_l2_resident_grad_y_ms"] = round(ms, 5)
     out["plain_by_column_slices"] = []
     for sl in (1, 2, 4, 8):
         ce.set_backward_tuning(column_slices=sl)
