@@ -85,6 +85,29 @@ __device__ __forceinline__ __bf16 ShuffleElem(__bf16 v, int src, int width) {
   return __builtin_bit_cast(__bf16, static_cast<unsigned short>(bits));
 }
 
+//! Row ids and row offsets as the gather kernels compute them.  A row offset is id * width:
+//! written naively with a sign-extended 32-bit id and an `int` width that is a full 64 x 64-bit
+//! multiply -- three integer multiplies (quarter rate) and three more instructions PER LOOKUP,
+//! more issue time than the eight converts and four packed adds that pool the row.  Ids are
+//! non-negative, so a 32-bit id is ZERO-extended and the width enters as an unsigned 32-bit value:
+//! the compiler then emits one v_mad_u64_u32 (32 x 32 -> 64 plus the base).  64-bit ids keep
+//! the general multiply (they may address outside the table on purpose: TranslateIndicesForRowCache).
+template <typename IndexT>
+__device__ __forceinline__ int64_t WidenIndex(const IndexT r) {
+  if constexpr (sizeof(IndexT) == 4) return static_cast<int64_t>(static_cast<uint32_t>(r));
+  else return static_cast<int64_t>(r);
+}
+__device__ __forceinline__ int64_t RowElems(const int64_t r, const int width) {
+  return r * static_cast<int64_t>(static_cast<uint32_t>(width));
+}
+//! base + r * width elements, computed in BYTES so that scaling by the element size and adding the
+//! base fold into the same v_mad_u64_u32 (id x row_bytes + base: one instruction per lookup).
+template <typename ElemT>
+__device__ __forceinline__ const ElemT* RowPtr(const ElemT* base, const int64_t r, const int width) {
+  const int64_t row_bytes = static_cast<int64_t>(static_cast<uint32_t>(width) * static_cast<uint32_t>(sizeof(ElemT)));
+  return reinterpret_cast<const ElemT*>(reinterpret_cast<const char*>(base) + r * row_bytes);
+}
+
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
 #if defined(CUEMBED_TUNE_ROW_LOAD_NT)   // tools/tune_forward.py --policies: rejected, see DESIGN.md
@@ -170,7 +193,7 @@ struct RowPool {
           for (int u = 0; u < kUnroll; ++u) {
             const int64_t r = index_at(base + u);
             if constexpr (kWeighted) w[u] = weight_at(base + u);
-            row[u] = LoadPack<ElemT, N>(lane_base + r * width);
+            row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
           }
         };
         auto consume = [&](Pack<ElemT, N>(&row)[kUnroll], ElemT(&w)[kUnroll]) {
@@ -207,7 +230,7 @@ struct RowPool {
       for (int u = 0; u < kUnroll; ++u) {
         const int64_t r = index_at(j + u);
         if constexpr (kWeighted) w[u] = weight_at(j + u);
-        row[u] = LoadPack<ElemT, N>(lane_base + r * width);
+        row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -226,7 +249,7 @@ struct RowPool {
         if (u < rem) {
           const int64_t r = index_at(j + u);
           if constexpr (kWeighted) w[u] = weight_at(j + u);
-          row[u] = LoadPack<ElemT, N>(lane_base + r * width);
+          row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -299,7 +322,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     const IndexT* my_idx = stage_idx + slot * num_hots;
     const ElemT* my_w = stage_w + slot * num_hots;
     pool.template Gather<kUnroll, kPipelined>(lane_base, width, hot,
-                [&](int j) { return static_cast<int64_t>(my_idx[j]); },
+                [&](int j) { return WidenIndex(my_idx[j]); },
                 [&](int j) { return my_w[j]; });
   } else {
     if (sample >= batch) return;
@@ -333,7 +356,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
         }
         const int n = (hot - c < group) ? hot - c : group;
         pool.template Gather<kUnroll, kPipelined>(lane_base, width, n,
-                    [&](int j) { return static_cast<int64_t>(__shfl(cur_i, j, group)); },
+                    [&](int j) { return WidenIndex(__shfl(cur_i, j, group)); },
                     [&](int j) { return ShuffleElem(cur_w, j, group); });
         cur_i = next_i;
         cur_w = next_w;
@@ -342,7 +365,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
       // ---- any row split: every lane reads its sample's index straight from global
       // memory (one address per sample: a broadcast load that mostly hits L1).
       pool.template Gather<kUnroll, kPipelined>(lane_base, width, hot,
-                  [&](int j) { return static_cast<int64_t>(my_idx[j]); },
+                  [&](int j) { return WidenIndex(my_idx[j]); },
                   [&](int j) { return my_w[j]; });
     }
   }
@@ -430,7 +453,7 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
   RowPool<ElemT, AccT, N, kWeighted> pool;
   pool.template Gather<kForwardUnroll, false>(
       table + static_cast<int64_t>(lane_x) * N, width, j1 - j0,
-      [&](int j) { return static_cast<int64_t>(my_idx[j]); }, [&](int j) { return my_w[j]; });
+      [&](int j) { return WidenIndex(my_idx[j]); }, [&](int j) { return my_w[j]; });
 
   // ---- fold the slices that live in the same wavefront (lanes < 64 only) ----
   const int tid = slice * lanes + lane_x;
@@ -571,11 +594,11 @@ WeightGradKernel(const ElemT* __restrict__ table,
       if (j0 + kForwardUnroll <= hot) {
 #pragma unroll
         for (int u = 0; u < kForwardUnroll; ++u)
-          row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(ahead[u]) * width);
+          row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, WidenIndex(ahead[u]), width));
       } else {
 #pragma unroll
         for (int u = 0; u < kForwardUnroll; ++u)
-          if (j0 + u < hot) row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(ahead[u]) * width);
+          if (j0 + u < hot) row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, WidenIndex(ahead[u]), width));
       }
     };
     request_ids(0);
@@ -632,7 +655,7 @@ WeightGradKernel(const ElemT* __restrict__ table,
 #pragma unroll
       for (int u = 0; u < kForwardUnroll; ++u) {
         if (u < nb)
-          row[u] = LoadPack<ElemT, N>(table + static_cast<int64_t>(my_idx[j0 + u]) * width +
+          row[u] = LoadPack<ElemT, N>(table + RowElems(WidenIndex(my_idx[j0 + u]), width) +
                                       static_cast<int64_t>(c) * N);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -685,7 +708,7 @@ GatherConcatKernel(const ElemT* __restrict__ table,
     Pack<ElemT, N> row[kForwardUnroll];
 #pragma unroll
     for (int u = 0; u < kForwardUnroll; ++u) {
-      if (j + u < num_hots) row[u] = LoadPack<ElemT, N>(lane_base + static_cast<int64_t>(ahead[u]) * width);
+      if (j + u < num_hots) row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, WidenIndex(ahead[u]), width));
     }
     request_ids(j + kForwardUnroll);
     __builtin_amdgcn_sched_barrier(0);

@@ -279,7 +279,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
           part_flags[seg] |= continues ? (kPartTail | (run_shared ? kPartWhole : 0)) : kPartHead;
         }
       } else {
-        FlushStore<GradT, N>(lane_dst + row * width, acc);
+        FlushStore<GradT, N>(lane_dst + RowElems(row, width), acc);
       }
 #pragma unroll
       for (int e = 0; e < N; ++e) acc[e] = 0.f;
@@ -287,17 +287,17 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     };
 
     int i = 0;
-    int64_t row_cur = static_cast<int64_t>(my_rows[0]);
+    int64_t row_cur = WidenIndex(my_rows[0]);   // zero-extended like every id here (the -1 sentinels stay distinct)
     for (; i + kBackwardUnroll <= count; i += kBackwardUnroll) {
       Pack<GradT, N> g[kBackwardUnroll];
       GradT w[kBackwardUnroll];
       int64_t row_next[kBackwardUnroll];
 #pragma unroll
       for (int u = 0; u < kBackwardUnroll; ++u) {
-        const int64_t sid = static_cast<int64_t>(my_sids[i + u]);
+        const int64_t sid = WidenIndex(my_sids[i + u]);   // staged as int32, non-negative
         if constexpr (kWeighted) w[u] = my_w[i + u];
-        row_next[u] = static_cast<int64_t>(my_rows[i + u + 1]);
-        g[u] = LoadPack<GradT, N>(lane_src + sid * width);
+        row_next[u] = WidenIndex(my_rows[i + u + 1]);
+        g[u] = LoadPack<GradT, N>(RowPtr(lane_src, sid, width));
       }
 #pragma unroll
       for (int u = 0; u < kBackwardUnroll; ++u) {
@@ -308,9 +308,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
       }
     }
     for (; i < count; ++i) {
-      const int64_t sid = static_cast<int64_t>(my_sids[i]);
-      const Pack<GradT, N> g = LoadPack<GradT, N>(lane_src + sid * width);
-      const int64_t row_next = static_cast<int64_t>(my_rows[i + 1]);
+      const int64_t sid = WidenIndex(my_sids[i]);
+      const Pack<GradT, N> g = LoadPack<GradT, N>(RowPtr(lane_src, sid, width));
+      const int64_t row_next = WidenIndex(my_rows[i + 1]);
       float wf = 1.f;
       if constexpr (kWeighted) wf = static_cast<float>(my_w[i]);
       AccumulateRow<GradT, N, kWeighted>(acc, g, wf);
