@@ -50,7 +50,7 @@ rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_ra_fetch" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_ra_write" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/pmc_ra_trace" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
-python tools/rocprof_summary.py "$O/pmc_ra_trace" > "$O/pipeline_c2_run_aware_kernel_trace_stats.txt" 2>/dev/null
+python "$R/tools/rocprof_summary.py" "$O/pmc_ra_trace" > "$O/pipeline_c2_run_aware_kernel_trace_stats.txt" 2>/dev/null
 cd "$R"
 python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
   --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
