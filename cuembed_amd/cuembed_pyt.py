@@ -235,9 +235,20 @@ def cuembed_forward(params, idx, offsets, weights):
     return cuembed_embedding_forward(params, idx, offsets, weights, mode="sum")
 
 
+def _narrow_for_index_work(idx, offsets, num_categories):
+    """The reference's binding takes int64 indices (cuembed_embedding.cu:18-23).  When the table has fewer
+    than 2^31 rows and the batch fewer than 2^31 lookups, the index work of the backward (row ids, radix
+    sort, remap, scatter-add) runs on int32 copies: half the bytes through every sorting pass
+    (transpose + remap at C4: 0.148 -> 0.124 ms, scatter 0.29 -> 0.27 ms, for one 17 MB conversion)."""
+    if idx.dtype == torch.int64 and num_categories < 2 ** 31 and idx.numel() < 2 ** 31:
+        return idx.to(torch.int32), (None if offsets is None else offsets.to(torch.int32))
+    return idx, offsets
+
+
 def cuembed_backward(ctx, out_grad):
     idx, offsets, weights = ctx.saved_tensors
     nnz = idx.size(0)
+    idx, offsets = _narrow_for_index_work(idx, offsets, ctx.num_categories)
     if getattr(ctx, "sparse_grad", False):
         return _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz)
     # equivalent of nn.EmbeddingBag(include_last_offset=True).  (The reference slices offsets[:-1] for its
@@ -322,6 +333,7 @@ class _CuEmbFixed(torch.autograd.Function):
     def backward(ctx, out_grad):
         idx, weights = ctx.saved_tensors
         batch, hot = idx.shape
+        idx, _ = _narrow_for_index_work(idx, None, ctx.num_categories)
         if ctx.mode == "concat":   # every lookup has its own gradient row: sample id = position
             y = out_grad.reshape(batch * hot, -1)
             layout = idx.contiguous().view(batch * hot, 1)
