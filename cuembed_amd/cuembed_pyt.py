@@ -239,8 +239,9 @@ def _narrow_for_index_work(idx, offsets, num_categories):
     """The reference's binding takes int64 indices (cuembed_embedding.cu:18-23).  When the table has fewer
     than 2^31 rows and the batch fewer than 2^31 lookups, the index work of the backward (row ids, radix
     sort, remap, scatter-add) runs on int32 copies: half the bytes through every sorting pass
-    (transpose + remap at C4: 0.148 -> 0.124 ms, scatter 0.29 -> 0.27 ms, for one 17 MB conversion)."""
-    if idx.dtype == torch.int64 and num_categories < 2 ** 31 and idx.numel() < 2 ** 31:
+    (C4 step 0.624 -> 0.597 ms for one 17 MB conversion; small batches are launch-bound and the two extra
+    conversion launches cost more than they save -- B = 1024: 0.199 -> 0.228 ms -- hence the size gate)."""
+    if idx.dtype == torch.int64 and num_categories < 2 ** 31 and (1 << 18) <= idx.numel() < 2 ** 31:
         return idx.to(torch.int32), (None if offsets is None else offsets.to(torch.int32))
     return idx, offsets
 
