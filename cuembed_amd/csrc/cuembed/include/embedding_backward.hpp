@@ -179,7 +179,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
     int fill_shift;
     HotFillDivisor(hot.samples_per_fill, &fill_magic, &fill_shift);
     HotRunDetectKernel<IndexT><<<multiples, kHotDetectThreads, 0, stream>>>(
-        rows, sample_ids, static_cast<int>(nnz), hot.stride, block_len, hot.samples_per_fill, fill_magic, fill_shift,
+        rows, sample_ids, static_cast<int>(nnz), hot.stride, block_len, fill_magic, fill_shift,
         hot.num_fills(), table, bounds);
     auto chunk_kernel = weights != nullptr ? HotRowChunkSumKernel<GradT, IndexT, N, true>
                                            : HotRowChunkSumKernel<GradT, IndexT, N, false>;

@@ -41,14 +41,13 @@ constexpr int kHotPieces = 2;              //!< partial rows per (chunk, run): l
 constexpr int kHotSplitLookups = 96;       //!< ... when the run has more than this many lookups per chunk on average
 constexpr int kHotChunkBytes = 128 * 1024; //!< grad_y bytes staged in LDS per workgroup (of 160 KiB per CU)
 constexpr int kHotThreads = 1024;
-constexpr int kHotWaves = kHotThreads / 64;
 constexpr int kHotMaxChunks = 1024;        //!< bounds the workspace; more samples -> several chunks per workgroup
 constexpr int kHotDetectThreads = 1024;    //!< only the few workgroups that find a hot run use them all
 constexpr int kHotBatch = 8;               //!< LDS row reads a wavefront keeps in flight
 
 struct HotRun {
   int row;          //!< output row (dense id in a compressed gradient, table row otherwise)
-  int begin;        //!< position of the run's first lookup
+  int begin;        //!< position of a lookup of the run (= first_block * block_len): where its table row id is read
   int first_block;  //!< nz-blocks [first_block, end_block) of the segmented kernel lie inside the run ...
   int end_block;    //!< ... and are summed by HotRowChunkSumKernel instead
 };
@@ -106,7 +105,7 @@ __host__ __device__ inline int HotPiecesOf(const HotRun& r, const int block_len,
 template <typename IndexT>
 __global__ void __launch_bounds__(kHotDetectThreads)
 HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ sample_ids, const int nnz,
-                   const int stride, const int block_len, const int samples_per_fill, const unsigned fill_magic,
+                   const int stride, const int block_len, const unsigned fill_magic,
                    const int fill_shift, const int num_fills, HotRunTable* __restrict__ table,
                    int* __restrict__ bounds) {
   __shared__ int mult[kHotMaxMultiples + 1];
@@ -208,7 +207,6 @@ HotRunDetectKernel(const IndexT* __restrict__ rows, const IndexT* __restrict__ s
   auto fill_of = [&](const IndexT sid) {
     return static_cast<int>((static_cast<unsigned long long>(static_cast<unsigned>(sid)) * fill_magic) >> fill_shift);
   };
-  (void)samples_per_fill;
   // kScanBatch loads per thread are issued before the first is used: the walk is a dependent
   // chain of memory round trips otherwise (the stores below keep the compiler from overlapping them)
   // (8, not more: with 32 the detection itself is no faster, and the SEGMENTED kernel of the same
