@@ -1,0 +1,56 @@
+"""bench.py's JSON contract, checked without a GPU: the roofline block is built from measured traffic
+(profiles/traffic_c2.json, written by tools/traffic_from_pmc.py), every fraction of the HBM peak is
+<= 1 by construction, and application (algorithmic) GB/s is never presented as an HBM rate."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_traffic_file_schema_and_calibration():
+    with open(os.path.join(ROOT, "profiles", "traffic_c2.json")) as f:
+        t = json.load(f)
+    assert "tools/traffic_from_pmc.py" in t["generated_by"]
+    assert t["fetch_correction"] == 2.0 and t["write_correction"] == 1.0
+    k = t["kernels"]
+    for name in ("forward_c2", "forward_c2_alpha0", "calibration_unique_rows", "backward_c4", "transpose_c4"):
+        assert k[name]["hbm_bytes_per_launch"] > 0, name
+    # the FETCH_SIZE x 2 correction is re-checked on a launch whose read volume is known exactly
+    assert abs(k["calibration_unique_rows"]["measured_over_expected"] - 1.0) < 0.02
+    # power-law: fabric traffic far below the algorithmic bytes; uniform: about equal to them
+    alg = 2 * 65536 * 65 * 256
+    assert k["forward_c2"]["hbm_bytes_per_launch"] < 0.5 * alg
+    assert 0.9 * alg < k["forward_c2_alpha0"]["hbm_bytes_per_launch"] < 1.1 * alg
+
+
+def test_roofline_entries_are_fractions():
+    import bench
+    traffic = bench.load_traffic("c2")
+    assert traffic["forward_c2"]["hbm_bytes_per_launch"] > 0 and "_source" in traffic
+    cfg = dict(bench.WORKLOADS["c2"])
+    alg = bench.algorithmic_bytes(cfg, None)
+    assert alg == 2181038080
+    result = {"config": {"name": "c2"},
+              "roofline": {"algorithmic_bytes_per_launch": alg},
+              "extras": {"alpha0_uniform_back_to_back": {"ms": 0.36, "GBps": alg / 0.36e-3 / 1e9},
+                         "backward_compressed_ms": 0.268, "backward_unique_rows": 572029,
+                         "transpose_and_remap_ms": 0.129}}
+    bench.finish_roofline(result, traffic, cfg)
+    rl = result["roofline"]
+    comp = rl["hbm_bound_companion"]
+    assert comp["bound"] == "hbm" and 0.5 < comp["frac"] <= 1.0
+    assert abs(comp["achieved"] - comp["traffic"] / 0.36e-3 / 1e9) < 1.0
+    kinds = [o["kernel"] for o in rl["other_kernels"]]
+    assert any("EmbeddingBackward" in x for x in kinds) and any("Transpose" in x for x in kinds)
+    for o in rl["other_kernels"]:
+        assert 0.0 < o["frac"] <= 1.0 and o["peak"] == bench.HBM_PEAK_GBPS
+        assert o["traffic"] >= o["algorithmic_bytes_per_launch"] * 0.9      # traffic is measured, not assumed
+    # the headline fraction: measured bytes over a plausible kernel time stays below 1
+    fwd = traffic["forward_c2"]["hbm_bytes_per_launch"]
+    assert fwd / 0.136e-3 / 1e9 / bench.HBM_PEAK_GBPS < 1.0
+    # while the application figure exceeds the peak -- which is why it is not divided by it anywhere
+    assert alg / 0.136e-3 / 1e9 > bench.HBM_PEAK_GBPS
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "pct_of_hbm_peak" not in src
