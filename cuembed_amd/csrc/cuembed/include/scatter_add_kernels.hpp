@@ -214,23 +214,36 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   int* part_flags = reinterpret_cast<int*>(lds_raw + off);         // [seg]
 
   {
-    // every segment's lanes stage their own segment (no index arithmetic beyond a stride)
-    int32_t* seg_rows = st_rows + seg * row_stride;
-    const int64_t seg_begin = block_begin + static_cast<int64_t>(seg) * segment_len;
-    for (int i = lane_x; i < segment_len; i += lanes) {
-      const int64_t g = seg_begin + i;
-      seg_rows[1 + i] = g < nnz ? static_cast<int32_t>(rows[g]) : -1;
+    // The workgroup's COO triples are ONE contiguous range of the sorted arrays: all threads copy it
+    // with fully coalesced loads (consecutive threads, consecutive lookups) into the per-segment
+    // padded slices.  (Round 1 let the lanes of a segment stage their own segment: with 4 column
+    // slices that is 8 lanes x 4 bytes per request, eight scattered 32-byte pieces per wavefront
+    // load, paid once per slice -- 0.03 ms of the kernel at the C4 shape.)
+    const int tid = seg * lanes + lane_x;
+    const int threads = lanes * segments_per_block;
+    for (int e = tid; e < block_len; e += threads) {
+      const int64_t g = block_begin + e;
+      const int s = e / segment_len;
+      const int i = e - s * segment_len;
+      st_rows[s * row_stride + 1 + i] = g < nnz ? static_cast<int32_t>(rows[g]) : -1;
       if (g < nnz) {
-        st_sids[seg * sid_stride + i] = static_cast<int32_t>(sample_ids[g]);  // (non-temporal: 6-20 % slower)
-        if constexpr (kWeighted) st_w[seg * w_stride + i] = weights[g];
+        st_sids[s * sid_stride + i] = static_cast<int32_t>(sample_ids[g]);  // (non-temporal: 6-20 % slower)
+        if constexpr (kWeighted) st_w[s * w_stride + i] = weights[g];
       }
     }
-    if (lane_x == 0) {
-      seg_rows[0] = (seg_begin > 0 && seg_begin - 1 < nnz) ? static_cast<int32_t>(rows[seg_begin - 1]) : -1;
-      const int64_t after = seg_begin + segment_len;
-      seg_rows[segment_len + 1] = after < nnz ? static_cast<int32_t>(rows[after]) : -1;
-    }
     if (lane_x == 0) part_flags[seg] = 0;
+    __syncthreads();
+    // the lookup before and after every segment: a neighbour's staged id, or -- at the two ends of
+    // the workgroup's range -- one more element of the sorted array (-1 outside it)
+    if (lane_x == 0) {
+      int32_t* seg_rows = st_rows + seg * row_stride;
+      const int64_t before = block_begin - 1, after = block_begin + block_len;
+      seg_rows[0] = seg > 0 ? st_rows[(seg - 1) * row_stride + segment_len]
+                            : ((before >= 0 && before < nnz) ? static_cast<int32_t>(rows[before]) : -1);
+      seg_rows[segment_len + 1] = seg + 1 < segments_per_block
+                                      ? st_rows[(seg + 1) * row_stride + 1]
+                                      : (after < nnz ? static_cast<int32_t>(rows[after]) : -1);
+    }
   }
   __syncthreads();
   // Compressed gradient: inverse_mapping[dense id] = table row id, written at the first lookup of

@@ -22,4 +22,9 @@ out["gy_l2_resident"]=timed(ti,folded)
 for run in (1,4,64,2048,65536):
     out["runs_of_%d_gy_l2_resident"%run]=timed((pos//run).contiguous(),folded)
     out["runs_of_%d_real_samples"%run]=timed((pos//run).contiguous(),ts)
+for sl in (1, 2, 4):
+    for seg in (32, 64, 128):
+        ce.set_backward_tuning(segment_len=seg, column_slices=sl)
+        out["runs_of_64_gy_l2_resident_slices%d_seg%d" % (sl, seg)] = timed((pos // 64).contiguous(), folded)
+ce.set_backward_tuning()
 print(json.dumps(out))
