@@ -53,7 +53,7 @@ constexpr int64_t kHotMinLookups = int64_t{1} << 20;
 inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
   int len = kMaxSegmentLen;
   const int forced = BackwardTuningCell(0).load(std::memory_order_relaxed);
-  if (forced >= kMinSegmentLen && forced <= 4096) return forced;
+  if (forced >= kMinSegmentLen && forced <= 4096) return forced & ~7;  // the walk is unrolled by 8
   while (len > kMinSegmentLen && (nnz / len) * lanes_per_row < kBackwardTargetLanes) len /= 2;
   return len;
 }
@@ -95,6 +95,7 @@ inline ScatterShape PlanScatter(const int width, const int64_t nnz, const RowSpl
     else if (s.segment_len > kMinSegmentLen) s.segment_len /= 2;
     else break;
   }
+  s.segment_len = s.segment_len < 8 ? 8 : s.segment_len & ~7;
   const int64_t num_segments = (nnz + s.segment_len - 1) / s.segment_len;
   s.nz_blocks = (num_segments + s.segments_per_block - 1) / s.segments_per_block;
   // one workgroup per (nz block, slice); with slices > 1 the 8 / slices XCDs that share a

@@ -75,6 +75,12 @@ __device__ __forceinline__ void FlushStore(GradT* dst, const float (&acc)[N]) {
   __builtin_nontemporal_store(*reinterpret_cast<raw_t*>(&p), reinterpret_cast<raw_t*>(dst));
 }
 
+//! Padding (words) of a segment's slice of packed sample ids: keeps every slice 16-byte aligned
+//! (the walk fetches 4 lookups per ds_read_b128) and shifts consecutive segments by 4 LDS banks.
+constexpr int kPackedPad = 4;
+//! Bit 31 of a staged sample id: "this lookup is the last one of its run".
+constexpr uint32_t kRunEndBit = 0x80000000u;
+
 //! LDS needed by SegmentedScatterAddKernel for `segments_per_block` segments of
 //! `segment_len` lookups handled by `lanes_per_row` lanes each:
 //!   row ids for [first - 1, last + 1] (two sentinels), sample ids, weights (if any),
@@ -88,7 +94,8 @@ __host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int 
   // own padded slice: a wavefront reads the SAME position of 8 different
   // segments at a time, and with a power-of-two stride all 8 would hit one LDS bank.
   const size_t segs = static_cast<size_t>(segments_per_block);
-  size_t bytes = segs * (segment_len + 2) * sizeof(int32_t) + segs * (segment_len + 1) * sizeof(int32_t);
+  size_t bytes = (segs * (segment_len + 2) * sizeof(int32_t) + 15) / 16 * 16;   // row ids
+  bytes += segs * (segment_len + kPackedPad) * sizeof(uint32_t);                // packed sample ids
   bytes = (bytes + 15) / 16 * 16;
   if (weighted) bytes += segs * (segment_len + 2) * sizeof(GradT);
   bytes = (bytes + 15) / 16 * 16;
@@ -182,6 +189,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   }
   const ColumnSlice cs = ColumnSlice::Of(block_idx, column_slices);
   const int64_t block_begin = cs.block * block_len;
+  if (block_begin >= nnz) return;  // the grid is rounded up to whole rounds of 8 workgroups
   if (hot != nullptr) {
     // nz-blocks inside a hot run were summed by HotRowChunkSumKernel: thread h looks at entry h
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -196,14 +204,15 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 
   // ---- LDS carve-up (must match ScatterStageBytes) ----
   // per segment: rows [segment_len + 2] = (lookup before, the segment's row ids, lookup after);
-  // sample ids [segment_len + 1]; weights [segment_len + 2] -- strides that are not multiples of
-  // the 64 LDS banks, so the 8 segments of a wavefront read from 8 different banks
+  // packed sample ids [segment_len + kPackedPad]; weights [segment_len + 2] -- strides that are not
+  // multiples of the 64 LDS banks, so the 8 segments of a wavefront read from different banks
   const int row_stride = segment_len + 2;
-  const int sid_stride = segment_len + 1;
+  const int pk_stride = segment_len + kPackedPad;
   const int w_stride = segment_len + 2;
   int32_t* st_rows = reinterpret_cast<int32_t*>(lds_raw);
-  int32_t* st_sids = st_rows + segments_per_block * row_stride;
-  size_t off = (static_cast<size_t>(segments_per_block) * (row_stride + sid_stride) * sizeof(int32_t) + 15) / 16 * 16;
+  size_t off = (static_cast<size_t>(segments_per_block) * row_stride * sizeof(int32_t) + 15) / 16 * 16;
+  uint32_t* st_pk = reinterpret_cast<uint32_t*>(lds_raw + off);
+  off = (off + static_cast<size_t>(segments_per_block) * pk_stride * sizeof(uint32_t) + 15) / 16 * 16;
   GradT* st_w = reinterpret_cast<GradT*>(lds_raw + off);
   if (kWeighted) off += static_cast<size_t>(segments_per_block) * w_stride * sizeof(GradT);
   off = (off + 15) / 16 * 16;
@@ -216,20 +225,26 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   {
     // The workgroup's COO triples are ONE contiguous range of the sorted arrays: all threads copy it
     // with fully coalesced loads (consecutive threads, consecutive lookups) into the per-segment
-    // padded slices.  (Round 1 let the lanes of a segment stage their own segment: with 4 column
-    // slices that is 8 lanes x 4 bytes per request, eight scattered 32-byte pieces per wavefront
-    // load, paid once per slice -- 0.03 ms of the kernel at the C4 shape.)
+    // padded slices.  The run structure is decided HERE, once per lookup, not in the walk: a staged
+    // sample id carries kRunEndBit when the next lookup belongs to another row (sample ids are
+    // non-negative 32-bit values: nnz and the batch are `int` in the API).  Positions past nnz
+    // hold sample 0 without the bit: their lanes gather a valid row and never flush it.
     const int tid = seg * lanes + lane_x;
     const int threads = lanes * segments_per_block;
     for (int e = tid; e < block_len; e += threads) {
       const int64_t g = block_begin + e;
       const int s = e / segment_len;
       const int i = e - s * segment_len;
-      st_rows[s * row_stride + 1 + i] = g < nnz ? static_cast<int32_t>(rows[g]) : -1;
+      int32_t r = -1;
+      uint32_t pk = 0;
       if (g < nnz) {
-        st_sids[s * sid_stride + i] = static_cast<int32_t>(sample_ids[g]);  // (non-temporal: 6-20 % slower)
+        r = static_cast<int32_t>(rows[g]);
+        const int32_t r_next = g + 1 < nnz ? static_cast<int32_t>(rows[g + 1]) : -1;
+        pk = static_cast<uint32_t>(static_cast<int32_t>(sample_ids[g])) | (r_next != r ? kRunEndBit : 0u);
         if constexpr (kWeighted) st_w[s * w_stride + i] = weights[g];
       }
+      st_rows[s * row_stride + 1 + i] = r;
+      st_pk[s * pk_stride + i] = pk;
     }
     if (lane_x == 0) part_flags[seg] = 0;
     __syncthreads();
@@ -265,72 +280,102 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   GradT* lane_dst = grad_out + column0;
   float* my_part = part + static_cast<size_t>(seg) * 2 * N * lanes;
 
-  if (active) {
-    const int count = static_cast<int>((begin + segment_len < nnz) ? segment_len : nnz - begin);
+  {
+    // ---- the walk: every lane group runs the SAME segment_len iterations (uniform loop, scalar
+    // branches); what differs per segment is only where runs end.
     const int32_t* my_rows = st_rows + seg * row_stride + 1;  // my_rows[-1] = lookup before the segment
-    const int32_t* my_sids = st_sids + seg * sid_stride;
+    const uint32_t* my_pk = st_pk + seg * pk_stride;
     const GradT* my_w = st_w + seg * w_stride;
+    typedef uint32_t __attribute__((ext_vector_type(4))) word4_t;
+    constexpr int K = kBackwardUnroll;
+    static_assert(K % 4 == 0, "packed ids are fetched four at a time");
 
-    // A run is "shared" when it also has lookups in a neighbouring segment.
-    bool run_shared = my_rows[-1] == my_rows[0];                    // sentinel -1 never matches
-    const bool tail_shared = my_rows[count] == my_rows[count - 1];  // sentinel past the end of nnz
+    // A run is "shared" when it also has lookups in a neighbouring segment (the -1 sentinels and
+    // the -1 of positions past nnz never count).
+    bool first_pending = my_rows[0] >= 0 && my_rows[-1] == my_rows[0];   // the first run came in from before
+    const bool tail_shared = my_rows[segment_len - 1] >= 0 && my_rows[segment_len] == my_rows[segment_len - 1];
 
     float acc[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) acc[e] = 0.f;
 
-    auto end_of_run = [&](int64_t row, bool is_last_of_segment) {
-      const bool continues = is_last_of_segment && tail_shared;
-      if (run_shared || continues) {
-        // park the partial: slot 0 = run that came in from the previous segment and ends here,
-        // slot 1 = run that goes on into the next segment (kPartWhole: it also came in).
-        const int slot = continues ? 1 : 0;
+    auto park = [&](const int slot, const int64_t row, const int flag) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) my_part[(slot * N + e) * lanes + lane_x] = acc[e];
-        if (lane_x == 0) {
-          part_row[seg * 2 + slot] = row;
-          part_flags[seg] |= continues ? (kPartTail | (run_shared ? kPartWhole : 0)) : kPartHead;
-        }
-      } else {
-        FlushStore<GradT, N>(lane_dst + RowElems(row, width), acc);
+      for (int e = 0; e < N; ++e) my_part[(slot * N + e) * lanes + lane_x] = acc[e];
+      if (lane_x == 0) {
+        part_row[seg * 2 + slot] = row;
+        part_flags[seg] |= flag;
       }
+    };
+    auto fetch_ids = [&](uint32_t (&dst)[K], const int i0) {
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = 0.f;
-      run_shared = false;
+      for (int q = 0; q < K / 4; ++q) {
+        const word4_t v = *reinterpret_cast<const word4_t*>(my_pk + i0 + 4 * q);
+        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      }
+    };
+    // rows in flight are held as raw dwords (one register tuple per lookup, re-used by the
+    // request that replaces it), not as N separate elements
+    typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
+    auto gather = [&](const uint32_t packed) {
+      return *reinterpret_cast<const raw_t*>(RowPtr(lane_src, static_cast<int64_t>(packed & ~kRunEndBit), width));
     };
 
+    // kBackwardUnroll gathers stay in flight for the whole walk: the row of lookup i + K is
+    // requested as soon as the registers of lookup i have been converted (a rolling window, not
+    // load-8 / wait / add-8: the wave's own arithmetic overlaps its own memory latency).
+    raw_t g[K];
+    uint32_t cur[K], nxt[K];
+    fetch_ids(cur, 0);
+#pragma unroll
+    for (int u = 0; u < K; ++u) g[u] = gather(cur[u]);
+    auto batch = [&](const int i, auto more_tag) {
+      constexpr bool kMore = decltype(more_tag)::value;
+      if constexpr (kMore) fetch_ids(nxt, i + K);
+      GradT w[K];
+      if constexpr (kWeighted) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) w[u] = my_w[i + u];
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        float f[N];
+        const Pack<GradT, N> row_u = __builtin_bit_cast(Pack<GradT, N>, g[u]);
+        if constexpr (kWeighted) {
+          const float wf = static_cast<float>(w[u]);
+#pragma unroll
+          for (int e = 0; e < N; ++e) f[e] = A::mul(static_cast<float>(row_u.v[e]), wf);
+        } else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) f[e] = static_cast<float>(row_u.v[e]);
+        }
+        if constexpr (kMore) {
+          __builtin_amdgcn_sched_barrier(0);   // the registers of lookup i are free: request i + K into them
+          g[u] = gather(nxt[u]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], f[e]);
+        if (static_cast<int32_t>(cur[u]) < 0) {   // kRunEndBit: the run ends with this lookup
+          const int64_t row = WidenIndex(my_rows[i + u]);
+          if (first_pending) park(0, row, kPartHead);   // its first lookups are in earlier segments
+          else FlushStore<GradT, N>(lane_dst + RowElems(row, width), acc);
+          first_pending = false;
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] = 0.f;
+        }
+      }
+      if constexpr (kMore) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) cur[u] = nxt[u];
+      }
+    };
     int i = 0;
-    int64_t row_cur = WidenIndex(my_rows[0]);   // zero-extended like every id here (the -1 sentinels stay distinct)
-    for (; i + kBackwardUnroll <= count; i += kBackwardUnroll) {
-      Pack<GradT, N> g[kBackwardUnroll];
-      GradT w[kBackwardUnroll];
-      int64_t row_next[kBackwardUnroll];
-#pragma unroll
-      for (int u = 0; u < kBackwardUnroll; ++u) {
-        const int64_t sid = WidenIndex(my_sids[i + u]);   // staged as int32, non-negative
-        if constexpr (kWeighted) w[u] = my_w[i + u];
-        row_next[u] = WidenIndex(my_rows[i + u + 1]);
-        g[u] = LoadPack<GradT, N>(RowPtr(lane_src, sid, width));
-      }
-#pragma unroll
-      for (int u = 0; u < kBackwardUnroll; ++u) {
-        AccumulateRow<GradT, N, kWeighted>(acc, g[u], kWeighted ? static_cast<float>(w[u]) : 1.f);
-        const bool last = (i + u + 1 == count);
-        if (last || row_next[u] != row_cur) end_of_run(row_cur, last);
-        row_cur = row_next[u];
-      }
-    }
-    for (; i < count; ++i) {
-      const int64_t sid = WidenIndex(my_sids[i]);
-      const Pack<GradT, N> g = LoadPack<GradT, N>(RowPtr(lane_src, sid, width));
-      const int64_t row_next = WidenIndex(my_rows[i + 1]);
-      float wf = 1.f;
-      if constexpr (kWeighted) wf = static_cast<float>(my_w[i]);
-      AccumulateRow<GradT, N, kWeighted>(acc, g, wf);
-      const bool last = (i + 1 == count);
-      if (last || row_next != row_cur) end_of_run(row_cur, last);
-      row_cur = row_next;
-    }
+    for (; i + K < segment_len; i += K) batch(i, std::true_type{});
+    batch(i, std::false_type{});   // the last K lookups: nothing left to request
+    // the segment's last run goes on into the next segment (kPartWhole: it also came in)
+    if (tail_shared)
+      park(1, WidenIndex(my_rows[segment_len - 1]), kPartTail | (first_pending ? kPartWhole : 0));
   }
   __syncthreads();
   if (!active) return;
