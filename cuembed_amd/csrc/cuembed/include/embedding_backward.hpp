@@ -198,14 +198,17 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
    }
   }
   const int samples_per_chunk = hot.samples_per_fill * hot.fills_per_chunk;
+  int seg_shift = -1;
+  if ((s.segment_len & (s.segment_len - 1)) == 0)
+    for (seg_shift = 0; (1 << seg_shift) < s.segment_len; ++seg_shift) {}
   const dim3 grid(static_cast<unsigned>(s.grid_blocks + (hot.enabled ? kHotMaxRuns : 0)), 1, 1);
   if (weights != nullptr)
     SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, s.lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, grad_out, s.slices, run_ids, inverse_mapping,
+        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping,
         table, partial, hot.chunks, samples_per_chunk, static_cast<int>(num_grad_y_rows));
   else
     SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, s.lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, grad_out, s.slices, run_ids, inverse_mapping,
+        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping,
         table, partial, hot.chunks, samples_per_chunk, static_cast<int>(num_grad_y_rows));
 }
 

@@ -138,6 +138,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const GradT* __restrict__ weights,
                           const int64_t nnz,
                           const int segment_len,
+                          const int segment_shift,  // log2(segment_len), or -1 when it is not a power of two
                           GradT* __restrict__ grad_out,
                           const int column_slices,  // 1, 2 or 4: see ColumnSlice
                           const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
@@ -233,7 +234,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     const int threads = lanes * segments_per_block;
     for (int e = tid; e < block_len; e += threads) {
       const int64_t g = block_begin + e;
-      const int s = e / segment_len;
+      const int s = segment_shift >= 0 ? e >> segment_shift : e / segment_len;
       const int i = e - s * segment_len;
       int32_t r = -1;
       uint32_t pk = 0;
@@ -295,13 +296,23 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     bool first_pending = my_rows[0] >= 0 && my_rows[-1] == my_rows[0];   // the first run came in from before
     const bool tail_shared = my_rows[segment_len - 1] >= 0 && my_rows[segment_len] == my_rows[segment_len - 1];
 
-    float acc[N];
+    // the running sum lives in register PAIRS: v_pk_add_f32 adds a pair per instruction and a
+    // pair is cleared by one 64-bit move
+    typedef float __attribute__((ext_vector_type(2))) pair_t;
+    constexpr int kPairs = (N + 1) / 2;
+    pair_t acc[kPairs];
 #pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    for (int j = 0; j < kPairs; ++j) acc[j] = pair_t{0.f, 0.f};
+    auto unpair = [&](float (&dst)[N]) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) dst[e] = (e & 1) ? acc[e / 2].y : acc[e / 2].x;
+    };
 
     auto park = [&](const int slot, const int64_t row, const int flag) {
+      float a[N];
+      unpair(a);
 #pragma unroll
-      for (int e = 0; e < N; ++e) my_part[(slot * N + e) * lanes + lane_x] = acc[e];
+      for (int e = 0; e < N; ++e) my_part[(slot * N + e) * lanes + lane_x] = a[e];
       if (lane_x == 0) {
         part_row[seg * 2 + slot] = row;
         part_flags[seg] |= flag;
@@ -339,30 +350,39 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
       }
 #pragma unroll
       for (int u = 0; u < K; ++u) {
-        float f[N];
+        pair_t f[kPairs];
         const Pack<GradT, N> row_u = __builtin_bit_cast(Pack<GradT, N>, g[u]);
-        if constexpr (kWeighted) {
-          const float wf = static_cast<float>(w[u]);
 #pragma unroll
-          for (int e = 0; e < N; ++e) f[e] = A::mul(static_cast<float>(row_u.v[e]), wf);
-        } else {
-#pragma unroll
-          for (int e = 0; e < N; ++e) f[e] = static_cast<float>(row_u.v[e]);
+        for (int e = 0; e < 2 * kPairs; ++e) {
+          float x = 0.f;
+          if (e < N) {
+            x = static_cast<float>(row_u.v[e < N ? e : 0]);
+            if constexpr (kWeighted) x = A::mul(x, static_cast<float>(w[u]));
+          }
+          if (e & 1) f[e / 2].y = x; else f[e / 2].x = x;
         }
         if constexpr (kMore) {
           __builtin_amdgcn_sched_barrier(0);   // the registers of lookup i are free: request i + K into them
           g[u] = gather(nxt[u]);
           __builtin_amdgcn_sched_barrier(0);
         }
+        {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = A::add(acc[e], f[e]);
+          for (int j = 0; j < kPairs; ++j) acc[j] = acc[j] + f[j];
+        }
         if (static_cast<int32_t>(cur[u]) < 0) {   // kRunEndBit: the run ends with this lookup
           const int64_t row = WidenIndex(my_rows[i + u]);
-          if (first_pending) park(0, row, kPartHead);   // its first lookups are in earlier segments
-          else FlushStore<GradT, N>(lane_dst + RowElems(row, width), acc);
+          if (first_pending) {
+            park(0, row, kPartHead);   // its first lookups are in earlier segments
+          } else {
+            float a[N];
+            unpair(a);
+            FlushStore<GradT, N>(const_cast<GradT*>(RowPtr(lane_dst, row, width)), a);
+          }
           first_pending = false;
 #pragma unroll
-          for (int e = 0; e < N; ++e) acc[e] = 0.f;
+          for (int j = 0; j < kPairs; ++j) asm("v_mov_b64 %0, 0" : "=v"(acc[j]));   // one move per pair
         }
       }
       if constexpr (kMore) {
