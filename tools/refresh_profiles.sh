@@ -62,6 +62,8 @@ python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" -
   done
 } > "$O/pmc_passes.txt"
 rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_ra_*
+# SQ issue / wait counters of the same pipeline (two passes of 8 counters)
+bash tools/pmc_sq_pass.sh > /dev/null 2>&1 && cp "$R/gpurun_out/pmc_sq.txt" "$O/pmc_sq_pipeline.txt"
 # the bench line again, now with roofline.traffic from the traffic file measured above
 cp "$O/traffic_c2.json" "$R/profiles/traffic_c2.json"
 python bench.py > "$O/bench_c2_line.json" 2>> "$O/bench.err"
