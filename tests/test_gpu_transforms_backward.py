@@ -270,6 +270,31 @@ def test_backward_column_slices_small_shapes(ce, oracle, slices, tuning):
                 assert np.array_equal(host(ginv), winv)
 
 
+@pytest.mark.parametrize("segment_len", [8, 12, 20, 40, 64, 256, 4096])
+def test_backward_forced_segment_lengths(ce, oracle, segment_len, tuning):
+    """The segment walk is a rolling window of 8 gathers over a uniform loop: forced lengths that are
+    not multiples of 8 (rounded down by the launcher), a single batch per segment (8), segments
+    longer than most runs and longer than the whole input (4096), with 1 and 4 column slices; the
+    last workgroup is ragged (nnz is not a multiple of anything) and the grid has idle workgroups."""
+    for slices in (1, 4):
+        tuning(segment_len=segment_len, column_slices=slices)
+        for (W, B, H, ncat, alpha) in [(256, 700, 37, 900, 1.15), (128, 123, 5, 40, 0.0), (64, 3001, 1, 7, 0.0)]:
+            a = oracle.allocate_forward(ncat, W, B, H, alpha=alpha, elem=np.float32)
+            sid = oracle.extract_row_ids_from_fixed(B, H)
+            ti, ts, tw = oracle.transpose(sid, a["indices"], a["weights"])
+            gy = (np.mod(oracle.allocate_grad_y(B * W).reshape(B, W), 3) - 1).astype(np.float32)
+            remap = oracle.compute_compressed_grad_indices(ti)
+            nu = int(remap[-1]) + 1
+            for weights in (None, tw):
+                want, winv = oracle.embedding_backward(gy, W, nu, ti, ts, remap, weights)
+                got, ginv = ce.embedding_backward(dev(gy), nu, dev(ti), dev(ts), dev(remap), dev(weights))
+                assert np.array_equal(host(got), want), (segment_len, slices, W, B, H, weights is not None)
+                assert np.array_equal(host(ginv), winv)
+            want, _ = oracle.embedding_backward(gy, W, ncat, ti, ts)          # dense gradient, memset path
+            got, _ = ce.embedding_backward(dev(gy), ncat, dev(ti), dev(ts))
+            assert np.array_equal(host(got), want), (segment_len, slices, W, B, H, "dense")
+
+
 def test_backward_million_lookups_default_heuristics(ce, oracle):
     """nnz >= 2^20 takes the column-sliced path by default (fp32, W=128: four 128-byte slices)."""
     W, B, H, ncat = 128, 16384, 64, 100_000
