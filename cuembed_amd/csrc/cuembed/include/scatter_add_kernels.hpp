@@ -5,7 +5,7 @@
 // that it is balanced no matter how skewed the run lengths are (at the north-star
 // shape one row owns a run of 65,528 lookups); `lanes_per_row` lanes walk one
 // segment in nz order, gathering grad_y[sample_id] row slices with kBackwardUnroll
-// loads in flight and keeping the running sum in fp32 registers.  When a run ends:
+// loads in flight (a rolling window) and keeping the running sum in fp32 registers.  When a run ends:
 //   * the run lies entirely inside this segment  -> one plain vector store;
 //   * the run continues from / into a neighbour segment -> the partial is combined with its
 //     neighbours inside the workgroup through LDS; only what crosses a WORKGROUP boundary
@@ -112,10 +112,13 @@ enum : int { kPartHead = 1, kPartTail = 2, kPartWhole = 4 };
 //! 1. The workgroup's segments are consecutive, so their COO triples form ONE contiguous
 //!    range of the sorted arrays: it is copied into LDS with coalesced loads once; the walk
 //!    reads ids from LDS and only the grad_y row gathers stay on the global-memory path.
-//! 2. Each segment is walked in nz order by `lanes_per_row` lanes (kBackwardUnroll gathers in
-//!    flight, fp32 partial sums).  A run that lies inside the segment ends in a plain vector
-//!    store.  The partial sums of the segment's FIRST run (when it continues from the previous
-//!    segment) and LAST run (when it continues into the next one) are parked in LDS instead.
+//!    Where runs end is decided here, once per lookup (kRunEndBit of the staged sample id).
+//! 2. Each segment is walked in nz order by `lanes_per_row` lanes: a uniform loop over a rolling
+//!    window of kBackwardUnroll gathers (lookup i + K is requested into the registers of lookup
+//!    i as soon as those are converted), fp32 partial sums in register pairs.  A run that lies
+//!    inside the segment ends in a plain vector store.  The partial sums of the segment's FIRST
+//!    run (when it continues from the previous segment) and LAST run (when it continues into
+//!    the next one) are parked in LDS instead.
 //! 2b. XCD-aware column slices (`column_slices` > 1): grad_y (batch x width) is usually larger
 //!    than one XCD's 4 MiB L2 but far smaller than the 256 MiB Infinity Cache, so every L2
 //!    would stream all of it from the fabric.  Workgroup b (which runs on XCD b % 8) therefore
