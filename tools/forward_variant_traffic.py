@@ -21,7 +21,7 @@ idx = harness.generate_indices(10_000_000, 2 * B, H, alpha=alpha).reshape(2, -1)
 idxs = [torch.from_numpy(np.ascontiguousarray(idx[i])).to(dev) for i in range(2)]
 out = torch.empty((B, W), dtype=torch.float16, device=dev)
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for v in (0, 5, 10, 11):
+for v in [int(x) for x in os.environ.get("VARIANTS", "0,5,10,11").split(",")]:
     for t in range(6):
         L.variant_launch(v, ctypes.c_void_p(big.data_ptr()), W, B, ctypes.c_void_p(idxs[t % 2].data_ptr()), H,
                          ctypes.c_void_p(out.data_ptr()), 8, stream)
