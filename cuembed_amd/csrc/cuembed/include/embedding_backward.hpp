@@ -41,7 +41,7 @@ namespace detail {
 
 constexpr int kMaxSegmentLen = 128;
 constexpr int kMinSegmentLen = 8;
-constexpr int kMaxScatterStageBytes = 48 * 1024;
+constexpr int kMaxScatterStageBytes = 32 * 1024;   // five workgroups per CU (160 KiB of LDS)
 //! Lanes wanted in flight on the whole chip before segments are shortened:
 //! 256 CUs x 2048 lanes x 0.4 (the reference's 40 % target,
 //! embedding_lookup.cuh:312, :365-375, evaluated for MI355X without a device query).

@@ -84,7 +84,7 @@ constexpr uint32_t kRunEndBit = 0x80000000u;
 //! LDS needed by SegmentedScatterAddKernel for `segments_per_block` segments of
 //! `segment_len` lookups handled by `lanes_per_row` lanes each:
 //!   row ids for [first - 1, last + 1] (two sentinels), sample ids, weights (if any),
-//!   two fp32 partial rows per segment (head run / tail run) and their bookkeeping.
+//!   one fp32 partial row per segment (head run; the tail run's re-uses the id area) and their bookkeeping.
 template <typename GradT, typename IndexT>
 __host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int segment_len,
                                                     int lanes_per_row, int elems_per_lane,
@@ -99,8 +99,13 @@ __host__ __device__ inline size_t ScatterStageBytes(int segments_per_block, int 
   bytes = (bytes + 15) / 16 * 16;
   if (weighted) bytes += segs * (segment_len + 2) * sizeof(GradT);
   bytes = (bytes + 15) / 16 * 16;
-  bytes += static_cast<size_t>(segments_per_block) * 2 * lanes_per_row * elems_per_lane * sizeof(float);
-  bytes += static_cast<size_t>(segments_per_block) * (2 * sizeof(int64_t) + sizeof(int));
+  // one fp32 partial row per segment for the run that came in (written during the walk) ...
+  const size_t partial = segs * lanes_per_row * elems_per_lane * sizeof(float);
+  // ... and one for the run that goes on, which is parked AFTER the walk on top of the staged ids
+  // (dead by then): the staging area is as large as the larger of the two
+  if (bytes < partial) bytes = partial;
+  bytes += partial;
+  bytes += segs * (2 * sizeof(int64_t) + sizeof(int));
   return (bytes + 15) / 16 * 16;
 }
 
@@ -220,8 +225,11 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   GradT* st_w = reinterpret_cast<GradT*>(lds_raw + off);
   if (kWeighted) off += static_cast<size_t>(segments_per_block) * w_stride * sizeof(GradT);
   off = (off + 15) / 16 * 16;
-  float* part = reinterpret_cast<float*>(lds_raw + off);          // [seg][2][N][lanes]
-  off += static_cast<size_t>(segments_per_block) * 2 * lanes * N * sizeof(float);
+  const size_t partial_bytes = static_cast<size_t>(segments_per_block) * lanes * N * sizeof(float);
+  if (off < partial_bytes) off = partial_bytes;                     // (the id area also holds the tail partials, below)
+  float* part_head = reinterpret_cast<float*>(lds_raw + off);       // [seg][N][lanes]: run that came in from before
+  float* part_tail = reinterpret_cast<float*>(lds_raw);             // [seg][N][lanes]: run that goes on; ALIASES the staged ids
+  off += partial_bytes;
   int64_t* part_row = reinterpret_cast<int64_t*>(lds_raw + off);   // [seg][2]
   off += static_cast<size_t>(segments_per_block) * 2 * sizeof(int64_t);
   int* part_flags = reinterpret_cast<int*>(lds_raw + off);         // [seg]
@@ -282,7 +290,6 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const bool active = begin < nnz;
   const GradT* lane_src = grad_y + column0;
   GradT* lane_dst = grad_out + column0;
-  float* my_part = part + static_cast<size_t>(seg) * 2 * N * lanes;
 
   {
     // ---- the walk: every lane group runs the SAME segment_len iterations (uniform loop, scalar
@@ -311,15 +318,18 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
       for (int e = 0; e < N; ++e) dst[e] = (e & 1) ? acc[e / 2].y : acc[e / 2].x;
     };
 
-    auto park = [&](const int slot, const int64_t row, const int flag) {
-      float a[N];
-      unpair(a);
-#pragma unroll
-      for (int e = 0; e < N; ++e) my_part[(slot * N + e) * lanes + lane_x] = a[e];
+    auto note = [&](const int slot, const int64_t row, const int flag) {
       if (lane_x == 0) {
         part_row[seg * 2 + slot] = row;
         part_flags[seg] |= flag;
       }
+    };
+    auto park_head = [&](const int64_t row) {   // the run that came in from earlier segments ends here
+      float a[N];
+      unpair(a);
+#pragma unroll
+      for (int e = 0; e < N; ++e) part_head[(seg * N + e) * lanes + lane_x] = a[e];
+      note(0, row, kPartHead);
     };
     auto fetch_ids = [&](uint32_t (&dst)[K], const int i0) {
 #pragma unroll
@@ -377,7 +387,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
         if (static_cast<int32_t>(cur[u]) < 0) {   // kRunEndBit: the run ends with this lookup
           const int64_t row = WidenIndex(my_rows[i + u]);
           if (first_pending) {
-            park(0, row, kPartHead);   // its first lookups are in earlier segments
+            park_head(row);   // its first lookups are in earlier segments
           } else {
             float a[N];
             unpair(a);
@@ -396,9 +406,17 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     int i = 0;
     for (; i + K < segment_len; i += K) batch(i, std::true_type{});
     batch(i, std::false_type{});   // the last K lookups: nothing left to request
-    // the segment's last run goes on into the next segment (kPartWhole: it also came in)
-    if (tail_shared)
-      park(1, WidenIndex(my_rows[segment_len - 1]), kPartTail | (first_pending ? kPartWhole : 0));
+    // The segment's last run goes on into the next segment (kPartWhole: it also came in): its
+    // partial stays in registers until every walk of the workgroup is over, then it is parked on
+    // top of the staged ids, which nobody reads any more.
+    if (tail_shared) note(1, WidenIndex(my_rows[segment_len - 1]), kPartTail | (first_pending ? kPartWhole : 0));
+    __syncthreads();
+    if (tail_shared) {
+      float a[N];
+      unpair(a);
+#pragma unroll
+      for (int e = 0; e < N; ++e) part_tail[(seg * N + e) * lanes + lane_x] = a[e];
+    }
   }
   __syncthreads();
   if (!active) return;
@@ -409,7 +427,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const int last_seg = static_cast<int>(
       remaining >= block_len ? segments_per_block - 1 : (remaining + segment_len - 1) / segment_len - 1);
   auto add_part = [&](float (&sum)[N], int s, int slot) {
-    const float* p = part + (static_cast<size_t>(s) * 2 + slot) * N * lanes;
+    const float* p = (slot == 0 ? part_head : part_tail) + static_cast<size_t>(s) * N * lanes;
 #pragma unroll
     for (int e = 0; e < N; ++e) sum[e] = A::add(sum[e], p[e * lanes + lane_x]);
   };
