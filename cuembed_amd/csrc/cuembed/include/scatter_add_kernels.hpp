@@ -148,7 +148,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int segment_len,
                           const int segment_shift,  // log2(segment_len), or -1 when it is not a power of two
                           GradT* __restrict__ grad_out,
-                          const int column_slices,  // 1, 2 or 4: see ColumnSlice
+                          const int column_slices,  // 1, 2, 4 or 8: see ColumnSlice
                           const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
                           IndexT* __restrict__ inverse_mapping,      // ... and where the id of every run goes
                           const HotRunTable* __restrict__ hot,       // run-aware call: see hot_row_kernels.hpp ...

@@ -295,9 +295,11 @@ def test_backward_forced_segment_lengths(ce, oracle, segment_len, tuning):
             assert np.array_equal(host(got), want), (segment_len, slices, W, B, H, "dense")
 
 
-def test_backward_million_lookups_default_heuristics(ce, oracle):
-    """nnz >= 2^20 takes the column-sliced path by default (fp32, W=128: four 128-byte slices)."""
-    W, B, H, ncat = 128, 16384, 64, 100_000
+@pytest.mark.parametrize("W", [128, 256])
+def test_backward_million_lookups_default_heuristics(ce, oracle, W):
+    """nnz >= 2^20 takes the column-sliced path by default (fp32: W=128 four 128-byte slices,
+    W=256 eight, one per XCD)."""
+    B, H, ncat = 16384, 64, 100_000
     a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15)
     sid = oracle.extract_row_ids_from_fixed(B, H)
     ti, ts, _ = oracle.transpose(sid, a["indices"])
