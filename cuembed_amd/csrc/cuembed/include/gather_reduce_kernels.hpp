@@ -110,12 +110,25 @@ __device__ __forceinline__ const ElemT* RowPtr(const ElemT* base, const int64_t 
 
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
-#if defined(CUEMBED_TUNE_ROW_LOAD_NT)   // tools/tune_forward.py --policies: rejected, see DESIGN.md
+#if defined(CUEMBED_TUNE_ROW_LOAD_ASM)   // tools/tune_forward.py --policies: cache-policy bits by inline asm
+  static_assert(sizeof(Pack<ElemT, N>) == 16, "tuning build: 16-byte lanes only");
+  typedef unsigned __attribute__((ext_vector_type(4))) raw4_t;
+  raw4_t raw4;
+  asm volatile("global_load_dwordx4 %0, %1, off " CUEMBED_TUNE_ROW_LOAD_ASM : "=v"(raw4) : "v"(p) : "memory");
+  return *reinterpret_cast<const Pack<ElemT, N>*>(&raw4);
+#elif defined(CUEMBED_TUNE_ROW_LOAD_NT)   // tools/tune_forward.py --policies: rejected, see DESIGN.md
   typedef unsigned __attribute__((ext_vector_type(sizeof(Pack<ElemT, N>) / 4))) raw_t;
   const raw_t raw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
   return *reinterpret_cast<const Pack<ElemT, N>*>(&raw);
 #else
   return *reinterpret_cast<const Pack<ElemT, N>*>(p);
+#endif
+}
+
+//! (tuning builds with inline-asm loads: the compiler does not see them, so wait by hand)
+__device__ __forceinline__ void TuneWaitRowLoads() {
+#if defined(CUEMBED_TUNE_ROW_LOAD_ASM)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
@@ -232,6 +245,7 @@ struct RowPool {
         if constexpr (kWeighted) w[u] = weight_at(j + u);
         row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
       }
+      TuneWaitRowLoads();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) Add(row[u], w[u]);
@@ -252,6 +266,7 @@ struct RowPool {
           row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
         }
       }
+      TuneWaitRowLoads();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < kUnroll - 1; ++u) {

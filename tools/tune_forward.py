@@ -22,7 +22,10 @@ def build(so=SO, defines=()):
 
 
 # A/B of compile-time policies of the product kernel (variant 0): each policy is its own .so.
-POLICIES = {"plain": (), "row_nt": ("CUEMBED_TUNE_ROW_LOAD_NT",)}
+POLICIES = {"plain": (), "row_nt": ("CUEMBED_TUNE_ROW_LOAD_NT",),
+            "asm_plain": ('CUEMBED_TUNE_ROW_LOAD_ASM=""',), "asm_sc0": ('CUEMBED_TUNE_ROW_LOAD_ASM="sc0"',),
+            "asm_sc1": ('CUEMBED_TUNE_ROW_LOAD_ASM="sc1"',), "asm_sc0_sc1": ('CUEMBED_TUNE_ROW_LOAD_ASM="sc0 sc1"',),
+            "asm_nt": ('CUEMBED_TUNE_ROW_LOAD_ASM="nt"',)}
 
 
 def policy_so(name):
@@ -109,9 +112,14 @@ def policies_main():
     nbytes = 2 * B * (H + 1) * W
     big = torch.empty((10_000_000, W), dtype=torch.float16, device=dev).uniform_(-1, 1)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for alpha in (1.15, 1.05, 0.0):
-        idx = harness.generate_indices(10_000_000, 4 * B, H, alpha=alpha).reshape(4, -1)
-        idxs = [torch.from_numpy(np.ascontiguousarray(idx[i])).to(dev) for i in range(4)]
+    regimes = [("table of 32 rows (L1)", 32), ("table of 4096 rows (L2)", 4096), (1.15, None), (1.05, None), (0.0, None)]
+    for alpha, small_rows in regimes:
+        if small_rows is not None:
+            g = torch.Generator(device=dev).manual_seed(1)
+            idxs = [torch.randint(0, small_rows, (B * H,), device=dev, dtype=torch.int32, generator=g) for _ in range(4)]
+        else:
+            idx = harness.generate_indices(10_000_000, 4 * B, H, alpha=alpha).reshape(4, -1)
+            idxs = [torch.from_numpy(np.ascontiguousarray(idx[i])).to(dev) for i in range(4)]
 
         def launch(L, i, o):
             L.variant_launch(0, ctypes.c_void_p(big.data_ptr()), W, B, ctypes.c_void_p(idxs[i].data_ptr()), H,
@@ -133,8 +141,9 @@ def policies_main():
                 res.setdefault(n, []).append(a.elapsed_time(z) / 12)
         for n, ms in res.items():
             ms = sorted(ms)
-            print("alpha=%.2f  %-8s median %.4f ms (%6.0f GB/s)  min %.4f" %
-                  (alpha, n, ms[len(ms) // 2], nbytes / ms[len(ms) // 2] / 1e6, ms[0]))
+            print("%-24s  %-12s median %.4f ms (%6.0f GB/s)  min %.4f" %
+                  (("alpha=%.2f" % alpha) if small_rows is None else alpha, n, ms[len(ms) // 2],
+                   nbytes / ms[len(ms) // 2] / 1e6, ms[0]))
 
 
 if __name__ == "__main__":
