@@ -269,7 +269,7 @@ void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_
 void cuembed_set_forward_reduction_order(int order);
 int cuembed_get_forward_reduction_order(void);
 /* cuembed::SetBackwardTuning / GetBackwardTuning (tuning and tests; 0 = built-in heuristic):
- * lookups per nz-segment, XCD column slices of the gather (1, 2, 4, 8), hot-run detection stride
+ * lookups per nz-segment (rounded down to a multiple of 8), XCD column slices of the gather (1, 2, 4, 8), hot-run detection stride
  * of the run-aware backward (power of two >= 256; -1 disables its hot path).  Process-wide;
  * initial values from CUEMBED_BWD_SEGMENT_LEN / CUEMBED_BWD_SLICES / CUEMBED_BWD_HOT_STRIDE, read
  * once.  Results never depend on these. */
