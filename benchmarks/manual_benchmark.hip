@@ -55,8 +55,7 @@ struct Flags {
        weighted_sum = false, fp16_math = false, compressed_grad = true, skip_grad_init = true,
        forward_only = false, enable_csv = false, enable_stderr = true, clear_caches = true,
        bounded_sort = false,      // extension: Transpose sorts ceil(log2(num_categories)) key bits only
-       fused_row_ids = false,     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
-       run_aware = false;         // extension: EmbeddingBackwardRunAware (scratch buffer, hot runs chunk-major)
+       fused_row_ids = false;     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
 };
 
 bool ParseBool(const std::string& v) { return v.empty() || v == "1" || v == "true" || v == "True" || v == "yes"; }
@@ -89,7 +88,6 @@ Flags ParseFlags(int argc, char** argv) {
   getb("enable_stderr", &f.enable_stderr); getb("clear_caches", &f.clear_caches);
   getb("bounded_sort", &f.bounded_sort);
   getb("fused_row_ids", &f.fused_row_ids);
-  getb("run_aware", &f.run_aware);
   for (auto& e : kv) {
     std::fprintf(stderr, "unknown flag --%s\n", e.first.c_str());
     std::exit(1);
@@ -150,7 +148,7 @@ struct Workload {
   DeviceBuffer<IndexT> indices, sample_ids, transpose_indices, transpose_remapped_indices,
       transpose_sample_ids, inverse_mapping;
   DeviceBuffer<OffsetT> offsets;
-  DeviceBuffer<char> workspace, backward_work;
+  DeviceBuffer<char> workspace;
   size_t lwork = 0;
 };
 
@@ -194,16 +192,6 @@ void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
 
 template <typename ElemT, typename IndexT, typename OffsetT>
 void RunBackward(Workload<ElemT, IndexT, OffsetT>& w, int num_unique) {
-  if (w.f.run_aware) {
-    size_t lwork = w.backward_work.n;
-    cuembed::EmbeddingBackwardRunAware<ElemT, IndexT>(
-        w.grad_y.ptr, w.f.embed_width, w.f.compressed_grad ? num_unique : w.f.num_categories,
-        static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
-        w.f.compressed_grad ? w.transpose_remapped_indices.ptr : nullptr,
-        w.f.weighted_sum ? w.transpose_weights.ptr : nullptr, w.f.skip_grad_init, w.grad_embedding.ptr,
-        w.f.compressed_grad ? w.inverse_mapping.ptr : nullptr, w.f.batch_size, w.backward_work.ptr, &lwork);
-    return;
-  }
   cuembed::EmbeddingBackward<ElemT, IndexT>(
       w.grad_y.ptr, w.f.embed_width, w.f.compressed_grad ? num_unique : w.f.num_categories,
       static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
@@ -354,13 +342,6 @@ void EmbeddingLookupBenchmark(const Flags& f) {
   w.grad_embedding.Resize(static_cast<size_t>(grad_rows) * f.embed_width);
   HIP_OK(hipMemset(w.grad_embedding.ptr, 0, w.grad_embedding.n * sizeof(ElemT)));
   w.inverse_mapping.Resize(f.compressed_grad ? num_unique : 0);
-  if (f.run_aware) {
-    size_t lw_b = 0;
-    cuembed::EmbeddingBackwardRunAware<ElemT, IndexT>(nullptr, f.embed_width, 0, static_cast<int>(w.nnz), nullptr,
-                                                      nullptr, nullptr, nullptr, false, nullptr, nullptr,
-                                                      f.batch_size, nullptr, &lw_b);
-    w.backward_work.Resize(lw_b);
-  }
   ms = timer.Run(f.iterations, [&] { RunBackward<ElemT, IndexT, OffsetT>(w, num_unique); });
   // unique rows actually touched (the reference counts them with thrust::unique_count)
   std::vector<IndexT> h_t(w.nnz);

@@ -8,8 +8,7 @@ replicated, gradient combined over RCCL (xGMI).  One process per GPU:
 One step on every rank = EmbeddingForward on its 65,536-sample shard, TransposeFixedHotness (row ids
 derived inside the first radix pass, index_bits from the table size; --reference_api runs
 ExtractRowIdsFromFixed + Transpose over all key bits instead, i.e. only what the reference's API
-offers), ComputeCompressedGradIndices, EmbeddingBackward into a compressed gradient (--run_aware:
-EmbeddingBackwardRunAware), then the exchange:
+offers), ComputeCompressedGradIndices, EmbeddingBackward into a compressed gradient, then the exchange:
   sparse : all-gather of the compressed rows + local merge (~293 MB per rank at this shape)
   dense  : scatter into the dense table gradient + RCCL all-reduce (5.12 GB per rank)
   none   : no exchange (upper bound / single GPU)
@@ -36,7 +35,6 @@ def main():
     p.add_argument("--sparse_algorithm", default="auto", choices=["auto", "allgather", "owner"])
     p.add_argument("--reference_api", action="store_true",
                    help="index work through the reference's entry points only (row-id kernel + unbounded Transpose)")
-    p.add_argument("--run_aware", action="store_true", help="EmbeddingBackwardRunAware for the compressed gradient")
     a = p.parse_args()
     import numpy as np
     import torch
@@ -62,8 +60,6 @@ def main():
     nnz = B * H
     work = torch.empty(max(ce.transpose_workspace_bytes(nnz, torch.int32), 1), dtype=torch.uint8, device=dev)
     dense = torch.zeros((a.rows, W), dtype=torch.float16, device=dev) if a.exchange == "dense" else None
-    bwd_work = torch.empty(ce.backward_workspace_bytes(torch.float16, torch.int32, W, nnz, B), dtype=torch.uint8,
-                           device=dev) if a.run_aware else None
     names = ["forward", "transpose", "backward", "exchange"]
 
     def step(ev):
@@ -84,7 +80,7 @@ def main():
             if use_dist:
                 D.allreduce_dense_grad(dense)
         else:
-            rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap, run_aware=a.run_aware, workspace=bwd_work)
+            rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
             ev[3].record()
             if a.exchange == "sparse" and use_dist:
                 D.allreduce_sparse_grad(rows, inv, a.rows, algorithm=a.sparse_algorithm)
@@ -113,7 +109,7 @@ def main():
         print(json.dumps({"workload": "fp16 fwd+bwd, %dx%d table, batch %d per GPU x %d GPUs, hotness %d, alpha %g"
                                       % (a.rows, W, B, world, H, a.alpha),
                           "exchange": a.exchange, "index_path": "reference_api" if a.reference_api else "fixed_hotness_bounded",
-                          "backward": "run_aware" if a.run_aware else "plain", "n_gpus": world, "ms_per_step": round(ms, 4),
+                          "n_gpus": world, "ms_per_step": round(ms, 4),
                           "samples_per_s": round(world * B / (ms * 1e-3)),
                           "breakdown_ms": {k: round(v, 4) for k, v in parts.items()}}), flush=True)
     if use_dist:

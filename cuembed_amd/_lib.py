@@ -24,11 +24,8 @@ def _declare(L):
     L.cuembed_embedding_forward.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _VP]
     L.cuembed_embedding_backward.restype = None
     L.cuembed_embedding_backward.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP]
-    L.cuembed_embedding_backward_run_aware.restype = None
-    L.cuembed_embedding_backward_run_aware.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP,
-                                                       _I, _VP, ctypes.POINTER(ctypes.c_size_t), _VP]
     L.cuembed_set_backward_tuning.restype = None
-    L.cuembed_set_backward_tuning.argtypes = [_I, _I, _I]
+    L.cuembed_set_backward_tuning.argtypes = [_I, _I]
     L.cuembed_get_backward_tuning.restype = None
     L.cuembed_get_backward_tuning.argtypes = [ctypes.POINTER(_I)]
     L.cuembed_transpose.restype = None
@@ -44,7 +41,8 @@ def _declare(L):
     L.cuembed_transpose_fixed_hotness.argtypes = [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP,
                                                   ctypes.POINTER(ctypes.c_size_t), _I, _VP]
     L.cuembed_translate_indices_for_row_cache.restype = None
-    L.cuembed_translate_indices_for_row_cache.argtypes = [_VP, _I, ctypes.c_int64, _VP, ctypes.c_int64, _VP, _VP]
+    L.cuembed_translate_indices_for_row_cache.argtypes = [_VP, _I, ctypes.c_int64, _VP, ctypes.c_int64, ctypes.c_int64,
+                                                          _VP, _VP]
     L.cuembed_compute_compressed_grad_indices.restype = None
     L.cuembed_compute_compressed_grad_indices.argtypes = [_VP, _I, _I, _VP, _VP,
                                                           ctypes.POINTER(ctypes.c_size_t), _VP]

@@ -16,16 +16,6 @@ void Backward(const void* grad_y, int embed_width, int num_rows, int nnz, const 
       static_cast<const ElemT*>(t_w), skip_init != 0, static_cast<ElemT*>(grad), inverse_mapping,
       Stream(stream));
 }
-template <typename ElemT, typename IndexT>
-void BackwardRunAware(const void* grad_y, int embed_width, int num_rows, int nnz, const IndexT* t_idx,
-                      const IndexT* t_sid, const IndexT* t_remap, const void* t_w, int skip_init,
-                      void* grad, IndexT* inverse_mapping, int num_grad_y_rows, char* work, size_t* lwork,
-                      cuembed_stream_t stream) {
-  cuembed::EmbeddingBackwardRunAware<ElemT, IndexT>(
-      static_cast<const ElemT*>(grad_y), embed_width, num_rows, nnz, t_idx, t_sid, t_remap,
-      static_cast<const ElemT*>(t_w), skip_init != 0, static_cast<ElemT*>(grad), inverse_mapping,
-      num_grad_y_rows, work, lwork, Stream(stream));
-}
 }  // namespace
 
 extern "C" {
@@ -75,42 +65,14 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
 #undef BWD
 }
 
-void cuembed_embedding_backward_run_aware(const void* grad_y, int elem_type, int embed_width,
-                                          int num_grad_embedding_rows, int nnz,
-                                          const void* transpose_indices, const void* transpose_sample_ids,
-                                          const void* transpose_remapped_indices, int index_type,
-                                          const void* transpose_weights, int skip_grad_init,
-                                          void* grad_embedding, void* inverse_mapping,
-                                          int num_grad_y_rows, char* work, size_t* lwork,
-                                          cuembed_stream_t stream) {
-#define BWD(E, I)                                                                             \
-  BackwardRunAware<E, I>(grad_y, embed_width, num_grad_embedding_rows, nnz,                   \
-                         static_cast<const I*>(transpose_indices),                            \
-                         static_cast<const I*>(transpose_sample_ids),                         \
-                         static_cast<const I*>(transpose_remapped_indices), transpose_weights, \
-                         skip_grad_init, grad_embedding, static_cast<I*>(inverse_mapping),    \
-                         num_grad_y_rows, work, lwork, stream)
-  switch ((elem_type << 1) | index_type) {
-    case 0: BWD(float, int32_t); break;
-    case 1: BWD(float, int64_t); break;
-    case 2: BWD(__half, int32_t); break;
-    case 3: BWD(__half, int64_t); break;
-    case 4: BWD(__hip_bfloat16, int32_t); break;
-    case 5: BWD(__hip_bfloat16, int64_t); break;
-    default: CUEMBED_C_API_BAD_TYPE();
-  }
-#undef BWD
-}
-
-void cuembed_set_backward_tuning(int segment_len, int column_slices, int hot_stride) {
-  cuembed::SetBackwardTuning(cuembed::BackwardTuning{segment_len, column_slices, hot_stride});
+void cuembed_set_backward_tuning(int segment_len, int column_slices) {
+  cuembed::SetBackwardTuning(cuembed::BackwardTuning{segment_len, column_slices});
 }
 
 void cuembed_get_backward_tuning(int* out) {
   const cuembed::BackwardTuning t = cuembed::GetBackwardTuning();
   out[0] = t.segment_len;
   out[1] = t.column_slices;
-  out[2] = t.hot_stride;
 }
 
 }  // extern "C"

@@ -119,14 +119,15 @@ void cuembed_transpose_fixed_hotness(const void* indices, const void* weights, i
 }
 
 void cuembed_translate_indices_for_row_cache(const void* indices, int index_type, int64_t nnz,
-                                             const int32_t* slot_of_row, int64_t cache_row_offset,
-                                             int64_t* translated, cuembed_stream_t stream) {
+                                             const int32_t* slot_of_row, int64_t num_rows,
+                                             int64_t cache_row_offset, int64_t* translated,
+                                             cuembed_stream_t stream) {
   if (index_type == CUEMBED_I32)
     cuembed::TranslateIndicesForRowCache<int32_t>(static_cast<const int32_t*>(indices), nnz, slot_of_row,
-                                                  cache_row_offset, translated, Stream(stream));
+                                                  num_rows, cache_row_offset, translated, Stream(stream));
   else if (index_type == CUEMBED_I64)
     cuembed::TranslateIndicesForRowCache<int64_t>(static_cast<const int64_t*>(indices), nnz, slot_of_row,
-                                                  cache_row_offset, translated, Stream(stream));
+                                                  num_rows, cache_row_offset, translated, Stream(stream));
   else
     CUEMBED_C_API_BAD_TYPE();
 }

@@ -9,19 +9,17 @@ namespace cuembed {
 
 //! Launch-shape overrides of the backward kernels (tuning / tests; 0 = the built-in heuristic).
 //! Process-wide like SetForwardReductionOrder; the initial values come from the environment
-//! (CUEMBED_BWD_SEGMENT_LEN, CUEMBED_BWD_SLICES, CUEMBED_BWD_HOT_STRIDE), read ONCE at first use.
+//! (CUEMBED_BWD_SEGMENT_LEN, CUEMBED_BWD_SLICES), read ONCE at first use.
 struct BackwardTuning {
   int segment_len;    //!< lookups per nz-segment (8 .. 4096)
   int column_slices;  //!< XCD column slices of the gather: 1, 2, 4 or 8
-  int hot_stride;     //!< run-aware backward: hot-run detection stride (power of two >= 256); -1 disables the hot path
 };
 
 namespace detail {
 inline std::atomic<int>& BackwardTuningCell(const int which) {
-  static std::atomic<int> cell[3] = {
+  static std::atomic<int> cell[2] = {
       {[] { const char* e = std::getenv("CUEMBED_BWD_SEGMENT_LEN"); return e ? std::atoi(e) : 0; }()},
-      {[] { const char* e = std::getenv("CUEMBED_BWD_SLICES"); return e ? std::atoi(e) : 0; }()},
-      {[] { const char* e = std::getenv("CUEMBED_BWD_HOT_STRIDE"); return e ? std::atoi(e) : 0; }()}};
+      {[] { const char* e = std::getenv("CUEMBED_BWD_SLICES"); return e ? std::atoi(e) : 0; }()}};
   return cell[which];
 }
 }  // namespace detail
@@ -29,12 +27,10 @@ inline std::atomic<int>& BackwardTuningCell(const int which) {
 inline void SetBackwardTuning(const BackwardTuning& t) {
   detail::BackwardTuningCell(0).store(t.segment_len, std::memory_order_relaxed);
   detail::BackwardTuningCell(1).store(t.column_slices, std::memory_order_relaxed);
-  detail::BackwardTuningCell(2).store(t.hot_stride, std::memory_order_relaxed);
 }
 inline BackwardTuning GetBackwardTuning() {
   return BackwardTuning{detail::BackwardTuningCell(0).load(std::memory_order_relaxed),
-                        detail::BackwardTuningCell(1).load(std::memory_order_relaxed),
-                        detail::BackwardTuningCell(2).load(std::memory_order_relaxed)};
+                        detail::BackwardTuningCell(1).load(std::memory_order_relaxed)};
 }
 
 namespace detail {
@@ -46,9 +42,6 @@ constexpr int kMaxScatterStageBytes = 32 * 1024;   // five workgroups per CU (16
 //! 256 CUs x 2048 lanes x 0.4 (the reference's 40 % target,
 //! embedding_lookup.cuh:312, :365-375, evaluated for MI355X without a device query).
 constexpr int64_t kBackwardTargetLanes = static_cast<int64_t>(256) * 2048 * 4 / 10;
-//! The run-aware path pays two extra launches; below this many lookups they cost more than the
-//! hot runs do (and grad_y fits the L2s anyway).
-constexpr int64_t kHotMinLookups = int64_t{1} << 20;
 
 inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
   int len = kMaxSegmentLen;
@@ -107,175 +100,30 @@ inline ScatterShape PlanScatter(const int width, const int64_t nnz, const RowSpl
   return s;
 }
 
-//! Plan of the run-aware part of one backward call (see hot_row_kernels.hpp); `enabled` is false
-//! when the shape cannot profit (few lookups, rows that do not split into 16-byte lanes of one
-//! wavefront, fewer than kHotMinLookupsPerSample lookups per grad_y row, ...).
-struct HotPlan {
-  bool enabled;
-  int stride, samples_per_fill, fills_per_chunk, chunks, lanes_per_row;
-  size_t table_bytes, bounds_bytes, partial_bytes, lds_bytes;
-  int num_fills() const { return chunks * fills_per_chunk; }
-  size_t work_bytes() const { return enabled ? table_bytes + bounds_bytes + partial_bytes : 0; }
-};
-
-//! The detection stride must be a multiple of the segmented kernel's nz-block (both are powers
-//! of two whenever the hot path applies); false when the shape leaves no room for that.
-inline bool FitHotStride(HotPlan* h, const int64_t nnz, const int block_len) {
-  if (!h->enabled) return false;
-  while (h->stride < block_len) h->stride *= 2;
-  if (h->stride % block_len != 0 || (nnz + h->stride - 1) / h->stride > kHotMaxMultiples || nnz < 2 * int64_t{h->stride})
-    h->enabled = false;
-  return h->enabled;
-}
-
-template <typename GradT>
-inline HotPlan PlanHot(const int width, const int64_t nnz, const int64_t num_grad_y_rows, const RowSplit split) {
-  HotPlan h{};
-  const size_t row_bytes = static_cast<size_t>(width) * sizeof(GradT);
-  const int forced = BackwardTuningCell(2).load(std::memory_order_relaxed);
-  constexpr int kMaxN = 16 / static_cast<int>(sizeof(GradT));
-  h.enabled = forced >= 0 && (nnz >= kHotMinLookups || forced > 0) && split.elems_per_lane == kMaxN &&
-              split.lanes_per_row <= 64 && 64 % split.lanes_per_row == 0 && num_grad_y_rows > 0 &&
-              nnz >= 4 * num_grad_y_rows;  // concat-like calls (every grad_y row used once) share nothing
-  if (!h.enabled) return h;
-  h.stride = HotStride(nnz);
-  if (forced >= 256 && (forced & (forced - 1)) == 0 && (nnz + forced - 1) / forced <= kHotMaxMultiples) h.stride = forced;
-  h.lanes_per_row = split.lanes_per_row;
-  h.samples_per_fill = static_cast<int>(kHotChunkBytes / row_bytes);
-  const int64_t fills = (num_grad_y_rows + h.samples_per_fill - 1) / h.samples_per_fill;
-  h.fills_per_chunk = static_cast<int>((fills + kHotMaxChunks - 1) / kHotMaxChunks);
-  const int64_t per_chunk = static_cast<int64_t>(h.samples_per_fill) * h.fills_per_chunk;
-  h.chunks = static_cast<int>((num_grad_y_rows + per_chunk - 1) / per_chunk);
-  h.table_bytes = (sizeof(HotRunTable) + 255) / 256 * 256;
-  h.bounds_bytes = (static_cast<size_t>(kHotMaxRuns) * (h.num_fills() + 1) * sizeof(int) + 255) / 256 * 256;
-  h.partial_bytes = static_cast<size_t>(h.chunks) * kHotMaxRuns * kHotPieces * width * sizeof(float);
-  h.lds_bytes = static_cast<size_t>(h.samples_per_fill) * row_bytes;
-  return h;
-}
-
 template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream,
                              const int64_t zero_rows /* > 0: zero only what needs it, see below */,
-                             const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */,
-                             HotPlan hot, const int64_t num_grad_y_rows, char* work) {
+                             const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */) {
   const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr);
   const dim3 block(s.lanes, s.segments_per_block, 1);
   const int block_len = s.segments_per_block * s.segment_len;
-  FitHotStride(&hot, nnz, block_len);
   if (zero_rows > 0) {
     const int64_t tail_blocks = (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock;
     ZeroSharedAndTailRowsKernel<GradT, IndexT><<<static_cast<unsigned>(s.nz_blocks + tail_blocks), 256, 0, stream>>>(
         rows, nnz, block_len, s.nz_blocks, width, zero_rows, grad_out);
   }
-  HotRunTable* table = nullptr;
-  float* partial = nullptr;
-  if constexpr (N * sizeof(GradT) == 16) {
-   if (hot.enabled) {
-    table = reinterpret_cast<HotRunTable*>(work);
-    int* bounds = reinterpret_cast<int*>(work + hot.table_bytes);
-    partial = reinterpret_cast<float*>(work + hot.table_bytes + hot.bounds_bytes);
-    const int multiples = static_cast<int>((nnz - 1) / hot.stride + 1);
-    unsigned fill_magic;
-    int fill_shift;
-    HotFillDivisor(hot.samples_per_fill, &fill_magic, &fill_shift);
-    HotRunDetectKernel<IndexT><<<multiples, kHotDetectThreads, 0, stream>>>(
-        rows, sample_ids, static_cast<int>(nnz), hot.stride, block_len, fill_magic, fill_shift,
-        hot.num_fills(), table, bounds);
-    auto chunk_kernel = weights != nullptr ? HotRowChunkSumKernel<GradT, IndexT, N, true>
-                                           : HotRowChunkSumKernel<GradT, IndexT, N, false>;
-    static const bool lds_ok = [&] {  // > 64 KiB of dynamic LDS has to be asked for, once per kernel
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(HotRowChunkSumKernel<GradT, IndexT, N, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kHotChunkBytes);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(HotRowChunkSumKernel<GradT, IndexT, N, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kHotChunkBytes);
-      return true;
-    }();
-    (void)lds_ok;
-    chunk_kernel<<<hot.chunks, kHotThreads, hot.lds_bytes, stream>>>(
-        grad_y, width, static_cast<int>(num_grad_y_rows), sample_ids, weights, table, bounds, partial,
-        hot.samples_per_fill, hot.fills_per_chunk, hot.num_fills(), hot.lanes_per_row);
-   }
-  }
-  const int samples_per_chunk = hot.samples_per_fill * hot.fills_per_chunk;
   int seg_shift = -1;
   if ((s.segment_len & (s.segment_len - 1)) == 0)
     for (seg_shift = 0; (1 << seg_shift) < s.segment_len; ++seg_shift) {}
-  const dim3 grid(static_cast<unsigned>(s.grid_blocks + (hot.enabled ? kHotMaxRuns : 0)), 1, 1);
+  const dim3 grid(static_cast<unsigned>(s.grid_blocks), 1, 1);
   if (weights != nullptr)
     SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, s.lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping,
-        table, partial, hot.chunks, samples_per_chunk, static_cast<int>(num_grad_y_rows));
+        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping);
   else
     SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, s.lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping,
-        table, partial, hot.chunks, samples_per_chunk, static_cast<int>(num_grad_y_rows));
-}
-
-//! Shared body of EmbeddingBackward and EmbeddingBackwardRunAware.  `work == nullptr` with
-//! `lwork != nullptr` only reports the workspace size.
-template <typename GradT, typename IndexT>
-inline void BackwardImpl(const GradT* grad_y, const int embed_width, const int num_grad_embedding_rows,
-                         const int nnz, const IndexT* transpose_indices, const IndexT* transpose_sample_ids,
-                         const IndexT* transpose_remapped_indices, const GradT* transpose_weights,
-                         const bool skip_grad_init, GradT* grad_embedding, IndexT* inverse_mapping,
-                         const bool run_aware, const int num_grad_y_rows, char* work, size_t* lwork,
-                         const hipStream_t stream) {
-  static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value ||
-                    std::is_same<GradT, __hip_bfloat16>::value,
-                "EmbeddingBackward: gradients must be float, __half or __hip_bfloat16");
-  using ElemT = DeviceElemT<GradT>;
-  const RowSplit split = SplitRow<ElemT>(embed_width, grad_y, grad_embedding);
-  HotPlan hot{};
-  if (run_aware) {
-    hot = PlanHot<ElemT>(embed_width, nnz, num_grad_y_rows, split);
-    if (work == nullptr) {  // phase 1 of the two-phase call (alignment of grad_y / grad_embedding unknown: assume the best)
-      RowSplit best = split;
-      best.elems_per_lane = 16 / static_cast<int>(sizeof(ElemT));
-      if (embed_width % best.elems_per_lane == 0) {
-        best.lanes_per_row = embed_width / best.elems_per_lane;
-        hot = PlanHot<ElemT>(embed_width, nnz, num_grad_y_rows, best);
-      }
-      // never 0: a caller that allocates "what was asked for" must end up with a non-null buffer,
-      // because work == nullptr means "query" (same convention as Transpose)
-      *lwork = hot.work_bytes() > 256 ? hot.work_bytes() : 256;
-      return;
-    }
-    if (hot.enabled) CUEMBED_ASSERT(lwork != nullptr && *lwork >= hot.work_bytes());
-  }
-
-  const IndexT* rows =
-      transpose_remapped_indices != nullptr ? transpose_remapped_indices : transpose_indices;
-
-  if (transpose_remapped_indices != nullptr && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
-  // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
-  // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
-  // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
-  const bool compressed = transpose_remapped_indices != nullptr;
-  if (!skip_grad_init && (!compressed || nnz <= 0)) {
-    (void)hipMemsetAsync(grad_embedding, 0,
-                         static_cast<size_t>(num_grad_embedding_rows) *
-                             static_cast<size_t>(embed_width) * sizeof(GradT),
-                         stream);
-  }
-  if (nnz <= 0) return;
-  const int64_t zero_rows = (!skip_grad_init && compressed) ? num_grad_embedding_rows : 0;
-
-  const IndexT* run_ids = compressed ? transpose_indices : nullptr;  // inverse mapping is written by the scatter
-  const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
-  const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
-  ElemT* out = reinterpret_cast<ElemT*>(grad_embedding);
-  constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
-  if (split.elems_per_lane == kMaxN)
-    LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
-                                           stream, zero_rows, run_ids, inverse_mapping, hot, num_grad_y_rows, work);
-  else if (split.elems_per_lane == kMaxN / 2)
-    LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
-                                               stream, zero_rows, run_ids, inverse_mapping, HotPlan{}, 0, nullptr);
-  else
-    LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
-                                               stream, zero_rows, run_ids, inverse_mapping, HotPlan{}, 0, nullptr);
+        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping);
 }
 
 }  // namespace detail
@@ -303,45 +151,42 @@ void EmbeddingBackward(const GradT* grad_y,
                        GradT* grad_embedding,
                        IndexT* inverse_mapping,
                        const hipStream_t stream = 0) {
-  detail::BackwardImpl<GradT, IndexT>(grad_y, embed_width, num_grad_embedding_rows, nnz, transpose_indices,
-                                      transpose_sample_ids, transpose_remapped_indices, transpose_weights,
-                                      skip_grad_init, grad_embedding, inverse_mapping, /*run_aware=*/false, 0,
-                                      nullptr, nullptr, stream);
-}
+  static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value ||
+                    std::is_same<GradT, __hip_bfloat16>::value,
+                "EmbeddingBackward: gradients must be float, __half or __hip_bfloat16");
+  using ElemT = detail::DeviceElemT<GradT>;
+  const detail::RowSplit split = detail::SplitRow<ElemT>(embed_width, grad_y, grad_embedding);
+  const IndexT* rows =
+      transpose_remapped_indices != nullptr ? transpose_remapped_indices : transpose_indices;
 
-/**
- * @brief EmbeddingBackward with a scratch buffer (this library's extension; same results up to
- * the rounding of where a run is cut into partial sums).  Knowing the number of grad_y rows
- * (`num_grad_y_rows` = batch size for sum / mean) and having scratch lets the call treat the few
- * very long runs of a skewed batch -- rows that almost every sample looks up -- chunk-major:
- * each chunk of grad_y rows is read once into LDS and serves all of those runs, instead of every
- * run streaming most of grad_y through the fabric again (hot_row_kernels.hpp).  Everything else
- * goes through the same kernel as EmbeddingBackward.
- *
- * Two-phase like Transpose(): `work == nullptr` => `*lwork` receives the bytes needed (0 when
- * the shape cannot profit; the call then equals EmbeddingBackward), nothing runs.
- */
-template <typename GradT, typename IndexT>
-void EmbeddingBackwardRunAware(const GradT* grad_y,
-                               const int embed_width,
-                               const int num_grad_embedding_rows,
-                               const int nnz,
-                               const IndexT* transpose_indices,
-                               const IndexT* transpose_sample_ids,
-                               const IndexT* transpose_remapped_indices,
-                               const GradT* transpose_weights,
-                               const bool skip_grad_init,
-                               GradT* grad_embedding,
-                               IndexT* inverse_mapping,
-                               const int num_grad_y_rows,
-                               char* work,
-                               size_t* lwork,
-                               const hipStream_t stream = 0) {
-  CUEMBED_ASSERT(lwork != nullptr);
-  detail::BackwardImpl<GradT, IndexT>(grad_y, embed_width, num_grad_embedding_rows, nnz, transpose_indices,
-                                      transpose_sample_ids, transpose_remapped_indices, transpose_weights,
-                                      skip_grad_init, grad_embedding, inverse_mapping, /*run_aware=*/true,
-                                      num_grad_y_rows, work, lwork, stream);
+  if (transpose_remapped_indices != nullptr && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
+  // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
+  // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
+  // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
+  const bool compressed = transpose_remapped_indices != nullptr;
+  if (!skip_grad_init && (!compressed || nnz <= 0)) {
+    (void)hipMemsetAsync(grad_embedding, 0,
+                         static_cast<size_t>(num_grad_embedding_rows) *
+                             static_cast<size_t>(embed_width) * sizeof(GradT),
+                         stream);
+  }
+  if (nnz <= 0) return;
+  const int64_t zero_rows = (!skip_grad_init && compressed) ? num_grad_embedding_rows : 0;
+
+  const IndexT* run_ids = compressed ? transpose_indices : nullptr;  // inverse mapping is written by the scatter
+  const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
+  const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
+  ElemT* out = reinterpret_cast<ElemT*>(grad_embedding);
+  constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
+  if (split.elems_per_lane == kMaxN)
+    detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
+                                                   stream, zero_rows, run_ids, inverse_mapping);
+  else if (split.elems_per_lane == kMaxN / 2)
+    detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
+                                                       split, stream, zero_rows, run_ids, inverse_mapping);
+  else
+    detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
+                                                       split, stream, zero_rows, run_ids, inverse_mapping);
 }
 
 }  // namespace cuembed

@@ -63,12 +63,13 @@ ExpandCsrKernel(const OffsetT* __restrict__ offsets, const int batch, IndexT* __
 }
 
 //! Row-cache translation (see TranslateIndicesForRowCache in index_transforms.hpp):
-//! out[i] = slot_of_row[idx[i]] >= 0 ? cache_row_offset + slot : idx[i].
+//! out[i] = slot_of_row[idx[i]] >= 0 ? cache_row_offset + slot : idx[i]; ids outside [0, num_rows)
+//! are passed through untouched (slot_of_row has num_rows entries).
 template <typename IndexT>
 __global__ void __launch_bounds__(256)
 TranslateForRowCacheKernel(const IndexT* __restrict__ indices, const int64_t count,
-                           const int32_t* __restrict__ slot_of_row, const int64_t cache_row_offset,
-                           int64_t* __restrict__ out) {
+                           const int32_t* __restrict__ slot_of_row, const int64_t num_rows,
+                           const int64_t cache_row_offset, int64_t* __restrict__ out) {
   const int64_t base =
       static_cast<int64_t>(blockIdx.x) * blockDim.x * kSequenceItemsPerThread + threadIdx.x;
   int64_t row[kSequenceItemsPerThread];
@@ -81,7 +82,7 @@ TranslateForRowCacheKernel(const IndexT* __restrict__ indices, const int64_t cou
 #pragma unroll
   for (int k = 0; k < kSequenceItemsPerThread; ++k) {
     const int64_t t = base + static_cast<int64_t>(k) * blockDim.x;
-    slot[k] = t < count ? slot_of_row[row[k]] : -1;
+    slot[k] = (t < count && row[k] >= 0 && row[k] < num_rows) ? slot_of_row[row[k]] : -1;
   }
 #pragma unroll
   for (int k = 0; k < kSequenceItemsPerThread; ++k) {

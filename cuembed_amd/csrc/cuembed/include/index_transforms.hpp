@@ -97,12 +97,14 @@ void ExtractRowIdsForConcat(const int nnz, IndexT* row_ids, const hipStream_t st
  * from HBM and only the others from wherever `params` lives -- unmodified kernel, bit-identical
  * results as long as the cached copies equal the table rows.  slot_of_row has one int32 per table
  * row (-1: not cached); which rows to cache (e.g. the most frequent ones of recent batches) is the
- * caller's policy -- cuembed_amd/row_cache.py has a simple one.
+ * caller's policy -- cuembed_amd/row_cache.py has a simple one.  `num_rows` is the length of
+ * slot_of_row: indices outside [0, num_rows) are copied through unchanged (never used to index it).
  */
 template <typename IndexT>
 void TranslateIndicesForRowCache(const IndexT* indices,
                                  const int64_t nnz,
                                  const int32_t* slot_of_row,
+                                 const int64_t num_rows,
                                  const int64_t cache_row_offset,
                                  int64_t* translated,
                                  const hipStream_t stream = 0) {
@@ -111,7 +113,7 @@ void TranslateIndicesForRowCache(const IndexT* indices,
   const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
   detail::TranslateForRowCacheKernel<IndexT>
       <<<static_cast<unsigned>((nnz + per_block - 1) / per_block), threads, 0, stream>>>(
-          indices, nnz, slot_of_row, cache_row_offset, translated);
+          indices, nnz, slot_of_row, num_rows, cache_row_offset, translated);
 }
 
 /**

@@ -23,7 +23,6 @@
 
 #include "cuembed/include/embedding_types.hpp"
 #include "cuembed/include/gather_reduce_kernels.hpp"
-#include "cuembed/include/hot_row_kernels.hpp"
 
 namespace cuembed {
 namespace detail {
@@ -150,11 +149,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           GradT* __restrict__ grad_out,
                           const int column_slices,  // 1, 2, 4 or 8: see ColumnSlice
                           const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
-                          IndexT* __restrict__ inverse_mapping,      // ... and where the id of every run goes
-                          const HotRunTable* __restrict__ hot,       // run-aware call: see hot_row_kernels.hpp ...
-                          const float* __restrict__ hot_partial,     // ... partial rows of the hot runs ...
-                          const int hot_chunks,                      // ... one set per sample chunk
-                          const int hot_samples_per_chunk, const int hot_num_samples) {
+                          IndexT* __restrict__ inverse_mapping) {    // ... and where the id of every run goes
   using A = Arith<float>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane_x = threadIdx.x;
@@ -162,53 +157,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const int seg = threadIdx.y;
   const int segments_per_block = blockDim.y;
   const int block_len = segments_per_block * segment_len;
-  unsigned block_idx = blockIdx.x;
-  if (hot != nullptr) {
-    // Run-aware call.  The first kHotMaxRuns workgroups of the grid each combine one hot run: the
-    // fp32 partial rows that HotRowChunkSumKernel left per sample chunk are added up in chunk
-    // order and the total goes into the output row with ONE atomic per element (the row also
-    // receives the run's ragged ends from ordinary workgroups, so it cannot be a plain store).
-    if (block_idx < static_cast<unsigned>(kHotMaxRuns)) {
-      if (static_cast<int>(block_idx) >= hot->count) return;
-      const HotRun r = hot->run[block_idx];
-      if (r.end_block <= r.first_block) return;
-      const int pieces = HotPiecesOf(r, hot->block_len, hot_samples_per_chunk, hot_num_samples);
-      const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-      const int threads = blockDim.x * blockDim.y;
-      constexpr int kPair = sizeof(GradT) == 2 ? 2 : 1;  // 16-bit atomics come in pairs
-      for (int col = tid * kPair; col < width; col += threads * kPair) {
-        float sum[kPair];
-#pragma unroll
-        for (int e = 0; e < kPair; ++e) sum[e] = 0.f;
-        const float* p = hot_partial + static_cast<size_t>(block_idx) * kHotPieces * width + col;
-        for (int c = 0; c < hot_chunks; ++c) {
-          for (int q = 0; q < pieces; ++q) {
-#pragma unroll
-            for (int e = 0; e < kPair; ++e) sum[e] = A::add(sum[e], p[static_cast<size_t>(q) * width + e]);
-          }
-          p += static_cast<size_t>(kHotMaxRuns) * kHotPieces * width;
-        }
-        FlushAtomic<kPair>(grad_out + static_cast<int64_t>(r.row) * width + col, sum);
-      }
-      // the run's first lookup may be the first lookup of a skipped nz-block
-      if (run_ids != nullptr && tid == 0) inverse_mapping[r.row] = run_ids[r.begin];
-      return;
-    }
-    block_idx -= kHotMaxRuns;
-  }
-  const ColumnSlice cs = ColumnSlice::Of(block_idx, column_slices);
+  const ColumnSlice cs = ColumnSlice::Of(blockIdx.x, column_slices);
   const int64_t block_begin = cs.block * block_len;
   if (block_begin >= nnz) return;  // the grid is rounded up to whole rounds of 8 workgroups
-  if (hot != nullptr) {
-    // nz-blocks inside a hot run were summed by HotRowChunkSumKernel: thread h looks at entry h
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    bool inside = false;
-    if (tid < hot->count) {
-      const HotRun r = hot->run[tid];
-      inside = cs.block >= r.first_block && cs.block < r.end_block;
-    }
-    if (__syncthreads_or(inside)) return;
-  }
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * lanes + lane_x) * N;
 
   // ---- LDS carve-up (must match ScatterStageBytes) ----

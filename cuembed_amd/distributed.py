@@ -24,14 +24,27 @@ def _stage_on_host(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+class _CompletedWork:
+    """What an async collective returns when it had to run synchronously (host-staged path)."""
+
+    def wait(self, timeout=None):
+        return True
+
+    def is_completed(self):
+        return True
+
+
 def _all_reduce_sum(t, group=None, async_op=False):
+    """In-place sum across ranks.  async_op=True returns a handle with wait() / is_completed(); on the
+    host-staged path (gloo group, device tensor) the copies and the collective are blocking, so the
+    handle is already complete and nothing overlaps."""
     import torch.distributed as dist
     if not _stage_on_host(t, group):
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     h = t.cpu()
     dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     t.copy_(h)
-    return None
+    return _CompletedWork() if async_op else None
 
 
 def _all_gather(t, group=None):

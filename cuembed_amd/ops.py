@@ -173,41 +173,27 @@ def embedding_weight_grad(params, indices, grad_y, offsets=None, batch_size=None
     return out
 
 
-def set_backward_tuning(segment_len=0, column_slices=0, hot_stride=0):
-    """Launch-shape overrides of the backward kernels (tuning / tests; 0 = built-in heuristic;
-    hot_stride=-1 disables the hot path of the run-aware backward).  Results never depend on them."""
-    _lib.lib().cuembed_set_backward_tuning(int(segment_len), int(column_slices), int(hot_stride))
+def set_backward_tuning(segment_len=0, column_slices=0):
+    """Launch-shape overrides of the backward kernels (tuning / tests; 0 = built-in heuristic).
+    Results never depend on them."""
+    _lib.lib().cuembed_set_backward_tuning(int(segment_len), int(column_slices))
 
 
 def get_backward_tuning():
-    out = (ctypes.c_int * 3)()
+    out = (ctypes.c_int * 2)()
     _lib.lib().cuembed_get_backward_tuning(out)
-    return dict(segment_len=out[0], column_slices=out[1], hot_stride=out[2])
-
-
-def backward_workspace_bytes(grad_dtype, index_dtype, embed_width, nnz, num_grad_y_rows):
-    """Phase 1 of cuembed::EmbeddingBackwardRunAware: scratch bytes for the run-aware backward."""
-    lwork = ctypes.c_size_t(0)
-    _lib.lib().cuembed_embedding_backward_run_aware(None, _ELEM[grad_dtype], embed_width, 0, nnz, None, None, None,
-                                                    _INDEX[index_dtype], None, 0, None, None, num_grad_y_rows,
-                                                    None, ctypes.byref(lwork), None)
-    return lwork.value
+    return dict(segment_len=out[0], column_slices=out[1])
 
 
 def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, transpose_sample_ids,
                        transpose_remapped_indices=None, transpose_weights=None,
-                       skip_grad_init=False, grad_embedding=None, inverse_mapping=None,
-                       run_aware=False, workspace=None):
+                       skip_grad_init=False, grad_embedding=None, inverse_mapping=None):
     """Scatter-add grad_y rows into the table gradient from index-sorted COO lookups.
 
     Full gradient: transpose_remapped_indices=None, num_grad_embedding_rows = table rows.
     Compressed: remapped indices given, num_grad_embedding_rows = num_unique; also returns
     inverse_mapping[num_unique].  With skip_grad_init=True the caller's grad_embedding must
-    already be zero.  Returns (grad_embedding, inverse_mapping or None).
-
-    run_aware=True (this library's extension, cuembed::EmbeddingBackwardRunAware): grad_y.shape[0]
-    is taken as the number of samples and a scratch buffer (`workspace`, allocated here when None)
-    lets the few very long runs of a skewed batch be summed chunk-major out of LDS."""
+    already be zero.  Returns (grad_embedding, inverse_mapping or None)."""
     _check_dev("grad_y", grad_y)
     dev = grad_y.device
     if grad_y.dim() != 2:
@@ -250,21 +236,6 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
                 raise TypeError("inverse_mapping must have the index dtype")
     else:
         inverse_mapping = None
-    if run_aware:
-        need = backward_workspace_bytes(grad_y.dtype, transpose_indices.dtype, width, nnz, grad_y.shape[0])
-        if workspace is None:
-            workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
-        elif workspace.numel() * workspace.element_size() < need:
-            raise ValueError("workspace too small: need %d bytes" % need)
-        _check_dev("workspace", workspace, dev)
-        lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
-        with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
-            _lib.lib().cuembed_embedding_backward_run_aware(
-                _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices),
-                _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
-                int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), grad_y.shape[0],
-                _ptr(workspace), ctypes.byref(lwork), _stream(grad_y))
-        return grad_embedding, inverse_mapping
     with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
         _lib.lib().cuembed_embedding_backward(
             _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices),

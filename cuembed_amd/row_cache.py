@@ -11,7 +11,8 @@ params + int64(index) * width, so an index of (cache_rows - params) / width + sl
 `slot` of a device buffer through the table's own base pointer.  The indices of a batch are
 rewritten with one small kernel (slot_of_row[] lookup) and the unmodified forward kernel then reads
 cached rows from HBM and only the others over PCIe.  Results are bit-identical to running on the
-table itself as long as the cached copies are current (call refresh() after updating rows)."""
+table itself as long as the cached copies are current: there is no staleness guard, the caller must
+call refresh() after updating table rows.  Lookup indices outside the table are passed through untouched."""
 import ctypes
 
 import torch
@@ -46,8 +47,13 @@ class CachedHostTable:
         self.cached_ids = torch.empty((0,), dtype=torch.int64, device=self.device)
 
     def cache_rows(self, row_ids):
-        """Make `row_ids` (distinct table rows, at most capacity_rows) the cached set."""
-        row_ids = row_ids.to(device=self.device, dtype=torch.int64).reshape(-1)[: self.capacity]
+        """Make `row_ids` (distinct table rows, at most capacity_rows) the cached set.  Raises on more ids
+        than the cache holds and on ids outside the table (one host read-back; this is not the step path)."""
+        row_ids = row_ids.to(device=self.device, dtype=torch.int64).reshape(-1)
+        if row_ids.numel() > self.capacity:
+            raise ValueError("%d rows do not fit a cache of %d rows" % (row_ids.numel(), self.capacity))
+        if row_ids.numel() and (int(row_ids.min()) < 0 or int(row_ids.max()) >= self.rows):
+            raise IndexError("row ids must lie in [0, %d)" % self.rows)
         self.slot_of_row.fill_(-1)
         self.slot_of_row[row_ids] = torch.arange(row_ids.numel(), dtype=torch.int32, device=self.device)
         self.cached_ids = row_ids
@@ -74,7 +80,7 @@ class CachedHostTable:
             with torch.cuda.device(self.device):
                 _lib.lib().cuembed_translate_indices_for_row_cache(
                     ctypes.c_void_p(indices.data_ptr()), it, indices.numel(), ctypes.c_void_p(self.slot_of_row.data_ptr()),
-                    self.cache_row_offset, ctypes.c_void_p(out.data_ptr()), _ops._stream(indices))
+                    self.rows, self.cache_row_offset, ctypes.c_void_p(out.data_ptr()), _ops._stream(indices))
         return out
 
     def forward(self, indices, offsets=None, weights=None, batch_size=None, num_hots=0, mode="sum", use_cache=True,

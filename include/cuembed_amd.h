@@ -187,22 +187,6 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
                                 const void* transpose_weights, int skip_grad_init,
                                 void* grad_embedding, void* inverse_mapping,
                                 cuembed_stream_t stream);
-/* Extension (cuembed::EmbeddingBackwardRunAware): cuembed_embedding_backward with a scratch
- * buffer and the number of grad_y rows (the batch size for sum / mean).  Two-phase like
- * cuembed_transpose: work == NULL => *lwork receives the bytes needed (never 0), nothing runs.
- * The few very long runs of a skewed batch (rows that almost every sample looks up) are then
- * summed chunk-major out of LDS -- each chunk of grad_y rows is read once for all of them --
- * instead of every such run streaming most of grad_y through the fabric again; everything else
- * runs exactly as in cuembed_embedding_backward.  Same results up to where a run is cut into
- * fp32 partial sums.  Shapes that cannot profit fall back to cuembed_embedding_backward. */
-void cuembed_embedding_backward_run_aware(const void* grad_y, int elem_type, int embed_width,
-                                          int num_grad_embedding_rows, int nnz,
-                                          const void* transpose_indices, const void* transpose_sample_ids,
-                                          const void* transpose_remapped_indices, int index_type,
-                                          const void* transpose_weights, int skip_grad_init,
-                                          void* grad_embedding, void* inverse_mapping,
-                                          int num_grad_y_rows, char* work, size_t* lwork,
-                                          cuembed_stream_t stream);
 void cuembed_transpose(const void* rows, const void* cols, const void* weights, int nnz,
                        int index_type, int weight_type, void* transpose_rows,
                        void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
@@ -248,10 +232,11 @@ void cuembed_extract_row_ids_for_concat(int nnz, int index_type, void* row_ids,
  * in elements (the buffers must differ by a whole number of rows).  cuembed_embedding_forward with
  * index_type = CUEMBED_I64 on `translated` and the table's own `params` pointer then reads cached
  * rows from HBM and the rest from the table -- same kernel, same bits.  slot_of_row: one int32 per
- * table row, -1 = not cached. */
+ * table row (num_rows entries), -1 = not cached; indices outside [0, num_rows) pass through unchanged. */
 void cuembed_translate_indices_for_row_cache(const void* indices, int index_type, int64_t nnz,
-                                             const int32_t* slot_of_row, int64_t cache_row_offset,
-                                             int64_t* translated, cuembed_stream_t stream);
+                                             const int32_t* slot_of_row, int64_t num_rows,
+                                             int64_t cache_row_offset, int64_t* translated,
+                                             cuembed_stream_t stream);
 
 /* ---- extension: gradient w.r.t. the per-lookup weights ---------------------- */
 /* grad_weights[s, j] = dot(params[indices[s, j], :], grad_y[s, :]); one entry per lookup;
@@ -269,12 +254,11 @@ void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_
 void cuembed_set_forward_reduction_order(int order);
 int cuembed_get_forward_reduction_order(void);
 /* cuembed::SetBackwardTuning / GetBackwardTuning (tuning and tests; 0 = built-in heuristic):
- * lookups per nz-segment (rounded down to a multiple of 8), XCD column slices of the gather (1, 2, 4, 8), hot-run detection stride
- * of the run-aware backward (power of two >= 256; -1 disables its hot path).  Process-wide;
- * initial values from CUEMBED_BWD_SEGMENT_LEN / CUEMBED_BWD_SLICES / CUEMBED_BWD_HOT_STRIDE, read
- * once.  Results never depend on these. */
-void cuembed_set_backward_tuning(int segment_len, int column_slices, int hot_stride);
-void cuembed_get_backward_tuning(int* out3);
+ * lookups per nz-segment (rounded down to a multiple of 8), XCD column slices of the gather
+ * (1, 2, 4, 8).  Process-wide; initial values from CUEMBED_BWD_SEGMENT_LEN / CUEMBED_BWD_SLICES,
+ * read once.  Results never depend on these. */
+void cuembed_set_backward_tuning(int segment_len, int column_slices);
+void cuembed_get_backward_tuning(int* out2);
 
 /* ---- introspection ------------------------------------------------------- */
 /* Launch shape the forward would use (no launch): out[0] = elements per lane,

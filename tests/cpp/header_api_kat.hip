@@ -208,30 +208,9 @@ void ExtensionTransposeKat(hipStream_t stream) {
   // row-cache index translation: rows 3 and 0 are cached in slots 0 and 1, cache 1000 rows above the table
   DeviceArray<int32_t> slot_of_row(std::vector<int32_t>{1, -1, -1, 0, -1});
   DeviceArray<int64_t> translated(4);
-  cuembed::TranslateIndicesForRowCache<IndexT>(idx.ptr, 4, slot_of_row.ptr, 1000, translated.ptr, stream);
+  cuembed::TranslateIndicesForRowCache<IndexT>(idx.ptr, 4, slot_of_row.ptr, 5, 1000, translated.ptr, stream);
   HIP_OK(hipStreamSynchronize(stream));
   ExpectInt("row cache translation", translated.host(), {1, 1000, 1001, 4});
-}
-
-template <typename GradT, typename IndexT>
-void ExtensionBackwardKat(hipStream_t stream) {
-  // EmbeddingBackwardRunAware on the backward KAT (too small for the hot path: must equal EmbeddingBackward)
-  DeviceArray<IndexT> t_idx(std::vector<IndexT>{0, 1, 3, 3});
-  DeviceArray<IndexT> remap(std::vector<IndexT>{0, 1, 2, 2});
-  DeviceArray<IndexT> t_sid(std::vector<IndexT>{1, 0, 0, 1});
-  DeviceArray<GradT> gy(Vec<GradT>({1, 2, 3, 4, 5, 6, 7, 8}));
-  DeviceArray<GradT> cgrad(12);
-  DeviceArray<IndexT> inv(3);
-  const GradT* no_w = nullptr;
-  size_t lwork = 0;
-  cuembed::EmbeddingBackwardRunAware<GradT, IndexT>(gy.ptr, 4, 3, 4, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false,
-                                                    cgrad.ptr, inv.ptr, /*num_grad_y_rows=*/2, nullptr, &lwork, stream);
-  DeviceArray<char> work(lwork);
-  cuembed::EmbeddingBackwardRunAware<GradT, IndexT>(gy.ptr, 4, 3, 4, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false,
-                                                    cgrad.ptr, inv.ptr, 2, work.ptr, &lwork, stream);
-  HIP_OK(hipStreamSynchronize(stream));
-  Expect("run-aware bwd compressed", cgrad.host(), {5, 6, 7, 8, 1, 2, 3, 4, 6, 8, 10, 12});
-  ExpectInt("run-aware bwd inverse mapping", inv.host(), {0, 1, 3});
 }
 
 int main() {
@@ -263,9 +242,7 @@ int main() {
   // extensions
   ExtensionTransposeKat<int32_t, float>(stream);
   ExtensionTransposeKat<int64_t, __half>(stream);
-  ExtensionBackwardKat<float, int32_t>(stream);
-  ExtensionBackwardKat<__half, int64_t>(stream);
-  cuembed::SetBackwardTuning(cuembed::BackwardTuning{0, 0, 0});
+  cuembed::SetBackwardTuning(cuembed::BackwardTuning{0, 0});
   HIP_OK(hipStreamDestroy(stream));
   if (g_failures) {
     std::fprintf(stderr, "%d known-answer checks failed\n", g_failures);

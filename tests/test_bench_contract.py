@@ -47,10 +47,41 @@ def test_roofline_entries_are_fractions():
     for o in rl["other_kernels"]:
         assert 0.0 < o["frac"] <= 1.0 and o["peak"] == bench.HBM_PEAK_GBPS
         assert o["traffic"] >= o["algorithmic_bytes_per_launch"] * 0.9      # traffic is measured, not assumed
+        # the fraction of the kernel's OWN roofline (reference formula bytes) sits next to the traffic-based one
+        assert abs(o["algorithmic_frac"] - o["algorithmic_bytes_per_launch"] / (o["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+        assert o["algorithmic_frac"] <= o["frac"] + 1e-9
+    assert abs(comp["algorithmic_frac"] - alg / 0.36e-3 / 1e9 / 8000.0) < 1e-3
     # the headline fraction: measured bytes over a plausible kernel time stays below 1
     fwd = traffic["forward_c2"]["hbm_bytes_per_launch"]
     assert fwd / 0.136e-3 / 1e9 / bench.HBM_PEAK_GBPS < 1.0
     # while the application figure exceeds the peak -- which is why it is not divided by it anywhere
     assert alg / 0.136e-3 / 1e9 > bench.HBM_PEAK_GBPS
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "pct_of_hbm_peak" not in src
+
+
+def test_traffic_file_is_stamped_with_the_kernel_sources():
+    import bench
+    sha = bench.kernel_sources_sha16()
+    assert len(sha) == 16 and int(sha, 16) >= 0
+    t = bench.load_traffic("c2")
+    assert "_sha16" in t          # None for files written before the stamp existed; bench.py then reports traffic_stale
+
+
+def test_gpus_n_starts_its_own_ranks_and_fails_cleanly_without_a_gpu():
+    """`python bench.py --gpus 2` typed as is: the parent starts two rank processes before touching any
+    GPU API; here (no GPU) both ranks refuse to run, and the parent must relay that as a non-zero exit,
+    leave no rank behind and remove the shared index stream."""
+    import glob
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-side launcher check")
+    before = set(glob.glob("/dev/shm/cuembed_bench_idx_*"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "c1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "rank" in r.stderr and "exited with code" in r.stderr
+    assert "needs a GPU" in r.stderr                      # the ranks' own message reaches the caller
+    assert r.stdout.strip() == ""                         # no JSON line from a failed job
+    assert set(glob.glob("/dev/shm/cuembed_bench_idx_*")) == before

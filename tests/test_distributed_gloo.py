@@ -57,7 +57,8 @@ def _worker(rank, world, port, csr, ret):
         t_idx, t_sid, t_w = O.transpose(sid, idx.numpy(), w.numpy())
         dense, _ = O.embedding_backward(gy, W, ncat, t_idx, t_sid, None, t_w)
         dense_t = torch.from_numpy(dense.copy())
-        D.allreduce_dense_grad(dense_t)
+        work = D.allreduce_dense_grad(dense_t, async_op=True)     # a handle on every path
+        work.wait()
         full_sid = O.extract_row_ids_from_csr(a["offsets"]) if csr else O.extract_row_ids_from_fixed(B, H)
         f_idx, f_sid, f_w = O.transpose(full_sid, a["indices"], a["weights"])
         want, _ = O.embedding_backward(gy_full, W, ncat, f_idx, f_sid, None, f_w)

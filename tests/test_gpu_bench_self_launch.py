@@ -1,0 +1,51 @@
+"""`python3 bench.py --gpus 2 --steps 20 --warmup 5`, typed exactly like that with no launcher around it:
+bench.py starts its own two rank processes (before touching the GPU), they share the box's GPU(s), rank 0's
+JSON line comes back through the parent.  This is the command a scaling run issues with N = 2, 4, 8."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                       timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_as_typed():
+    import torch
+    line = _run(["--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["scaling"] == "weak" and line["config"]["global_batch"] == 2 * 65536
+    assert line["config"]["ranks_share_gpus"] == (torch.cuda.device_count() < 2)
+    assert line["config"]["rendezvous_backend"] in ("gloo", "nccl")
+    assert line["value"] > 0 and line["roofline"]["achieved"] > 0
+    # two ranks time-sharing one GPU deliver about one GPU's worth; two GPUs about twice that
+    assert line["ms_per_step"] > 0.1
+
+
+def test_gpus_1_line_has_the_contract_fields():
+    line = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-c3"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_reference_protocol",
+              "pct_of_hbm_peak", "preroll_ms"):
+        assert k in line, k
+    rl = line["roofline"]
+    assert rl["bound"] == "l2+fabric" and 0 < rl["frac"] <= 1.0 and rl["traffic"] > 0
+    assert abs(line["pct_of_hbm_peak"] - 100 * rl["frac"]) < 0.02
+    assert "protocol" in line["config"] and line["value_reference_protocol"]["value"] > 0
+    for o in rl["other_kernels"]:
+        assert "algorithmic_frac" in o and o["algorithmic_frac"] <= o["frac"] + 1e-9
+    assert line["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True

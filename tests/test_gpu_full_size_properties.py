@@ -90,15 +90,9 @@ def test_config4_backward_compressed_full_size(ce, oracle, idx_t):
     grad16, _ = ce.embedding_backward(gy16, nu, t_idx, t_sid, remap)
     ref16 = torch.zeros((nu, W), device="cuda").index_add_(0, remap.long(), gy16.float()[t_sid.long()])
     assert float(ref16.abs().max()) < 2048 and torch.equal(grad16.float(), ref16)
-    # the extension entry points at full size, default heuristics (detection stride 8192 -> 58 hot runs):
-    # same transposed arrays without a sample-id array, same gradient through the run-aware backward
+    # the extension entry point at full size: same transposed arrays without a sample-id array
     f_idx, f_sid, _ = ce.transpose_fixed_hotness(idx, B, H, num_categories=rows)
     assert torch.equal(f_idx, t_idx) and torch.equal(f_sid, t_sid)
-    assert ce.backward_workspace_bytes(torch.float32, idx_t, W, nnz, B) > (1 << 20)      # the hot path is on
-    grad_ra, inv_ra = ce.embedding_backward(gy, nu, t_idx, t_sid, remap, run_aware=True)
-    assert torch.equal(grad_ra, grad) and torch.equal(inv_ra, inv)
-    grad16_ra, _ = ce.embedding_backward(gy16, nu, t_idx, t_sid, remap, run_aware=True)
-    assert torch.equal(grad16_ra, grad16)
     # dense gradient of a smaller table slice of the same lookups == scatter of the compressed one
     small_rows = 200_000
     keep = t_idx < small_rows

@@ -45,3 +45,20 @@ def test_host_table_with_row_cache(oracle, dtype, idx_dtype):
     assert torch.equal(t.forward(idx, num_hots=H), want)
     torch.cuda.synchronize()
     assert ce._lib.lib().cuembed_peek_last_error() == 0
+
+
+def test_row_cache_rejects_bad_ids_and_passes_foreign_indices_through():
+    from cuembed_amd.row_cache import CachedHostTable
+    host = torch.zeros((100, 8), dtype=torch.float32).pin_memory()
+    t = CachedHostTable(host, "cuda", capacity_rows=4)
+    with pytest.raises(ValueError):
+        t.cache_rows(torch.arange(5))                      # more ids than the cache holds
+    with pytest.raises(IndexError):
+        t.cache_rows(torch.tensor([1, 100]))               # outside the table
+    with pytest.raises(IndexError):
+        t.cache_rows(torch.tensor([-1]))
+    t.cache_rows(torch.tensor([7, 3]))
+    # indices outside [0, rows) are never used to index slot_of_row: they come back unchanged
+    idx = torch.tensor([3, 7, 5, 100, 1 << 40, -2], dtype=torch.int64, device="cuda")
+    tr = t.translate(idx)
+    assert tr.tolist() == [t.cache_row_offset + 1, t.cache_row_offset + 0, 5, 100, 1 << 40, -2]

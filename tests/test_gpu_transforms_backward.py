@@ -33,7 +33,7 @@ def ce():
 def tuning(ce):
     """cuembed::SetBackwardTuning for one test; the heuristics are restored afterwards."""
     yield ce.set_backward_tuning
-    ce.set_backward_tuning(0, 0, 0)
+    ce.set_backward_tuning(0, 0)
 
 
 @pytest.fixture(scope="module")

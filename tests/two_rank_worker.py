@@ -71,7 +71,8 @@ def main():
         t_idx, t_sid, t_w = ce.transpose(sid, idx.contiguous(), None if w is None else w.contiguous(),
                                          num_categories=ncat, num_rows=b_loc)
         dense, _ = ce.embedding_backward(gy, ncat, t_idx, t_sid, None, t_w)
-        D.allreduce_dense_grad(dense)
+        work = D.allreduce_dense_grad(dense, async_op=True)   # host-staged on gloo: a completed handle, not None
+        assert work is not None and work.wait() is not False and work.is_completed()
 
         # the unsharded result: HIP on the whole batch (every rank computes it) and the oracle
         f_sid = (ce.extract_row_ids_from_csr(d(a["offsets"]), nnz=a["indices"].shape[0], dtype=torch.int32)

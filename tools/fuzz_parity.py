@@ -3,8 +3,7 @@
 random table shapes, batch sizes, hotness, index distributions and types, fixed / CSR layouts,
 weights -- forward (bit-exact), row-id extraction, Transpose (bit-exact, stable; with and without the
 key / row bounds; the fused fixed-hotness variant; signed keys and arbitrary payloads), compressed-index
-remap, EmbeddingBackward dense and compressed and the run-aware variant with a random detection stride
-(exact on small-integer gradients).
+remap, EmbeddingBackward dense and compressed (exact on small-integer gradients).
 
     python tools/fuzz_parity.py [--seconds 300] [--seed 0]
 
@@ -105,15 +104,6 @@ def one_case(rng, ce, O, np, torch, verbose=False):
         got_c, got_inv = ce.embedding_backward(dev(gy), nu, d_ti, d_ts, d_remap, d_tw if use_w else None)
         assert np.array_equal(got_c.float().cpu().numpy(), want_c), ("backward compressed", desc)
         assert np.array_equal(got_inv.cpu().numpy(), want_inv), ("inverse mapping", desc)
-        # the run-aware entry point, with the hot path forced on for a random detection stride
-        stride = int(2 ** rng.integers(8, 12))
-        ce.set_backward_tuning(hot_stride=stride)
-        try:
-            ra_c, ra_inv = ce.embedding_backward(dev(gy), nu, d_ti, d_ts, d_remap, d_tw if use_w else None,
-                                                 run_aware=True)
-        finally:
-            ce.set_backward_tuning()
-        assert torch.equal(ra_c, got_c) and torch.equal(ra_inv, got_inv), ("backward run-aware", stride, desc)
         if ncat * W <= 40_000_000:
             want_d, _ = O.embedding_backward(gy.astype(np.float32), W, ncat, ti, ts, None, w32)
             got_d, _ = ce.embedding_backward(dev(gy), ncat, d_ti, d_ts, None, d_tw if use_w else None)

@@ -11,7 +11,7 @@ python bench.py > "$O/bench_c2_line.json" 2> "$O/bench.err"
 C2="--num_categories 10000000 --embed_width 256 --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true"
 C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 --hotness 128 --csr_input=true --weighted_sum=true"
 {
-  for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--run_aware" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
+  for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
     echo "== C2/C4 $ex"; benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
   for ex in "" "--bounded_sort"; do
@@ -23,7 +23,6 @@ python benchmarks/train_step_benchmark.py --exchange none > "$O/train_step_none.
 python benchmarks/train_step_benchmark.py --exchange none --reference_api >> "$O/train_step_none.json" 2>> "$O/train_step.err"
 python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_native_binding.jsonl" 2> "$O/torch_probe.err"
 CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_python_ctypes_ops.jsonl" 2>> "$O/torch_probe.err"
-python tools/hot_run_probe.py > "$O/hot_run_probe.json" 2> "$O/hot_run_probe.err"
 python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
 python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
 # profiler passes last (they clock lower); the program goes directly after `--`
@@ -46,22 +45,17 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_pipe_fetch" -- $PP > "
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_pipe_write" -- $PP >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_pipe_tcc" -- $PP >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$O/pmc_pipe.log" 2>&1
-# the run-aware backward (extension) through the same passes: its traffic is reported next to the plain one
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_ra_fetch" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_ra_write" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/pmc_ra_trace" -- $PP --run_aware >> "$O/pmc_pipe.log" 2>&1
-python "$R/tools/rocprof_summary.py" "$O/pmc_ra_trace" > "$O/pipeline_c2_run_aware_kernel_trace_stats.txt" 2>/dev/null
 cd "$R"
 python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
   --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
   --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" \
-  --run-aware-fetch "$O/pmc_ra_fetch" --run-aware-write "$O/pmc_ra_write" --out "$O/traffic_c2.json" > /dev/null
+  --out "$O/traffic_c2.json" > /dev/null
 {
-  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc pmc_ra_fetch pmc_ra_write; do
+  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc; do
     echo "#### $d"; python tools/rocprof_summary.py "$O/$d" 2>/dev/null
   done
 } > "$O/pmc_passes.txt"
-rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_ra_*
+rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_*
 # SQ issue / wait counters of the same pipeline (two passes of 8 counters)
 bash tools/pmc_sq_pass.sh > /dev/null 2>&1 && cp "$R/gpurun_out/pmc_sq.txt" "$O/pmc_sq_pipeline.txt"
 # the bench line again, now with roofline.traffic from the traffic file measured above

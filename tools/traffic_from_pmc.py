@@ -24,7 +24,10 @@ import csv
 import glob
 import json
 import os
+import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FETCH_CORRECTION = 2.0
 WRITE_CORRECTION = 1.0
@@ -61,7 +64,11 @@ def pick(disp, substr, counter):
     return [c[counter] for _, n, c in disp if substr in n and counter in c]
 
 
+ROWS = []   # (kernel tag, FETCH_SIZE KiB, WRITE_SIZE KiB, dispatches) of every entry, for --rows-out
+
+
 def entry(fetch_kb, write_kb, launches, kernel):
+    ROWS.append((kernel, fetch_kb, write_kb, launches))
     e = {"kernel": kernel, "launches_averaged": launches,
          "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb}
     if fetch_kb is not None and write_kb is not None:
@@ -72,12 +79,15 @@ def entry(fetch_kb, write_kb, launches, kernel):
 def main():
     p = argparse.ArgumentParser()
     for k in ("forward-fetch", "forward-write", "forward-tcc", "pipeline-fetch", "pipeline-write",
-              "pipeline-tcc", "pipeline-trace", "run-aware-fetch", "run-aware-write"):
+              "pipeline-tcc", "pipeline-trace", "c3-fetch", "c3-write", "c3-tcc"):
         p.add_argument("--" + k)
-    p.add_argument("--iters", type=int, required=True, help="launches per pattern in the forward passes")
+    p.add_argument("--iters", type=int, default=0, help="launches per pattern in the forward passes")
     p.add_argument("--expected-unique-read-bytes", type=int, default=65536 * 64 * 512)
     p.add_argument("--workload", default="c2 (fp16 sum, 10Mx256, batch 65536, hotness 64, alpha 1.15) + its C4 backward")
     p.add_argument("--out", required=True)
+    p.add_argument("--rows-out", help="text file: one `traffic_row` line per entry of the JSON (the per-pass averages "
+                                      "it was computed from), committed under profiles/ next to the pass summaries; "
+                                      "tests/test_bench_contract.py recomputes the JSON's byte counts from it")
     a = p.parse_args()
     res = {"workload": a.workload,
            "generated_by": "tools/traffic_from_pmc.py from the rocprofv3 --pmc passes of tools/refresh_profiles.sh",
@@ -87,7 +97,19 @@ def main():
                      "64 B), re-checked in `calibration_unique_rows`; L2->fabric requests, Infinity-Cache hits included"
                      % (FETCH_CORRECTION, WRITE_CORRECTION),
            "fetch_correction": FETCH_CORRECTION, "write_correction": WRITE_CORRECTION, "kernels": {}}
+    import bench
+    res["kernel_sources_sha16"] = bench.kernel_sources_sha16()   # bench.py reports a mismatch as traffic_stale
     K = res["kernels"]
+    if a.c3_fetch and a.c3_write:
+        # passes over `bench.py --workload c3 --no-extras --no-cpu-baseline`: every GatherReduceKernel dispatch
+        # is a C3 forward launch (two CSR batches cycled); the first launches run on cold caches: drop two
+        cf = pick(read_counters(a.c3_fetch), "GatherReduceKernel", "FETCH_SIZE")
+        cw = pick(read_counters(a.c3_write), "GatherReduceKernel", "WRITE_SIZE")
+        K["forward_c3"] = entry(avg(cf[2:]), avg(cw[2:]), len(cf) - 2, "GatherReduceKernel")
+        if a.c3_tcc:
+            t = read_counters(a.c3_tcc)
+            h, m = avg(pick(t, "GatherReduceKernel", "TCC_HIT_sum")[2:]), avg(pick(t, "GatherReduceKernel", "TCC_MISS_sum")[2:])
+            K["forward_c3"]["l2"] = {"TCC_HIT_sum": h, "TCC_MISS_sum": m, "hit_rate": round(h / (h + m), 4)}
     if a.forward_fetch and a.forward_write:
         ff = pick(read_counters(a.forward_fetch), "GatherReduceKernel", "FETCH_SIZE")
         fw = pick(read_counters(a.forward_write), "GatherReduceKernel", "WRITE_SIZE")
@@ -111,12 +133,6 @@ def main():
         bf = pick(pf, "SegmentedScatterAddKernel", "FETCH_SIZE")
         bw = pick(pw, "SegmentedScatterAddKernel", "WRITE_SIZE")
         K["backward_c4"] = entry(avg(bf), avg(bw), len(bf), "SegmentedScatterAddKernel")
-        hot_f = pick(pf, "HotRow", "FETCH_SIZE")
-        if hot_f:   # run-aware backward: the hot-row kernels belong to the same EmbeddingBackward call
-            hot_w = pick(pw, "HotRow", "WRITE_SIZE")
-            calls = len(bf)
-            K["backward_c4"]["hot_row_kernels"] = entry(sum(hot_f) / calls, sum(hot_w) / calls, calls, "HotRow*")
-            K["backward_c4"]["hbm_bytes_per_launch"] += K["backward_c4"]["hot_row_kernels"]["hbm_bytes_per_launch"]
         calls = max(len(bf), 1)     # one transpose (+ remap) per backward in the benchmark loop
         sf = [c["FETCH_SIZE"] for _, n_, c in pf if any(s in n_ for s in SORT_FAMILY) and "FETCH_SIZE" in c]
         sw = [c["WRITE_SIZE"] for _, n_, c in pw if any(s in n_ for s in SORT_FAMILY) and "WRITE_SIZE" in c]
@@ -132,22 +148,15 @@ def main():
             for name, v in tr.items():
                 if "SegmentedScatterAddKernel" in name:
                     K["backward_c4"]["kernel_ms_profiled"] = round(avg(v) / 1e6, 5)
-    if a.run_aware_fetch and a.run_aware_write:
-        # EmbeddingBackwardRunAware: detection + chunk sums + the segmented kernel without the hot blocks
-        rf, rw = read_counters(a.run_aware_fetch), read_counters(a.run_aware_write)
-        calls = max(len(pick(rf, "SegmentedScatterAddKernel", "FETCH_SIZE")), 1)
-        parts = {}
-        total_f = total_w = 0.0
-        for tag in ("HotRunDetect", "HotRowChunkSum", "SegmentedScatterAdd", "ZeroSharedAndTailRows"):
-            f_, w_ = sum(pick(rf, tag, "FETCH_SIZE")) / calls, sum(pick(rw, tag, "WRITE_SIZE")) / calls
-            parts[tag] = entry(f_, w_, calls, tag + "Kernel")
-            total_f += f_
-            total_w += w_
-        K["backward_c4_run_aware"] = entry(total_f, total_w, calls, "all kernels of one EmbeddingBackwardRunAware call")
-        K["backward_c4_run_aware"]["parts"] = parts
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
         f.write("\n")
+    if a.rows_out:
+        names = [k for k in K]                    # entries were created in the order of ROWS
+        with open(a.rows_out, "a") as f:
+            for name, (kernel, fk, wk, n) in zip(names, ROWS):
+                f.write("traffic_row %s %s FETCH_SIZE_KiB=%.4f WRITE_SIZE_KiB=%.4f dispatches=%d kernel=%s\n"
+                        % (os.path.basename(a.out), name, fk, wk, n, kernel.replace(" ", "_")))
     print(json.dumps(res, indent=1))
 
 
