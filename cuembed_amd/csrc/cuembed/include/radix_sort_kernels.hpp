@@ -187,10 +187,6 @@ __device__ __forceinline__ ArrayRoute RouteArray(const PassPlan& plan, const boo
   return r;
 }
 
-//! Offset (in 32-bit elements) of the second narrow array inside a scratch buffer of n 64-bit elements:
-//! n rounded up to a multiple of 4, so that both halves start 16-byte aligned (vector loads).
-__host__ __device__ __forceinline__ int64_t NarrowHalf(const int64_t n) { return (n + 3) & ~int64_t{3}; }
-
 //! One array of the sort in its three places; `tmp` holds n elements of T, or two arrays of n
 //! 32-bit elements when the array travels narrow.
 template <typename T>
@@ -208,7 +204,7 @@ __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int wher
                                            T (&item)[kSortItems]) {
   if constexpr (sizeof(T) == 8) {
     if (narrow && where >= kBufTmp0) {
-      const unsigned* p = reinterpret_cast<const unsigned*>(a.tmp) + (where == kBufTmp1 ? NarrowHalf(n) : 0);
+      const unsigned* p = reinterpret_cast<const unsigned*>(a.tmp) + (where == kBufTmp1 ? n : 0);
 #pragma unroll
       for (int r = 0; r < kSortItems; ++r) {
         const int64_t i = pos0 + static_cast<int64_t>(r) * stride;
@@ -471,7 +467,7 @@ __device__ __forceinline__ void StoreRouted(const SortArray<T>& a, const int whe
                                             const int64_t n, const unsigned dest, const T value) {
   if constexpr (sizeof(T) == 8) {
     if (narrow && where >= kBufTmp0) {
-      unsigned* p = reinterpret_cast<unsigned*>(a.tmp) + (where == kBufTmp1 ? NarrowHalf(n) : 0);
+      unsigned* p = reinterpret_cast<unsigned*>(a.tmp) + (where == kBufTmp1 ? n : 0);
       p[dest] = static_cast<unsigned>(value);
       return;
     }
@@ -604,327 +600,6 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     V2 item[kSortItems];
     LoadRouted<V2>(v2, v2_route.src, false, n, wave_base + lane, 64, V2(), item);
     StageAndStore<V2>(stage, item, slot, dest, count, v2, v2_route.dst, false, n);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Scatter pass, ONE WAVEFRONT per 4096-key tile (round 3; replaces the 256-thread kernel above for
-// multi-tile sorts).  The match-any ranking costs ~110 VALU instructions per round of 64 keys and a
-// 256-thread tile is VALU-issue bound on them.  Here every lane owns 64 CONSECUTIVE keys of the
-// tile ("blocked": the tile's order is lane-major), so the stable rank of a key splits into
-//     keys with a smaller digit in the tile                          (tile_start[d])
-//   + keys with the same digit in LOWER lanes                       (prefix over byte counters)
-//   + keys with the same digit EARLIER IN THIS LANE                 (the counter's old value)
-// and the counters are PRIVATE per (digit, lane): cnt[digit][lane] is one byte (a lane has at most
-// 64 keys), four lanes per dword, 256 x 64 bytes = 16 KiB per tile.  A lane bumps its own byte with
-// ds_add_rtn_u32 (1 << 8 * (lane & 3)); other lanes of the dword only ever touch other bytes, so
-// the returned byte is the lane's own running count whatever order the hardware serves the lanes
-// in -- no ballots, no peers, no dependence on the order of conflicting LDS atomics.  Then one pass
-// over the 256 rows (4 rows per lane, v_sad_u8 byte sums) turns the counters into 16-bit prefixes per
-// dword, and a key's position is two LDS reads and four VALU instructions.  About 2,500 wave
-// instructions per tile instead of ~7,000, no workgroup barriers that wait for another wave, 29 KiB
-// of LDS per tile (5 tiles per CU).
-// Keys and payloads still leave through LDS in digit order, so global stores are runs.
-constexpr int kWaveItems = kSortTile / 64;   // consecutive keys per lane
-constexpr int kWaveChunk = 16;               // of which this many are in registers at a time
-constexpr int kCntRow = 20;                  // dwords per digit row: 16 (= 64 byte counters) + 4 of padding, so that
-                                             // 16 lanes reading 16 bytes of 16 different rows cover all 64 banks
-
-typedef unsigned __attribute__((ext_vector_type(4))) sort_u4_t;
-
-//! Exclusive prefix of `v` over the 64 lanes; *total = sum over the wavefront.
-__device__ __forceinline__ unsigned WaveExclusiveScan(const unsigned v, unsigned* total) {
-  const int lane = threadIdx.x & 63;
-  unsigned incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned up = __shfl_up(incl, d);
-    if (lane >= d) incl += up;
-  }
-  *total = __shfl(incl, 63);
-  return incl - v;
-}
-
-//! kWaveChunk consecutive elements starting at element `first` of `p` (`first` is a multiple of 16
-//! elements).  `vec`: the whole tile is in range and p is 16-byte aligned -> 16-byte loads.
-template <typename T>
-__device__ __forceinline__ void LoadBlockedRaw(const T* __restrict__ p, const int64_t n, const int64_t first,
-                                               const bool vec, T (&item)[kWaveChunk]) {
-  if (vec) {
-    constexpr int kVecs = static_cast<int>(sizeof(T) * kWaveChunk / 16);
-    union { sort_u4_t raw[kVecs]; T elem[kWaveChunk]; } u;
-    const sort_u4_t* q = reinterpret_cast<const sort_u4_t*>(p + first);
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) u.raw[j] = q[j];
-#pragma unroll
-    for (int r = 0; r < kWaveChunk; ++r) item[r] = u.elem[r];
-  } else {
-#pragma unroll
-    for (int r = 0; r < kWaveChunk; ++r) item[r] = first + r < n ? p[first + r] : T();
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ bool Aligned16(const T* p) {
-  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-}
-
-//! The same from wherever the route says (see LoadRouted); `full` = the whole tile is in range.
-template <typename T>
-__device__ __forceinline__ void LoadBlocked(const SortArray<T>& a, const int where, const bool narrow,
-                                            const int64_t n, const int64_t first, const T high, const bool full,
-                                            T (&item)[kWaveChunk]) {
-  if constexpr (sizeof(T) == 8) {
-    if (narrow && where >= kBufTmp0) {
-      const unsigned* p = reinterpret_cast<const unsigned*>(a.tmp) + (where == kBufTmp1 ? NarrowHalf(n) : 0);
-      unsigned lo[kWaveChunk];
-      LoadBlockedRaw<unsigned>(p, n, first, full && Aligned16(p), lo);
-#pragma unroll
-      for (int r = 0; r < kWaveChunk; ++r) item[r] = static_cast<T>(static_cast<T>(lo[r]) | high);
-      return;
-    }
-  }
-  const T* p = where == kBufIn ? a.in : (where == kBufOut ? a.out : a.tmp);
-  LoadBlockedRaw<T>(p, n, first, full && Aligned16(p), item);
-}
-
-template <typename KeyT, typename V1, typename V2>
-struct WaveScatterLds {
-  static constexpr size_t kKey = sizeof(KeyT);
-  static constexpr size_t kV1 = std::is_same<V1, NoPayload>::value ? 0 : sizeof(V1);
-  static constexpr size_t kV2 = std::is_same<V2, NoPayload>::value ? 0 : sizeof(V2);
-  static constexpr size_t kElem = kKey > kV1 ? (kKey > kV2 ? kKey : kV2) : (kV1 > kV2 ? kV1 : kV2);
-  static constexpr size_t kStageBytes = kSortTile * kElem;
-  static constexpr size_t kCntBytes = static_cast<size_t>(kSortBins) * kCntRow * sizeof(unsigned);
-  static constexpr size_t kRegion = kStageBytes > kCntBytes ? kStageBytes : kCntBytes;
-};
-
-//! Puts one array of the tile into digit order through LDS and stores it: lane-blocked elements
-//! (fetched chunk by chunk through `fetch(chunk, item)`) go to stage[pos], then element q of the
-//! sorted tile goes to global position dest[q / 64] of lane q % 64.
-template <typename T, typename Fetch>
-__device__ __forceinline__ void WaveStageAndStore(unsigned char* region, const unsigned (&pos)[kWaveItems / 2],
-                                                  const unsigned (&dest)[kWaveItems], const int count,
-                                                  const SortArray<T>& a, const int where, const bool narrow,
-                                                  const int64_t n, Fetch fetch) {
-  T* stage = reinterpret_cast<T*>(region);
-  const int lane = threadIdx.x;
-  __syncthreads();   // the previous user of the region (counters, or the previous array) is done
-#pragma unroll
-  for (int c = 0; c < kWaveItems / kWaveChunk; ++c) {
-    T item[kWaveChunk];
-    fetch(c, item);
-#pragma unroll
-    for (int r = 0; r < kWaveChunk; ++r) {
-      const int k = c * kWaveChunk + r;
-      const unsigned p = (k & 1) ? pos[k / 2] >> 16 : pos[k / 2] & 0xffffu;
-      if (p != 0xffffu) stage[p] = item[r];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < kWaveItems; ++i) {
-    const int q = i * 64 + lane;
-    if (q < count) StoreRouted<T>(a, where, narrow, n, dest[i], stage[q]);
-  }
-}
-
-template <typename KeyT, typename V1, typename V2>
-__global__ void __launch_bounds__(64)
-RadixScatterWaveKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
-                       const int64_t n, const int pass, const int passes, const SortMode mode,
-                       const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
-                       const int num_tiles, const unsigned long long* __restrict__ state) {
-  const PassPlan plan = PlanPass(state, pass, passes, mode);
-  if (!plan.active) return;
-  const int shift = 8 * pass;
-  const unsigned flip = SignFlip(mode, pass);
-  constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
-  constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
-  const bool narrow_v1 = kHasV1 && sizeof(V1) == 8 && plan.narrow_v1;
-  const ArrayRoute key_route = RouteArray(plan, plan.narrow_keys);
-  const ArrayRoute v1_route = RouteArray(plan, narrow_v1);
-  const ArrayRoute v2_route = RouteArray(plan, false);
-  using Lds = WaveScatterLds<KeyT, V1, V2>;
-  __shared__ __attribute__((aligned(16))) unsigned char region[Lds::kRegion];  // byte counters, then the staging area
-  __shared__ __attribute__((aligned(16))) unsigned short base16[kSortBins * 16];  // [digit][lane / 4]: tile-local position
-                                                                                   // of the digit's first key in lanes >= 4 * (lane / 4)
-  __shared__ unsigned gbase[kSortBins];  // global position of the tile's first key with this digit, minus its tile-local one
-  unsigned* cnt = reinterpret_cast<unsigned*>(region);
-  const int lane = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int64_t tile_base = static_cast<int64_t>(tile) * kSortTile;
-  const int count = static_cast<int>(n - tile_base < kSortTile ? n - tile_base : kSortTile);
-  const bool full = count == kSortTile;
-  const int64_t lane_base = tile_base + lane * kWaveItems;   // the lane's first element
-  const int lane_first = lane * kWaveItems;                  // ... tile-local
-
-  {  // zero the counters (20 KiB: 20 x 16 bytes per lane)
-    sort_u4_t* z = reinterpret_cast<sort_u4_t*>(region);
-    constexpr int kVecs = static_cast<int>(Lds::kCntBytes / 16 / 64);
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) z[j * 64 + lane] = sort_u4_t{0u, 0u, 0u, 0u};
-  }
-  // global position of the tile's first key of digit d = lane + 64 * i (lane l owns four digits)
-  unsigned digit_base[4];
-  {
-    unsigned before[4], bin_sum[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = lane + 64 * i;
-      if (bin_total != nullptr) {
-        before[i] = tile_prefix[static_cast<size_t>(d) * num_tiles + tile];
-        bin_sum[i] = bin_total[d];
-      } else {  // few tiles: no scan launch -- add up the raw tile histograms of the digit here
-        const unsigned* row = tile_prefix + static_cast<size_t>(d) * num_tiles;
-        before[i] = 0;
-        bin_sum[i] = 0;
-        for (int t = 0; t < num_tiles; ++t) {
-          const unsigned c = row[t];
-          if (t < tile) before[i] += c;
-          bin_sum[i] += c;
-        }
-      }
-    }
-    unsigned carry = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned total;
-      const unsigned smaller = WaveExclusiveScan(bin_sum[i], &total);
-      digit_base[i] = carry + smaller + before[i];
-      carry += total;
-    }
-  }
-  __syncthreads();
-
-  // ---- A: count.  Digits and in-lane ranks are kept (4 per register); the keys are not. ----
-  const unsigned lane_shift = 8u * (lane & 3);
-  const unsigned lane_one = 1u << lane_shift;
-  const unsigned lane_quad = static_cast<unsigned>(lane) >> 2;
-  unsigned dig[kWaveItems / 4], rank_in_lane[kWaveItems / 4];
-#pragma unroll
-  for (int c = 0; c < kWaveItems / kWaveChunk; ++c) {
-    KeyT key[kWaveChunk];
-    LoadBlocked<KeyT>(keys, key_route.src, plan.narrow_keys, n, lane_base + c * kWaveChunk,
-                      static_cast<KeyT>(plan.key_high), full, key);
-    unsigned old[kWaveChunk];
-#pragma unroll
-    for (int r = 0; r < kWaveChunk; ++r) {
-      const int k = c * kWaveChunk + r;
-      const unsigned d = static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip;
-      if ((k & 3) == 0) dig[k / 4] = d; else dig[k / 4] |= d << (8 * (k & 3));
-      old[r] = 0;
-      if (full || lane_first + k < count) old[r] = atomicAdd(&cnt[d * kCntRow + lane_quad], lane_one);
-    }
-#pragma unroll
-    for (int r = 0; r < kWaveChunk; ++r) {
-      const int k = c * kWaveChunk + r;
-      const unsigned mine = (old[r] >> lane_shift) & 0xffu;
-      if ((k & 3) == 0) rank_in_lane[k / 4] = mine; else rank_in_lane[k / 4] |= mine << (8 * (k & 3));
-    }
-  }
-  __syncthreads();
-
-  // ---- B: rows of byte counters -> 16-bit prefixes per dword; digit totals -> tile-local starts ----
-  {
-    unsigned w[4][16], total[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const sort_u4_t* row = reinterpret_cast<const sort_u4_t*>(cnt + (lane + 64 * i) * kCntRow);
-      total[i] = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const sort_u4_t v = row[j];
-        w[i][4 * j + 0] = v.x; w[i][4 * j + 1] = v.y; w[i][4 * j + 2] = v.z; w[i][4 * j + 3] = v.w;
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) total[i] = __builtin_amdgcn_sad_u8(w[i][j], 0u, total[i]);
-    }
-    unsigned carry = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned sum;
-      const unsigned tile_start = carry + WaveExclusiveScan(total[i], &sum);
-      carry += sum;
-      const int d = lane + 64 * i;
-      gbase[d] = digit_base[i] - tile_start;
-      unsigned running = tile_start;
-      unsigned packed[8];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if ((j & 1) == 0) packed[j / 2] = running; else packed[j / 2] |= running << 16;
-        running = __builtin_amdgcn_sad_u8(w[i][j], 0u, running);
-      }
-      sort_u4_t* out = reinterpret_cast<sort_u4_t*>(base16 + d * 16);
-      out[0] = sort_u4_t{packed[0], packed[1], packed[2], packed[3]};
-      out[1] = sort_u4_t{packed[4], packed[5], packed[6], packed[7]};
-    }
-  }
-  __syncthreads();
-
-  // ---- C: tile-local position of every key in digit order (two per register) ----
-  unsigned pos[kWaveItems / 2];
-  {
-    const unsigned lane_mask = lane_one - 1u;   // the bytes of the lower lanes of my dword
-#pragma unroll
-    for (int k = 0; k < kWaveItems; ++k) {
-      const unsigned d = (dig[k / 4] >> (8 * (k & 3))) & 0xffu;
-      const unsigned r = (rank_in_lane[k / 4] >> (8 * (k & 3))) & 0xffu;
-      const unsigned c32 = cnt[d * kCntRow + lane_quad];
-      const unsigned b = base16[d * 16 + lane_quad];
-      unsigned p = __builtin_amdgcn_sad_u8(c32 & lane_mask, 0u, b + r);
-      if (!(full || lane_first + k < count)) p = 0xffffu;
-      if ((k & 1) == 0) pos[k / 2] = p; else pos[k / 2] |= p << 16;
-    }
-  }
-
-  // ---- keys: through LDS into digit order, then out in runs; dest[] serves the payloads too ----
-  unsigned dest[kWaveItems];
-  {
-    KeyT* stage = reinterpret_cast<KeyT*>(region);
-    __syncthreads();   // every counter has been read
-#pragma unroll
-    for (int c = 0; c < kWaveItems / kWaveChunk; ++c) {
-      KeyT key[kWaveChunk];   // second read of the tile's keys (L2): cheaper than 64 live registers
-      LoadBlocked<KeyT>(keys, key_route.src, plan.narrow_keys, n, lane_base + c * kWaveChunk,
-                        static_cast<KeyT>(plan.key_high), full, key);
-#pragma unroll
-      for (int r = 0; r < kWaveChunk; ++r) {
-        const int k = c * kWaveChunk + r;
-        const unsigned p = (k & 1) ? pos[k / 2] >> 16 : pos[k / 2] & 0xffffu;
-        if (p != 0xffffu) stage[p] = key[r];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kWaveItems; ++i) {
-      const int q = i * 64 + lane;
-      if (q < count) {
-        const KeyT k = stage[q];
-        const unsigned d = static_cast<unsigned>((k >> shift) & 0xff) ^ flip;
-        dest[i] = gbase[d] + static_cast<unsigned>(q);
-        StoreRouted<KeyT>(keys, key_route.dst, plan.narrow_keys, n, dest[i], k);
-      }
-    }
-  }
-  if constexpr (kHasV1) {
-    const bool implicit_v1 = plan.first && mode.v1_div > 0;
-    WaveStageAndStore<V1>(region, pos, dest, count, v1, v1_route.dst, narrow_v1, n,
-                          [&](const int c, V1 (&item)[kWaveChunk]) {
-                            if (implicit_v1) {
-#pragma unroll
-                              for (int r = 0; r < kWaveChunk; ++r)
-                                item[r] = static_cast<V1>(ImplicitPayload(mode, lane_base + c * kWaveChunk + r));
-                            } else {
-                              LoadBlocked<V1>(v1, v1_route.src, narrow_v1, n, lane_base + c * kWaveChunk, V1(0), full, item);
-                            }
-                          });
-  }
-  if constexpr (kHasV2) {
-    WaveStageAndStore<V2>(region, pos, dest, count, v2, v2_route.dst, false, n,
-                          [&](const int c, V2 (&item)[kWaveChunk]) {
-                            LoadBlocked<V2>(v2, v2_route.src, false, n, lane_base + c * kWaveChunk, V2(), full, item);
-                          });
   }
 }
 
@@ -1108,7 +783,7 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     if (scan_blocks > 0)
       RadixScanTilesKernel<<<scan_blocks, kSortThreads, 0, stream>>>(
           tile_hist, plan.num_tiles, bin_total, p, plan.passes, mode, tile_bits, state);
-    RadixScatterWaveKernel<KeyT, V1, V2><<<plan.num_tiles, 64, 0, stream>>>(
+    RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, v1, v2, count, p, plan.passes, mode, tile_hist, fold_scan ? nullptr : bin_total,
         plan.num_tiles, state);
   }
