@@ -104,13 +104,14 @@ template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream,
-                             const int64_t zero_rows /* > 0: zero only what needs it, see below */,
+                             const bool zero_shared /* compressed gradient: zero only what needs it, see below */,
+                             const int64_t zero_rows /* ... and the rows from the last id up to here (<= 0: none) */,
                              const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */) {
   const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr);
   const dim3 block(s.lanes, s.segments_per_block, 1);
   const int block_len = s.segments_per_block * s.segment_len;
-  if (zero_rows > 0) {
-    const int64_t tail_blocks = (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock;
+  if (zero_shared) {
+    const int64_t tail_blocks = zero_rows > 0 ? (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock : 0;
     ZeroSharedAndTailRowsKernel<GradT, IndexT><<<static_cast<unsigned>(s.nz_blocks + tail_blocks), 256, 0, stream>>>(
         rows, nnz, block_len, s.nz_blocks, width, zero_rows, grad_out);
   }
@@ -137,6 +138,13 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
  * `inverse_mapping[num_unique]` receives the table row of each).  Same contract
  * as the reference (embedding_lookup.cuh:397-483): the output must be zero
  * before the scatter; `skip_grad_init` means the caller already zeroed it.
+ *
+ * Extension: a compressed call may pass `num_grad_embedding_rows < 0` = "the number of unique rows
+ * is only known on the device" (it is transpose_remapped_indices[nnz - 1] + 1).  `grad_embedding`
+ * and `inverse_mapping` must then hold at least that many rows (nnz always suffices); rows past
+ * the last id are left untouched.  This takes the host read-back of num_unique out of a training
+ * step (the reference's benchmark reads it back between Transpose and EmbeddingBackward,
+ * manual_benchmark.cu:392-394).
  */
 template <typename GradT, typename IndexT>
 void EmbeddingBackward(const GradT* grad_y,
@@ -160,18 +168,20 @@ void EmbeddingBackward(const GradT* grad_y,
       transpose_remapped_indices != nullptr ? transpose_remapped_indices : transpose_indices;
 
   if (transpose_remapped_indices != nullptr && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
+  if (transpose_remapped_indices == nullptr) CUEMBED_ASSERT(num_grad_embedding_rows >= 0);  // "unknown" is a compressed-only extension
   // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
   // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
   // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
   const bool compressed = transpose_remapped_indices != nullptr;
-  if (!skip_grad_init && (!compressed || nnz <= 0)) {
+  if (!skip_grad_init && (!compressed || nnz <= 0) && num_grad_embedding_rows > 0) {
     (void)hipMemsetAsync(grad_embedding, 0,
                          static_cast<size_t>(num_grad_embedding_rows) *
                              static_cast<size_t>(embed_width) * sizeof(GradT),
                          stream);
   }
   if (nnz <= 0) return;
-  const int64_t zero_rows = (!skip_grad_init && compressed) ? num_grad_embedding_rows : 0;
+  const bool zero_shared = !skip_grad_init && compressed;
+  const int64_t zero_rows = num_grad_embedding_rows;
 
   const IndexT* run_ids = compressed ? transpose_indices : nullptr;  // inverse mapping is written by the scatter
   const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
@@ -180,13 +190,13 @@ void EmbeddingBackward(const GradT* grad_y,
   constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
   if (split.elems_per_lane == kMaxN)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
-                                                   stream, zero_rows, run_ids, inverse_mapping);
+                                                   stream, zero_shared, zero_rows, run_ids, inverse_mapping);
   else if (split.elems_per_lane == kMaxN / 2)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
-                                                       split, stream, zero_rows, run_ids, inverse_mapping);
+                                                       split, stream, zero_shared, zero_rows, run_ids, inverse_mapping);
   else
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
-                                                       split, stream, zero_rows, run_ids, inverse_mapping);
+                                                       split, stream, zero_shared, zero_rows, run_ids, inverse_mapping);
 }
 
 }  // namespace cuembed

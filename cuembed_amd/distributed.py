@@ -104,41 +104,51 @@ def _merge_on_gpu(ids, vals, num_categories):
     """Sum rows that carry the same id with the library's own kernels: the merge of the gathered
     (id, row) pairs IS an embedding backward -- Transpose sorts the ids (carrying the position of
     each row), ComputeCompressedGradIndices numbers the distinct ids, and EmbeddingBackward adds
-    the rows of each run (fp32 partial sums) into the compressed result."""
+    the rows of each run (fp32 partial sums) into the compressed result.
+    Returns (ids[capacity], rows[capacity, W], count) with count a 1-element device tensor: the
+    number of distinct ids stays on the device (EmbeddingBackward's num_grad_embedding_rows=None
+    extension), so the merge itself has no host read-back."""
     from . import ops
     m = ids.numel()
-    if m == 0:                       # every rank's compressed gradient was empty
-        return ids, vals
     pos = ops.extract_row_ids_for_concat(m, torch.int64, ids.device)
     t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories, num_rows=m)
     remap = ops.compute_compressed_grad_indices(t_ids)
-    num_unique = int(remap[-1].item()) + 1
-    merged, uniq = ops.embedding_backward(vals.contiguous(), num_unique, t_ids, t_pos, remap)
-    return uniq, merged
+    cap = min(m, num_categories)
+    merged = torch.empty((cap, vals.shape[1]), dtype=vals.dtype, device=vals.device)
+    uniq = torch.empty((cap,), dtype=torch.int64, device=vals.device)
+    ops.embedding_backward(vals.contiguous(), None, t_ids, t_pos, remap, grad_embedding=merged, inverse_mapping=uniq)
+    return uniq, merged, remap[-1:] + 1
 
 
 def _merge(ids, vals, num_categories):
-    """Sum rows with equal id; returns (ascending unique ids, summed rows)."""
+    """Sum rows with equal id; returns (ascending unique ids, summed rows, count) -- on the GPU padded to a
+    capacity with `count` a 1-element device tensor, on the CPU exact with count = None."""
+    if ids.numel() == 0:                 # nothing was gathered (every rank's compressed gradient was empty)
+        return ids, vals, None
     if vals.is_cuda:
         return _merge_on_gpu(ids, vals, num_categories)
     uniq, inverse = torch.unique(ids, sorted=True, return_inverse=True)
     summed = torch.zeros((uniq.numel(), vals.shape[1]), dtype=torch.float32, device=vals.device)
     summed.index_add_(0, inverse, vals.float())
-    return uniq, summed.to(vals.dtype)
+    return uniq, summed.to(vals.dtype), None
 
 
-def _gather_ragged(ids, vals, group):
+def _gather_ragged(ids, vals, group, count=None):
     """all-gather of per-rank (ids[n_r], vals[n_r, W]) with different n_r (padded to the maximum).
-    Returns the concatenation in rank order."""
+    `count` (1-element tensor on the tensors' device, or None = all rows) is the number of valid
+    leading rows of this rank.  Returns the concatenation in rank order.  ONE host read-back: all
+    ranks' counts."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
+    n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device) if count is None \
+        else count.reshape(1).to(torch.int64)
     counts = torch.cat(_all_gather(n, group)).tolist()          # one host read-back for all ranks' counts
     cap = max(max(counts), 1)
+    have = min(cap, vals.shape[0])
     pad_vals = torch.zeros((cap, vals.shape[1]), dtype=vals.dtype, device=vals.device)
-    pad_vals[: vals.shape[0]] = vals
+    pad_vals[:have] = vals[:have]
     pad_ids = torch.full((cap,), -1, dtype=torch.int64, device=ids.device)
-    pad_ids[: ids.shape[0]] = ids
+    pad_ids[:have] = ids[:have]
     all_vals = _all_gather(pad_vals, group)
     all_ids = _all_gather(pad_ids, group)
     return (torch.cat([all_ids[r][: counts[r]] for r in range(world)]),
@@ -150,12 +160,14 @@ def owner_bounds(num_categories, world):
     return [shard_bounds(num_categories, r, world) for r in range(world)]
 
 
-def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, algorithm="auto"):
+def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, algorithm="auto", num_unique=None):
     """Sum compressed gradients across ranks without materialising the dense table gradient.
 
     rows[num_unique_r, W] / inverse_mapping[num_unique_r] are this rank's compressed gradient
-    (EmbeddingBackward with remapped indices; ids ascending).  Returns (unique_ids, summed_rows),
-    identical on every rank.  Two algorithms:
+    (EmbeddingBackward with remapped indices; ids ascending).  `num_unique` (optional, a 1-element
+    device tensor, e.g. remap[-1:] + 1): only that many leading rows are valid -- for buffers that
+    were sized for the worst case because the count never left the device.  Returns
+    (unique_ids, summed_rows), identical on every rank.  Two algorithms:
 
       "allgather": every rank all-gathers all (id, row) pairs and merges them locally with one
                    sort + segmented sum.  Per rank ~ G * n * (W * elem + 8) bytes come in and
@@ -169,7 +181,9 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
       "auto"     : "owner" for more than 2 ranks, else "allgather".
 
     Either way the traffic is a few hundred MB per rank instead of num_categories * W * elem for
-    the dense all-reduce (at the north-star shape 293 MB vs 5.12 GB of gradient per rank)."""
+    the dense all-reduce (at the north-star shape 293 MB vs 5.12 GB of gradient per rank).
+    Host read-backs: two per call (the ranks' row counts before the exchange of rows; the size of the
+    result), whatever the algorithm -- the sizes of the tensors exchanged and returned are host values."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if algorithm == "auto":
@@ -178,24 +192,28 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
         raise ValueError("algorithm must be 'auto', 'allgather' or 'owner'")
     ids = inverse_mapping.to(torch.int64)
     if algorithm == "allgather":
-        all_ids, all_vals = _gather_ragged(ids, rows, group)
-        return _merge(all_ids, all_vals, num_categories)
+        all_ids, all_vals = _gather_ragged(ids, rows, group, count=num_unique)     # read-back 1: the ranks' counts
+        uniq, summed, count = _merge(all_ids, all_vals, num_categories)
+        if count is None:
+            return uniq, summed
+        k = int(count.item())                                                        # read-back 2: size of the result
+        return uniq[:k], summed[:k]
 
     # ---- owner-partitioned: all-to-all, merge my range, all-gather the merged pieces ----
     bounds = owner_bounds(num_categories, world)
     cuts = torch.tensor([b[0] for b in bounds] + [num_categories], dtype=torch.int64, device=ids.device)
+    if num_unique is not None:       # rows past the count hold nothing: give them an id beyond every range
+        valid = torch.arange(ids.numel(), device=ids.device) < num_unique.reshape(1).to(ids.device)
+        ids = torch.where(valid, ids, torch.full_like(ids, num_categories))
     pos = torch.searchsorted(ids, cuts)                      # ids ascend: range r = [pos[r], pos[r+1])
     send = (pos[1:] - pos[:-1]).to(torch.int64)
     # every rank learns the whole world x world split matrix with ONE collective and ONE host read-back
-    # (an all-to-all of the counts plus two .tolist() calls before)
-    splits = torch.stack(_all_gather(send, group)).tolist()
+    splits = torch.stack(_all_gather(send, group)).tolist()                          # read-back 1
     rank = dist.get_rank(group)
     send_l, recv_l = splits[rank], [splits[r][rank] for r in range(world)]
-    got_ids = _all_to_all_single(ids, recv_l, send_l, group)
-    got_vals = _all_to_all_single(rows, recv_l, send_l, group)
-    if got_ids.numel() > 0:
-        mine_ids, mine_vals = _merge(got_ids, got_vals, num_categories)
-    else:
-        mine_ids, mine_vals = got_ids, got_vals
+    total = sum(send_l)
+    got_ids = _all_to_all_single(ids[:total], recv_l, send_l, group)
+    got_vals = _all_to_all_single(rows[:total], recv_l, send_l, group)
+    mine_ids, mine_vals, count = _merge(got_ids, got_vals, num_categories)
     # owners hold disjoint, ascending id ranges in rank order: the concatenation is already sorted
-    return _gather_ragged(mine_ids.to(torch.int64), mine_vals, group)
+    return _gather_ragged(mine_ids.to(torch.int64), mine_vals, group, count=count)   # read-back 2

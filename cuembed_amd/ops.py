@@ -193,7 +193,12 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
     Full gradient: transpose_remapped_indices=None, num_grad_embedding_rows = table rows.
     Compressed: remapped indices given, num_grad_embedding_rows = num_unique; also returns
     inverse_mapping[num_unique].  With skip_grad_init=True the caller's grad_embedding must
-    already be zero.  Returns (grad_embedding, inverse_mapping or None)."""
+    already be zero.  Returns (grad_embedding, inverse_mapping or None).
+
+    Extension (compressed only): num_grad_embedding_rows=None = "num_unique is only known on the device"
+    (it is transpose_remapped_indices[-1] + 1).  grad_embedding and inverse_mapping must then be given
+    with at least that many rows (min(nnz, table rows) always suffices); rows past the last id are
+    left untouched and no host read-back is needed before the call."""
     _check_dev("grad_y", grad_y)
     dev = grad_y.device
     if grad_y.dim() != 2:
@@ -209,6 +214,15 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
         raise ValueError("transpose_sample_ids must have nnz entries")
     width = grad_y.shape[1]
     compressed = transpose_remapped_indices is not None
+    unknown_rows = num_grad_embedding_rows is None
+    if unknown_rows:
+        if not compressed or grad_embedding is None or inverse_mapping is None:
+            raise ValueError("num_grad_embedding_rows=None needs a compressed call with grad_embedding and "
+                             "inverse_mapping buffers given")
+        if grad_embedding.dim() != 2 or grad_embedding.shape[1] != width or \
+                inverse_mapping.numel() < grad_embedding.shape[0]:
+            raise ValueError("grad_embedding must be [capacity, width] and inverse_mapping hold capacity entries")
+        num_grad_embedding_rows = grad_embedding.shape[0]
     if compressed:
         _check_dev("transpose_remapped_indices", transpose_remapped_indices, dev)
         if transpose_remapped_indices.dtype != transpose_indices.dtype or \
@@ -238,7 +252,7 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
         inverse_mapping = None
     with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
         _lib.lib().cuembed_embedding_backward(
-            _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices),
+            _ptr(grad_y), et, width, -1 if unknown_rows else num_grad_embedding_rows, nnz, _ptr(transpose_indices),
             _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
             int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), _stream(grad_y))
     return grad_embedding, inverse_mapping

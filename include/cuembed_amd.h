@@ -180,6 +180,11 @@ void cuembed_embedding_forward(const void* params, int elem_type, int embed_widt
                                int offset_type, const void* weights, int batch_size,
                                int num_hots, int mode, int fp16_math, void* ret,
                                cuembed_stream_t stream);
+/* Extension: with a compressed gradient (transpose_remapped_indices != NULL) num_grad_embedding_rows may
+ * be negative = "num_unique is only known on the device" (it is transpose_remapped_indices[nnz-1] + 1):
+ * grad_embedding / inverse_mapping must hold at least that many rows (nnz always suffices), rows past
+ * the last id are left untouched, and no host read-back is needed between ComputeCompressedGradIndices
+ * and EmbeddingBackward.  Applies to the typed entry points as well. */
 void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_width,
                                 int num_grad_embedding_rows, int nnz,
                                 const void* transpose_indices, const void* transpose_sample_ids,

@@ -74,6 +74,16 @@ def _worker(rank, world, port, csr, ret):
             rebuilt = np.zeros_like(want)
             rebuilt[ids.numpy()] = rows.numpy()
             assert np.array_equal(rebuilt, want), algorithm
+        # buffers sized for the worst case with the count in a tensor (what a step without host read-backs hands over)
+        pad = 5 + rank
+        comp_pad = np.concatenate([comp, np.full((pad, W), 777.0, dtype=comp.dtype)])
+        inv_pad = np.concatenate([inv, np.full((pad,), 3, dtype=inv.dtype)])           # garbage ids past the count
+        for algorithm in ("allgather", "owner"):
+            ids, rows = D.allreduce_sparse_grad(torch.from_numpy(comp_pad), torch.from_numpy(inv_pad), ncat,
+                                                algorithm=algorithm, num_unique=torch.tensor([nu]))
+            rebuilt = np.zeros_like(want)
+            rebuilt[ids.numpy()] = rows.numpy()
+            assert np.array_equal(rebuilt, want), ("padded", algorithm)
         # nothing to exchange on any rank (a batch without lookups)
         for algorithm in ("allgather", "owner"):
             ids, rows = D.allreduce_sparse_grad(torch.empty((0, W)), torch.empty((0,), dtype=torch.int64), ncat,

@@ -101,3 +101,71 @@ def test_config4_backward_compressed_full_size(ce, oracle, idx_t):
     sel = inv < small_rows
     ref[inv[sel].long()] = grad[sel.nonzero().squeeze(1)]
     assert torch.equal(dense, ref)
+
+
+def _sub_coo(remap, t_idx, t_sid, dense_ids):
+    """The lookups of the selected runs (dense ids, ascending) as host arrays with the runs renumbered 0..k-1."""
+    d = dense_ids.to(remap.dtype)
+    lo = torch.searchsorted(remap, d)
+    hi = torch.searchsorted(remap, d + 1)
+    lens = (hi - lo)
+    pos = torch.repeat_interleave(lo, lens) + (torch.arange(int(lens.sum()), device=remap.device)
+                                               - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens))
+    new_remap = torch.repeat_interleave(torch.arange(d.numel(), device=remap.device), lens).to(torch.int32)
+    return (t_idx[pos].cpu().numpy().astype(np.int32), t_sid[pos].cpu().numpy().astype(np.int32),
+            new_remap.cpu().numpy(), lens.cpu().numpy())
+
+
+def test_config4_backward_reference_grad_y_recipe_against_oracle(ce, oracle):
+    """C4 at full size on the REFERENCE's own inputs: power-law indices of the manual_benchmark shape and
+    grad_y from AllocateBackward's recipe (integers U{-10..10}, engine 654321,
+    utils/src/embedding_allocation.cu:221-247), against the CPU oracle (embedding_lookup_cpu.hpp:96-144)
+    run on a sample of the runs -- 3,000 random rows plus the 64 longest runs:
+      fp32: every sampled row bit-exact (integer sums < 2^24 are exact in any order);
+      fp16: rows whose run is at most 204 lookups long keep every partial sum below 2048, where the
+            reference's per-lookup fp16 rounding is exact: bit-exact against the oracle; the longer runs
+            are compared with the exact (fp64) sum within the documented bound of fp32 partial sums +
+            16-bit flushes (tests/test_gpu_backward_tolerance.py::_hip_error_bound)."""
+    from cuembed_amd import harness
+    from test_gpu_backward_tolerance import EPS, TINY, _hip_error_bound   # noqa: F401
+    rows, W, B, H = 10_000_000, 256, 65536, 64
+    idx = torch.from_numpy(harness.generate_indices(rows, B, H, alpha=1.15)).cuda()
+    t_idx, t_sid, _ = ce.transpose_fixed_hotness(idx, B, H, num_categories=rows)
+    remap = ce.compute_compressed_grad_indices(t_idx)
+    nu = int(remap[-1].item()) + 1
+    counts = torch.bincount(remap.long(), minlength=nu)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    sample = torch.randperm(nu, device="cuda", generator=g)[:3000]
+    longest = torch.topk(counts, 64).indices
+    chosen = torch.unique(torch.cat([sample, longest]))                      # ascending dense ids
+    s_idx, s_sid, s_remap, lens = _sub_coo(remap, t_idx, t_sid, chosen)
+    assert lens.max() > 60000 and (lens == 1).any() and lens.sum() == s_idx.shape[0]
+    k = chosen.numel()
+    for elem in (np.float32, np.float16):
+        gy_host = harness.allocate_grad_y(B * W, elem).reshape(B, W)
+        assert gy_host.min() == -10 and gy_host.max() == 10 and np.array_equal(gy_host, np.rint(gy_host))
+        gy = torch.from_numpy(gy_host).cuda()
+        grad, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
+        got = grad[chosen].float().cpu().numpy()
+        want, want_inv = oracle.embedding_backward(gy_host, W, k, s_idx, s_sid, s_remap)
+        assert np.array_equal(inv[chosen].cpu().numpy(), want_inv)
+        if elem == np.float32:
+            assert np.array_equal(got, want)                                # all 3,000+ rows, every element
+            continue
+        short = lens <= 204
+        assert short.sum() > 2500 and (~short).sum() >= 58
+        assert np.array_equal(got[short], want[short].astype(np.float32))   # the reference's arithmetic, bit for bit
+        # the long runs: exact integer sums in fp64, and the bound of this library's arithmetic
+        terms = gy_host.astype(np.float64)
+        exact = np.zeros((k, W))
+        np.add.at(exact, s_remap, terms[s_sid])
+        scale = np.zeros((k, W))
+        np.add.at(scale, s_remap, np.abs(terms[s_sid]))
+        sq = np.zeros((k, W))
+        np.add.at(sq, s_remap, terms[s_sid] ** 2)
+        bound = _hip_error_bound("f16", exact, scale, np.sqrt(sq), lens)
+        err = np.abs(got.astype(np.float64) - exact)
+        assert np.all(err[~short] <= bound[~short]), float((err - bound)[~short].max())
+        # for the record: where no partial sum leaves the integers fp16 holds exactly, the result IS the integer sum
+        small = (~short) & (scale.max(axis=1) < 2048)
+        assert np.array_equal(got[small].astype(np.float64), exact[small])

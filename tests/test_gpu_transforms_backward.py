@@ -381,6 +381,20 @@ def test_backward_compressed_zero_init_without_full_memset(ce, oracle):
             want, winv = oracle.embedding_backward(gy.astype(np.float32), W, nu + extra, ti, ts, remap)
             assert np.array_equal(host(got).astype(np.float32), want), (elem[0], extra)
             assert np.array_equal(host(inv)[:nu], winv[:nu])
+        # extension: num_unique unknown on the host (num_grad_embedding_rows=None -> -1 in the C ABI): worst-case
+        # buffers, the first num_unique rows are the gradient, everything past the last id is left untouched
+        cap = min(ti.shape[0], ncat)
+        buf = torch.full((cap, W), 123.0, dtype=elem[1], device="cuda")
+        ibuf = torch.full((cap,), -5, dtype=torch.int32, device="cuda")
+        got, inv = ce.embedding_backward(dev(gy), None, dev(ti), dev(ts), dev(remap), grad_embedding=buf,
+                                         inverse_mapping=ibuf)
+        want, winv = oracle.embedding_backward(gy.astype(np.float32), W, nu, ti, ts, remap)
+        assert np.array_equal(host(got[:nu]).astype(np.float32), want) and np.array_equal(host(inv[:nu]), winv)
+        assert bool((got[nu:] == 123.0).all()) and bool((inv[nu:] == -5).all())
+        with pytest.raises(ValueError):
+            ce.embedding_backward(dev(gy), None, dev(ti), dev(ts), dev(remap))       # buffers are required
+        with pytest.raises(ValueError):
+            ce.embedding_backward(dev(gy), None, dev(ti), dev(ts), grad_embedding=buf, inverse_mapping=ibuf)  # dense
 
 
 @pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])

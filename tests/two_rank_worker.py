@@ -89,6 +89,19 @@ def main():
         remap = ce.compute_compressed_grad_indices(t_idx)
         nu = int(remap[-1].item()) + 1
         rows, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap, t_w)
+        # the same without the read-back: worst-case buffers, num_unique stays on the device
+        cap = min(t_idx.numel(), ncat)
+        rows_cap = torch.full((cap, W), 333.0, dtype=torch.float16, device=dev)
+        inv_cap = torch.full((cap,), 7, dtype=torch.int32, device=dev)
+        ce.embedding_backward(gy, None, t_idx, t_sid, remap, t_w, grad_embedding=rows_cap, inverse_mapping=inv_cap)
+        check("backward without num_unique on the host", torch.equal(rows_cap[:nu], rows) and torch.equal(inv_cap[:nu], inv)
+              and bool((rows_cap[nu:] == 333.0).all()))
+        for algorithm in ("allgather", "owner"):
+            ids, summed = D.allreduce_sparse_grad(rows_cap, inv_cap, ncat, algorithm=algorithm, num_unique=remap[-1:] + 1)
+            check(algorithm + ": exchange of worst-case buffers", bool((ids[1:] > ids[:-1]).all()))
+            rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device=dev)
+            rebuilt[ids.long()] = summed
+            check(algorithm + ": padded sparse exchange == dense all-reduce", torch.equal(rebuilt, dense))
         for algorithm in ("allgather", "owner"):
             ids, summed = D.allreduce_sparse_grad(rows, inv, ncat, algorithm=algorithm)
             check(algorithm + ": ids ascending and unique", bool((ids[1:] > ids[:-1]).all()))
