@@ -252,12 +252,12 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
     high = static_cast<KeyT>(plan.key_high);
     where = RouteArray(plan, narrow).src;
   }
-#pragma unroll
-  for (int w = 0; w < kSortWaves; ++w) count[w][tid] = 0;
-  __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile + tid;
   KeyT key[kSortItems];
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
+#pragma unroll
+  for (int w = 0; w < kSortWaves; ++w) count[w][tid] = 0;
+  __syncthreads();
   const bool reduce_bits = pass == 0 && tile_bits != nullptr;
   if (reduce_bits) {
     unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
@@ -525,6 +525,20 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   const int lane = tid & 63;
   const int64_t tile_base = static_cast<int64_t>(blockIdx.x) * kSortTile;
   const int count = static_cast<int>(n - tile_base < kSortTile ? n - tile_base : kSortTile);
+  // ---- load first (everything in flight at once): the digit bases below are computed under the loads' latency ----
+  const int64_t wave_base = tile_base + wave * (64 * kSortItems);
+  KeyT key[kSortItems];
+  LoadRouted<KeyT>(keys, key_route.src, plan.narrow_keys, n, wave_base + lane, 64,
+                   static_cast<KeyT>(plan.key_high), key);
+  // A 32-bit first payload is requested now as well, so that its latency overlaps the ranking.
+  // A 64-bit one would push the kernel past 128 VGPRs (3 instead of 4 resident workgroups per CU,
+  // i.e. a second round for a quarter of the 1024 tiles); it is loaded after the keys have left.
+  constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
+  V1 item1[kSortItems];
+  const bool implicit_v1 = kHasV1 && plan.first && mode.v1_div > 0;
+  if constexpr (kEarlyV1) {
+    if (!implicit_v1) LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
+  }
   {
     unsigned before_me, bin_sum;
     if (bin_total != nullptr) {
@@ -549,20 +563,7 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   }
   __syncthreads();
 
-  // ---- load (everything in flight at once), then rank inside the wave ----
-  const int64_t wave_base = tile_base + wave * (64 * kSortItems);
-  KeyT key[kSortItems];
-  LoadRouted<KeyT>(keys, key_route.src, plan.narrow_keys, n, wave_base + lane, 64,
-                   static_cast<KeyT>(plan.key_high), key);
-  // A 32-bit first payload is requested now as well, so that its latency overlaps the ranking.
-  // A 64-bit one would push the kernel past 128 VGPRs (3 instead of 4 resident workgroups per CU,
-  // i.e. a second round for a quarter of the 1024 tiles); it is loaded after the keys have left.
-  constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
-  V1 item1[kSortItems];
-  const bool implicit_v1 = kHasV1 && plan.first && mode.v1_div > 0;
-  if constexpr (kEarlyV1) {
-    if (!implicit_v1) LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
-  }
+  // ---- rank inside the wave ----
   unsigned slot[kSortItems];  // tile-local position in digit order
   RankTile<KeyT>(key, shift, flip, wave * (64 * kSortItems) + lane, count, wave_count, tile_start, slot);
 

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-python bench.py > "$O/bench_c2_line.json" 2> "$O/bench.err"
+python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2> "$O/bench.err"     # the driver's protocol
 C2="--num_categories 10000000 --embed_width 256 --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true"
 C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 --hotness 128 --csr_input=true --weighted_sum=true"
 {
@@ -46,19 +46,33 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_pipe_write" -- $PP >> 
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_pipe_tcc" -- $PP >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$O/pmc_pipe.log" 2>&1
 cd "$R"
+# C3 (fp32 weighted CSR forward): bench.py itself is the profiled program -- every GatherReduceKernel dispatch is a C3 launch
+cd /tmp
+PC="python3 $R/bench.py --workload c3 --steps 10 --warmup 0 --preroll-ms 0 --no-extras --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_c3_fetch" -- $PC > "$O/pmc_c3.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_c3_write" -- $PC >> "$O/pmc_c3.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_c3_tcc" -- $PC >> "$O/pmc_c3.log" 2>&1
+cd "$R"
+: > "$O/traffic_rows.txt"
 python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
   --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
   --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" \
-  --out "$O/traffic_c2.json" > /dev/null
+  --out "$O/traffic_c2.json" --rows-out "$O/traffic_rows.txt" > /dev/null
+python tools/traffic_from_pmc.py --c3-fetch "$O/pmc_c3_fetch" --c3-write "$O/pmc_c3_write" --c3-tcc "$O/pmc_c3_tcc" \
+  --workload "c3 (fp32 weighted sum, CSR bags U[0,128], 10Mx128, batch 65536)" \
+  --out "$O/traffic_c3.json" --rows-out "$O/traffic_rows.txt" > /dev/null
 {
-  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc; do
+  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc pmc_c3_fetch pmc_c3_write pmc_c3_tcc; do
     echo "#### $d"; python tools/rocprof_summary.py "$O/$d" 2>/dev/null
   done
 } > "$O/pmc_passes.txt"
-rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_*
+rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_c3_fetch "$O"/pmc_c3_write "$O"/pmc_c3_tcc
 # SQ issue / wait counters of the same pipeline (two passes of 8 counters)
 bash tools/pmc_sq_pass.sh > /dev/null 2>&1 && cp "$R/gpurun_out/pmc_sq.txt" "$O/pmc_sq_pipeline.txt"
 # the bench line again, now with roofline.traffic from the traffic file measured above
 cp "$O/traffic_c2.json" "$R/profiles/traffic_c2.json"
-python bench.py > "$O/bench_c2_line.json" 2>> "$O/bench.err"
+cp "$O/traffic_c3.json" "$R/profiles/traffic_c3.json"
+python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2>> "$O/bench.err"
+python bench.py --steps 200 --warmup 20 > "$O/bench_c2_line_200_steps.json" 2>> "$O/bench.err"
+python bench.py --gpus 2 --steps 20 --warmup 5 > "$O/bench_c2_two_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
 ls -la "$O"
