@@ -17,6 +17,10 @@ def test_traffic_file_schema_and_calibration():
     k = t["kernels"]
     for name in ("forward_c2", "forward_c2_alpha0", "calibration_unique_rows", "backward_c4", "transpose_c4"):
         assert k[name]["hbm_bytes_per_launch"] > 0, name
+    assert "backward_c4_run_aware" not in k          # the run-aware backward left the product in round 3
+    with open(os.path.join(ROOT, "profiles", "traffic_c3.json")) as f:
+        c3 = json.load(f)
+    assert c3["kernels"]["forward_c3"]["hbm_bytes_per_launch"] > 0 and c3["kernel_sources_sha16"] == t["kernel_sources_sha16"]
     # the FETCH_SIZE x 2 correction is re-checked on a launch whose read volume is known exactly
     assert abs(k["calibration_unique_rows"]["measured_over_expected"] - 1.0) < 0.02
     # power-law: fabric traffic far below the algorithmic bytes; uniform: about equal to them
@@ -56,6 +60,34 @@ def test_roofline_entries_are_fractions():
     assert fwd / 0.136e-3 / 1e9 / bench.HBM_PEAK_GBPS < 1.0
     # while the application figure exceeds the peak -- which is why it is not divided by it anywhere
     assert alg / 0.136e-3 / 1e9 > bench.HBM_PEAK_GBPS
+
+
+def test_traffic_files_follow_from_the_committed_counter_rows():
+    """profiles/r03_traffic_rows.txt holds the per-pass averages (KiB per dispatch) of the last refresh, written in
+    the same run as the JSON files bench.py reads and committed next to the rocprofv3 pass summaries: every
+    hbm_bytes_per_launch must be (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 of its row, within 0.5 %."""
+    rows = {}
+    with open(os.path.join(ROOT, "profiles", "r03_traffic_rows.txt")) as f:
+        for ln in f:
+            parts = ln.split()
+            if parts and parts[0] == "traffic_row":
+                kv = dict(p.split("=", 1) for p in parts[3:])
+                rows[(parts[1], parts[2])] = (float(kv["FETCH_SIZE_KiB"]), float(kv["WRITE_SIZE_KiB"]), int(kv["dispatches"]))
+    seen = 0
+    for name in ("traffic_c2.json", "traffic_c3.json"):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            t = json.load(f)
+        for key, e in t["kernels"].items():
+            fetch, write, n = rows[(name, key)]
+            want = (fetch * t["fetch_correction"] + write * t["write_correction"]) * 1024
+            assert abs(e["hbm_bytes_per_launch"] - want) <= 0.005 * want, (name, key)
+            assert e["launches_averaged"] == n
+            seen += 1
+    assert seen >= 6      # forward c2 / alpha 0 / calibration, backward c4, transpose c4, forward c3
+    # the same numbers are in the committed pass summaries (kernel-level averages over ALL dispatches of a pass)
+    summary = open(os.path.join(ROOT, "profiles", "r03_pmc_passes_forward_pipeline_c3.txt")).read()
+    for tag in ("#### pmc_fwd_fetch", "#### pmc_pipe_write", "#### pmc_c3_fetch", "SegmentedScatterAddKernel", "FETCH_SIZE"):
+        assert tag in summary
 
 
 def test_traffic_file_is_stamped_with_the_kernel_sources():

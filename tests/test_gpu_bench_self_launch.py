@@ -19,8 +19,8 @@ def _run(extra):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
                        timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # stdout is the ONE JSON line, nothing else
     return json.loads(lines[0])
 
 
