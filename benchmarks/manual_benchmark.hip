@@ -50,6 +50,7 @@ namespace {
 
 struct Flags {
   int num_categories = 1048576, embed_width = 128, batch_size = 1024, hotness = 1, iterations = 1;
+  int sample_blocks = 1;   // extension: Transpose in this many blocks of samples (0 = RecommendedSampleBlocks; compressed gradient only)
   float alpha = 0.f;
   bool use_int64_indices = false, check_result = false, half_embedding_type = false, csr_input = false,
        weighted_sum = false, fp16_math = false, compressed_grad = true, skip_grad_init = true,
@@ -88,6 +89,7 @@ Flags ParseFlags(int argc, char** argv) {
   getb("enable_stderr", &f.enable_stderr); getb("clear_caches", &f.clear_caches);
   getb("bounded_sort", &f.bounded_sort);
   getb("fused_row_ids", &f.fused_row_ids);
+  geti("sample_blocks", &f.sample_blocks);
   for (auto& e : kv) {
     std::fprintf(stderr, "unknown flag --%s\n", e.first.c_str());
     std::exit(1);
@@ -178,13 +180,17 @@ void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
     bits = 1;
     while ((int64_t{1} << bits) < w.f.num_categories) ++bits;
   }
+  int blocks = 1;
+  if (w.f.compressed_grad)   // never with a dense gradient: a table row would be produced once per block
+    blocks = w.f.sample_blocks > 0 ? w.f.sample_blocks
+                                   : cuembed::RecommendedSampleBlocks<ElemT>(w.f.embed_width, w.f.batch_size, w.nnz);
   if (fused)
     cuembed::TransposeFixedHotness<IndexT, ElemT>(w.indices.ptr, weights, w.f.batch_size, w.f.hotness,
                                                   w.transpose_indices.ptr, w.transpose_sample_ids.ptr, t_weights,
-                                                  w.workspace.ptr, &lwork, 0, bits);
+                                                  w.workspace.ptr, &lwork, 0, bits, blocks);
   else
     cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, weights, nnz, w.transpose_indices.ptr,
-                                      w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits);
+                                      w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits, 0, blocks);
   if (w.f.compressed_grad)
     cuembed::ComputeCompressedGradIndices<IndexT>(w.transpose_indices.ptr, nnz,
                                                   w.transpose_remapped_indices.ptr, w.workspace.ptr, &lwork);

@@ -33,6 +33,10 @@ def main():
     p.add_argument("--alpha", type=float, default=1.15)
     p.add_argument("--exchange", default="sparse", choices=["sparse", "dense", "none"])
     p.add_argument("--sparse_algorithm", default="auto", choices=["auto", "allgather", "owner"])
+    p.add_argument("--sample_blocks", default="auto",
+                   help="transpose the batch in this many blocks of samples (extension: an uncoalesced compressed gradient, "
+                        "every L2 gathers from 1 / blocks of grad_y at a time); auto = cuembed_recommended_sample_blocks, "
+                        "1 = the reference's fully sorted order.  Ignored with --reference_api and with --exchange dense")
     p.add_argument("--reference_api", action="store_true",
                    help="index work through the reference's entry points only (row-id kernel + unbounded Transpose)")
     a = p.parse_args()
@@ -65,6 +69,9 @@ def main():
     cap = min(nnz, a.rows)
     comp_rows = torch.empty((cap, W), dtype=torch.float16, device=dev) if a.exchange != "dense" else None
     comp_inv = torch.empty((cap,), dtype=torch.int32, device=dev) if a.exchange != "dense" else None
+    blocks = 1
+    if not a.reference_api and a.exchange != "dense":
+        blocks = ce.recommended_sample_blocks(torch.float16, W, B, nnz) if a.sample_blocks == "auto" else int(a.sample_blocks)
     names = ["forward", "transpose", "backward", "exchange"]
 
     def step(ev):
@@ -75,7 +82,8 @@ def main():
             sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, dev)
             t_idx, t_sid, _ = ce.transpose(sid, idx, workspace=work)
         else:
-            t_idx, t_sid, _ = ce.transpose_fixed_hotness(idx, B, H, workspace=work, num_categories=a.rows)
+            t_idx, t_sid, _ = ce.transpose_fixed_hotness(idx, B, H, workspace=work, num_categories=a.rows,
+                                                         sample_blocks=blocks)
         remap = ce.compute_compressed_grad_indices(t_idx)
         ev[2].record()
         if a.exchange == "dense":
@@ -114,6 +122,7 @@ def main():
         print(json.dumps({"workload": "fp16 fwd+bwd, %dx%d table, batch %d per GPU x %d GPUs, hotness %d, alpha %g"
                                       % (a.rows, W, B, world, H, a.alpha),
                           "exchange": a.exchange, "index_path": "reference_api" if a.reference_api else "fixed_hotness_bounded",
+                          "sample_blocks": blocks,
                           "n_gpus": world, "ms_per_step": round(ms, 4),
                           "samples_per_s": round(world * B / (ms * 1e-3)),
                           "breakdown_ms": {k: round(v, 4) for k, v in parts.items()}}), flush=True)

@@ -11,7 +11,7 @@ from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBack
                   EmbeddingForward, ExtractRowIdsForConcat, ExtractRowIdsFromCSR,
                   ExtractRowIdsFromFixed, Transpose, compressed_grad_workspace_bytes,
                   compute_compressed_grad_indices, embedding_backward, embedding_forward,
-                  get_backward_tuning, set_backward_tuning,
+                  get_backward_tuning, set_backward_tuning, recommended_sample_blocks, transpose_sample_block_length,
                   embedding_weight_grad,
                   extract_row_ids_for_concat, extract_row_ids_from_csr,
                   extract_row_ids_from_fixed, forward_launch_shape, get_forward_reduction_order,

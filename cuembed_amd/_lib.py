@@ -40,6 +40,16 @@ def _declare(L):
     L.cuembed_transpose_fixed_hotness.restype = None
     L.cuembed_transpose_fixed_hotness.argtypes = [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP,
                                                   ctypes.POINTER(ctypes.c_size_t), _I, _VP]
+    L.cuembed_transpose_sample_blocks.restype = None
+    L.cuembed_transpose_sample_blocks.argtypes = [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP,
+                                                  ctypes.POINTER(ctypes.c_size_t), _I, _I, _I, _VP]
+    L.cuembed_transpose_fixed_hotness_sample_blocks.restype = None
+    L.cuembed_transpose_fixed_hotness_sample_blocks.argtypes = [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP,
+                                                                ctypes.POINTER(ctypes.c_size_t), _I, _I, _VP]
+    L.cuembed_transpose_sample_block_length.restype = ctypes.c_int64
+    L.cuembed_transpose_sample_block_length.argtypes = [ctypes.c_int64, _I]
+    L.cuembed_recommended_sample_blocks.restype = _I
+    L.cuembed_recommended_sample_blocks.argtypes = [_I, _I, _I, ctypes.c_int64]
     L.cuembed_translate_indices_for_row_cache.restype = None
     L.cuembed_translate_indices_for_row_cache.argtypes = [_VP, _I, ctypes.c_int64, _VP, ctypes.c_int64, ctypes.c_int64,
                                                           _VP, _VP]

@@ -65,6 +65,16 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
 #undef BWD
 }
 
+int cuembed_recommended_sample_blocks(int elem_type, int embed_width, int batch_size, int64_t nnz) {
+  switch (elem_type) {
+    case 0: return cuembed::RecommendedSampleBlocks<float>(embed_width, batch_size, nnz);
+    case 1: return cuembed::RecommendedSampleBlocks<__half>(embed_width, batch_size, nnz);
+    case 2: return cuembed::RecommendedSampleBlocks<__hip_bfloat16>(embed_width, batch_size, nnz);
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+  return 1;
+}
+
 void cuembed_set_backward_tuning(int segment_len, int column_slices) {
   cuembed::SetBackwardTuning(cuembed::BackwardTuning{segment_len, column_slices});
 }

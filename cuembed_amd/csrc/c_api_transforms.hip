@@ -184,4 +184,49 @@ void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int 
 #undef EX
 }
 
+// Extension: Transpose in `sample_blocks` blocks of the (sample-major) input, each sorted on its own -- for the
+// compressed gradient path only (cuembed::Transpose, sample_blocks).
+void cuembed_transpose_sample_blocks(const void* rows, const void* cols, const void* weights, int nnz,
+                                     int index_type, int weight_type, void* transpose_rows,
+                                     void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
+                                     int index_bits, int row_bits, int sample_blocks, cuembed_stream_t stream) {
+#define TRB(I, W)                                                                                      \
+  cuembed::Transpose<I, W>(static_cast<const I*>(rows), static_cast<const I*>(cols),                   \
+                           static_cast<const W*>(weights), nnz, static_cast<I*>(transpose_rows),       \
+                           static_cast<I*>(transpose_cols), static_cast<W*>(transpose_weights), work,  \
+                           lwork, Stream(stream), index_bits, row_bits, sample_blocks)
+  switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {   // 16-bit weights move as bit patterns
+    case 0: TRB(int32_t, float); break;
+    case 1: TRB(int32_t, __half); break;
+    case 2: TRB(int64_t, float); break;
+    case 3: TRB(int64_t, __half); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef TRB
+}
+
+int64_t cuembed_transpose_sample_block_length(int64_t nnz, int sample_blocks) {
+  return cuembed::TransposeSampleBlockLength(nnz, sample_blocks);
+}
+
+void cuembed_transpose_fixed_hotness_sample_blocks(const void* indices, const void* weights, int batch_size,
+                                                   int num_hots, int index_type, int weight_type,
+                                                   void* transpose_indices, void* transpose_sample_ids,
+                                                   void* transpose_weights, char* work, size_t* lwork,
+                                                   int index_bits, int sample_blocks, cuembed_stream_t stream) {
+#define TFB(I, W)                                                                                               \
+  cuembed::TransposeFixedHotness<I, W>(static_cast<const I*>(indices), static_cast<const W*>(weights), batch_size, \
+                                       num_hots, static_cast<I*>(transpose_indices),                             \
+                                       static_cast<I*>(transpose_sample_ids), static_cast<W*>(transpose_weights), \
+                                       work, lwork, Stream(stream), index_bits, sample_blocks)
+  switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {   // 16-bit weights move as bit patterns
+    case 0: TFB(int32_t, float); break;
+    case 1: TFB(int32_t, __half); break;
+    case 2: TFB(int64_t, float); break;
+    case 3: TFB(int64_t, __half); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef TFB
+}
+
 }  // extern "C"

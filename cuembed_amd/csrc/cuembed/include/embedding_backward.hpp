@@ -130,6 +130,28 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
 }  // namespace detail
 
 /**
+ * @brief How many sample blocks Transpose(..., sample_blocks) should cut a batch into so that, while one
+ * block is being scattered, the part of grad_y an L2 gathers from fits that L2 (extension; see Transpose()).
+ * grad_y is `batch_size` rows of `embed_width` GradT; EmbeddingBackward gives every XCD a column slice of
+ * the row (ChooseColumnSlices: >= 128 bytes, only from 2^20 lookups up), so an L2 fronts
+ * batch_size x slice bytes -- 8.4 MB at C4 for 4 MiB of L2.  Returns 1 when nothing is to be gained.
+ */
+template <typename GradT>
+inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, const int64_t nnz) {
+  using ElemT = detail::DeviceElemT<GradT>;
+  const detail::RowSplit split = detail::SplitRow<ElemT>(embed_width, nullptr, nullptr);
+  const size_t row_bytes = static_cast<size_t>(embed_width) * sizeof(GradT);
+  const int slices = detail::ChooseColumnSlices(row_bytes, split.lanes_per_row, nnz);
+  if (slices <= 1) return 1;   // small problems: grad_y is not sliced (and fits the L2s anyway)
+  const size_t per_l2 = static_cast<size_t>(batch_size) * (row_bytes / slices);
+  const size_t budget = size_t{4} << 20;   // one XCD's L2
+  size_t blocks = (per_l2 + budget - 1) / budget;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 64) blocks = 64;   // what one Transpose call sorts separately (detail::kMaxSortSegments)
+  return static_cast<int>(blocks);
+}
+
+/**
  * @brief Embedding backward: scatter-add `grad_y` rows into the gradient of the
  * table, from index-sorted COO lookups (the output of Transpose()).  Full
  * gradient (`transpose_remapped_indices == nullptr`, `grad_embedding` has one row

@@ -141,6 +141,14 @@ void TranslateIndicesForRowCache(const IndexT* indices,
  *  - `row_bits` (default 0 = unknown).  int64 `rows` known to lie in [0, 2^row_bits), row_bits <=
  *    32 (sample ids always do: they are < nnz <= INT_MAX), travel as 32 bits between the passes
  *    without the library having to look at them first.
+ *  - `sample_blocks` (default 1 = the reference's result).  > 1 CHANGES the result: the input (sample-major
+ *    lookups) is cut into that many consecutive blocks of equal length and each block is transposed on its
+ *    own; the output is the concatenation of the sorted blocks.  For the COMPRESSED gradient path only:
+ *    ComputeCompressedGradIndices and EmbeddingBackward then produce one gradient row per (block, table row)
+ *    -- an uncoalesced compressed gradient: a table row looked up from several blocks appears once per
+ *    block in inverse_mapping -- and while a block is being scattered every L2 gathers from 1 / sample_blocks
+ *    of grad_y only (C4: EmbeddingBackward 0.258 -> 0.191 ms with 2 blocks, 572 k -> 679 k gradient rows).
+ *    RecommendedSampleBlocks() picks the count.  Never use it with a dense gradient.
  */
 template <typename IndexT, typename WeightT>
 void Transpose(const IndexT* rows,
@@ -154,7 +162,8 @@ void Transpose(const IndexT* rows,
                size_t* lwork,
                const hipStream_t stream = 0,
                const int index_bits = static_cast<int>(sizeof(IndexT) * 8),
-               const int row_bits = 0) {
+               const int row_bits = 0,
+               const int sample_blocks = 1) {
   using KeyT = typename std::make_unsigned<IndexT>::type;  // bit pattern; signed order via the top digit
   const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
                            ? index_bits
@@ -173,7 +182,7 @@ void Transpose(const IndexT* rows,
     assert(*lwork >= plan.total);
     detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
         keys_in, keys_out, rows, transpose_cols, nullptr, nullptr, n, key_bits, work, stream,
-        /*signed_keys=*/true, row_bits);
+        /*signed_keys=*/true, row_bits, /*v1_div=*/0, sample_blocks);
     return;
   }
   // weighted: sample id AND weight move with the key as two payload arrays (the reference
@@ -187,7 +196,13 @@ void Transpose(const IndexT* rows,
   assert(*lwork >= plan.total);
   detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, rows, transpose_cols, weights,
                                                 transpose_weights, n, key_bits, work, stream,
-                                                /*signed_keys=*/true, row_bits);
+                                                /*signed_keys=*/true, row_bits, /*v1_div=*/0, sample_blocks);
+}
+
+//! Where Transpose(..., sample_blocks) cuts: lookups [k * L, (k + 1) * L) form block k, L = this value
+//! (a multiple of 4096; inputs of up to 131,072 lookups are one block whatever was asked for).
+inline int64_t TransposeSampleBlockLength(const int64_t nnz, const int sample_blocks) {
+  return static_cast<int64_t>(detail::SortSegmentLength(static_cast<size_t>(nnz > 0 ? nnz : 0), sample_blocks));
 }
 
 /**
@@ -197,7 +212,7 @@ void Transpose(const IndexT* rows,
  * derives the sample id of lookup i as i / num_hots instead of reading an array that a kernel
  * would have had to write first (16.8 MB written and read back at the north-star shape, and one
  * launch).  num_hots = 1 gives the concat layout (ExtractRowIdsForConcat: row id = position).
- * Two-phase workspace query and `index_bits` as for Transpose().
+ * Two-phase workspace query, `index_bits` and `sample_blocks` as for Transpose().
  */
 template <typename IndexT, typename WeightT>
 void TransposeFixedHotness(const IndexT* indices,
@@ -210,7 +225,8 @@ void TransposeFixedHotness(const IndexT* indices,
                            char* work,
                            size_t* lwork,
                            const hipStream_t stream = 0,
-                           const int index_bits = static_cast<int>(sizeof(IndexT) * 8)) {
+                           const int index_bits = static_cast<int>(sizeof(IndexT) * 8),
+                           const int sample_blocks = 1) {
   using KeyT = typename std::make_unsigned<IndexT>::type;
   const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
                            ? index_bits
@@ -228,7 +244,7 @@ void TransposeFixedHotness(const IndexT* indices,
     assert(*lwork >= plan.total && num_hots > 0 && nnz <= INT32_MAX);
     detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
         keys_in, keys_out, nullptr, transpose_sample_ids, nullptr, nullptr, n, key_bits, work, stream,
-        /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots);
+        /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks);
     return;
   }
   const detail::RadixSortPlan<KeyT, IndexT, WeightT> plan(n, key_bits);
@@ -239,7 +255,7 @@ void TransposeFixedHotness(const IndexT* indices,
   assert(*lwork >= plan.total && num_hots > 0 && nnz <= INT32_MAX);
   detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, nullptr, transpose_sample_ids, weights,
                                                 transpose_weights, n, key_bits, work, stream,
-                                                /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots);
+                                                /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks);
 }
 
 /**

@@ -98,6 +98,7 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
 // [0, 2^index_bits); no digit is flipped then.
 constexpr int kStaticRoutePasses = 3;
 constexpr int kFoldScanTiles = 32;  // up to 131072 keys the tile scan is done inside the scatter kernel
+constexpr int kMaxSortSegments = 64; // input blocks that can be sorted on their own in one call (see RadixSortPairs)
 constexpr int kSelfSumTiles = 4096; // up to 16.7M keys every run-head scan workgroup sums the earlier tiles itself
 enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
@@ -344,8 +345,8 @@ __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* tot
   return before + incl - v;
 }
 
-//! One workgroup per bin: tile_hist[bin][*] becomes its exclusive prefix over the tiles;
-//! bin_total[bin] receives the sum.  In pass 0 an extra workgroup (the last of the grid) folds
+//! One workgroup per (segment, bin): tile_hist[bin][tiles of the segment] becomes its exclusive prefix over
+//! those tiles; bin_total[segment][bin] receives the sum.  In pass 0 an extra workgroup (the last of the grid) folds
 //! the tiles' OR/AND words into `state` (single writer, so nothing has to be zeroed first).
 //! Few tiles (<= kFoldScanTiles): the per-bin work is folded into the scatter kernel and only
 //! that extra workgroup is launched (grid = 1), in pass 0.
@@ -353,8 +354,8 @@ __global__ void __launch_bounds__(kSortThreads)
 RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
                      unsigned* __restrict__ bin_total, const int pass, const int passes, const SortMode mode,
                      const unsigned long long* __restrict__ tile_bits,
-                     unsigned long long* __restrict__ state) {
-  if (blockIdx.x == gridDim.x - 1 && gridDim.x != kSortBins) {  // the extra workgroup of pass 0
+                     unsigned long long* __restrict__ state, const int segment_tiles) {
+  if (blockIdx.x == gridDim.x - 1 && gridDim.x % kSortBins != 0) {  // the extra workgroup of pass 0
     __shared__ unsigned long long wave_bits[kSortWaves][kStateWords];
     unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
     for (int t = threadIdx.x; t < num_tiles; t += kSortThreads) {
@@ -391,17 +392,23 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
     return;
   }
   if (pass > 0 && !PlanPass(state, pass, passes, mode).active) return;
-  unsigned* row = tile_hist + static_cast<size_t>(blockIdx.x) * num_tiles;
+  // workgroup (segment, bin): the tiles of one segment (a block of the input that is sorted on its own;
+  // one segment = the whole input unless the caller asked for sample blocks)
+  const int bin = blockIdx.x % kSortBins;
+  const int segment = blockIdx.x / kSortBins;
+  const int first = segment * segment_tiles;
+  const int last = first + segment_tiles < num_tiles ? first + segment_tiles : num_tiles;
+  unsigned* row = tile_hist + static_cast<size_t>(bin) * num_tiles;
   unsigned carry = 0;
-  for (int base = 0; base < num_tiles; base += kSortThreads) {
+  for (int base = first; base < last; base += kSortThreads) {
     const int t = base + threadIdx.x;
-    const unsigned v = t < num_tiles ? row[t] : 0u;
+    const unsigned v = t < last ? row[t] : 0u;
     unsigned total;
     const unsigned excl = BlockExclusiveScan(v, &total);
-    if (t < num_tiles) row[t] = carry + excl;
+    if (t < last) row[t] = carry + excl;
     carry += total;
   }
-  if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
+  if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;   // [segment][bin]
 }
 
 //! Stable rank of the tile's keys by the digit at `shift`.  Lane l of wave w holds the keys at
@@ -502,7 +509,7 @@ __global__ void __launch_bounds__(kSortThreads, 4)
 RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
                    const int64_t n, const int pass, const int passes, const SortMode mode,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
-                   const int num_tiles, const unsigned long long* __restrict__ state) {
+                   const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles) {
   // which of (caller's input, caller's output, scratch) this pass reads and writes follows from
   // the passes that run at all and from how each array is stored in the scratch
   const PassPlan plan = PlanPass(state, pass, passes, mode);
@@ -541,9 +548,12 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   }
   {
     unsigned before_me, bin_sum;
+    unsigned segment_start = 0;   // the tile's segment is sorted on its own: positions start at its first element
     if (bin_total != nullptr) {
+      const int segment = static_cast<int>(blockIdx.x) / segment_tiles;
+      segment_start = static_cast<unsigned>(segment) * static_cast<unsigned>(segment_tiles) * kSortTile;
       before_me = tile_prefix[static_cast<size_t>(tid) * num_tiles + blockIdx.x];
-      bin_sum = bin_total[tid];
+      bin_sum = bin_total[segment * kSortBins + tid];
     } else {
       // few tiles: no scan launch -- thread `bin` adds up the raw tile histograms of its bin itself
       const unsigned* row = tile_prefix + static_cast<size_t>(tid) * num_tiles;
@@ -557,7 +567,7 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     }
     unsigned total;
     const unsigned smaller = BlockExclusiveScan(bin_sum, &total);
-    digit_base[tid] = smaller + before_me;
+    digit_base[tid] = segment_start + smaller + before_me;
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) wave_count[w][tid] = 0;
   }
@@ -720,7 +730,7 @@ struct RadixSortPlan {
     tile_hist = off;
     off += SortAlign(static_cast<size_t>(kSortBins) * num_tiles * sizeof(unsigned));
     bin_total = off;
-    off += SortAlign(kSortBins * sizeof(unsigned));
+    off += SortAlign(static_cast<size_t>(kMaxSortSegments) * kSortBins * sizeof(unsigned));
     tile_bits = off;
     off += SortAlign(static_cast<size_t>(kStateWords) * num_tiles * sizeof(unsigned long long));
     varying = off;
@@ -728,6 +738,16 @@ struct RadixSortPlan {
     total = off;
   }
 };
+
+//! Elements per block when n elements are sorted in `blocks` blocks (RadixSortPairs): a whole number of tiles,
+//! ceil(tiles / blocks) of them; the last block takes what is left.  Inputs of up to kFoldScanTiles tiles are
+//! always ONE block (the result is then the full sort).
+inline size_t SortSegmentLength(const size_t n, const int blocks) {
+  const size_t tiles = n == 0 ? 1 : (n + kSortTile - 1) / kSortTile;
+  size_t want = blocks < 1 ? 1 : (blocks > kMaxSortSegments ? kMaxSortSegments : blocks);
+  if (tiles <= static_cast<size_t>(kFoldScanTiles)) want = 1;
+  return (tiles + want - 1) / want * kSortTile;
+}
 
 //! Stable sort of n (key, v1[, v2]) by the low `key_bits` bits of the key.  Inputs are not
 //! modified; outputs and `work` (at least RadixSortPlan::total bytes) must not overlap the inputs.
@@ -738,11 +758,16 @@ struct RadixSortPlan {
 //!                kept as 32 bits between passes without looking; 0 = unknown, decided on the
 //!                device from the values themselves (pass 0 reads them once more for that).
 //!   v1_div     : > 0: v1_in is not read; the first payload of element i is i / v1_div.
+//!   blocks     : > 1: the input is cut into (at most) this many consecutive blocks of equal length -- a whole
+//!                number of 4096-element tiles each, the last one takes what is left -- and every block is sorted
+//!                ON ITS OWN: the output is the concatenation of the sorted blocks (same kernels, same launches;
+//!                only the tile scan and the digit bases are per block).  At most kMaxSortSegments; ignored for
+//!                inputs of up to kFoldScanTiles tiles.
 template <typename KeyT, typename V1, typename V2>
 inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in, V1* v1_out,
                            const V2* v2_in, V2* v2_out, const size_t n, const int key_bits,
                            char* work, hipStream_t stream, const bool signed_keys = false,
-                           const int v1_bits = 0, const int v1_div = 0) {
+                           const int v1_bits = 0, const int v1_div = 0, const int blocks = 1) {
   if (n == 0) return;
   const RadixSortPlan<KeyT, V1, V2> plan(n, key_bits);
   const int sign_pass = (signed_keys && key_bits >= static_cast<int>(8 * sizeof(KeyT))) ? plan.passes - 1 : -1;
@@ -777,16 +802,19 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
       mode.narrow_v1 == kNarrowIfConstantHigh ? reinterpret_cast<const unsigned long long*>(v1_in) : nullptr;
   const int64_t count = static_cast<int64_t>(n);
   const bool fold_scan = plan.num_tiles <= kFoldScanTiles;  // launch-bound sizes: one launch less per pass
+  // segments (blocks sorted on their own): whole tiles each; one segment unless the caller asked for more
+  const int segment_tiles = static_cast<int>(SortSegmentLength(n, blocks) / kSortTile);
+  const int segments = (plan.num_tiles + segment_tiles - 1) / segment_tiles;
   for (int p = 0; p < plan.passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64);
-    const int scan_blocks = (fold_scan ? 0 : kSortBins) + (p == 0 && device_state ? 1 : 0);
+    const int scan_blocks = (fold_scan ? 0 : kSortBins * segments) + (p == 0 && device_state ? 1 : 0);
     if (scan_blocks > 0)
       RadixScanTilesKernel<<<scan_blocks, kSortThreads, 0, stream>>>(
-          tile_hist, plan.num_tiles, bin_total, p, plan.passes, mode, tile_bits, state);
+          tile_hist, plan.num_tiles, bin_total, p, plan.passes, mode, tile_bits, state, segment_tiles);
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, v1, v2, count, p, plan.passes, mode, tile_hist, fold_scan ? nullptr : bin_total,
-        plan.num_tiles, state);
+        plan.num_tiles, state, segment_tiles);
   }
 }
 

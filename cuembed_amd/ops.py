@@ -269,14 +269,17 @@ def transpose_workspace_bytes(nnz, index_dtype, weight_dtype=None):
     return lwork.value
 
 
-def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num_rows=None):
+def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num_rows=None, sample_blocks=1):
     """Stable sort of (rows[i][, weights[i]]) by key cols[i] (callers pass rows = sample ids,
     cols = lookup indices).  Returns (sorted cols, rows carried along, weights carried along).
     Generic like the reference's: `cols` are ordered as signed numbers, `rows` may hold anything.
     num_categories (optional, this library's extension): every value in `cols` lies in
     [0, num_categories); the sort then skips the key digits that are always zero (same result,
     fewer passes).  num_rows (optional, extension): every value in `rows` lies in [0, num_rows)
-    -- int64 rows below 2^32 then travel as 32 bits without the library reading them to find out."""
+    -- int64 rows below 2^32 then travel as 32 bits without the library reading them to find out.
+    sample_blocks (optional, extension, CHANGES the result): > 1 cuts the (sample-major) input into that many
+    consecutive blocks and transposes each on its own -- compressed-gradient path only, see
+    recommended_sample_blocks()."""
     _check_dev("rows", rows)
     dev = rows.device
     _check_dev("cols", cols, dev)
@@ -304,16 +307,30 @@ def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num
     row_bits = 0 if not num_rows else max(1, int(num_rows - 1).bit_length())
     if nnz > 0:
         with torch.cuda.device(rows.device):   # the launch must happen on the tensors' device
-            _lib.lib().cuembed_transpose_hinted(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
-                                                _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(workspace),
-                                                ctypes.byref(lwork), bits, row_bits, _stream(rows))
+            _lib.lib().cuembed_transpose_sample_blocks(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
+                                                       _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(workspace),
+                                                       ctypes.byref(lwork), bits, row_bits, int(sample_blocks),
+                                                       _stream(rows))
     return t_rows, t_cols, t_w
 
 
-def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspace=None, num_categories=None):
+def transpose_sample_block_length(nnz, sample_blocks):
+    """Lookups per block of transpose(..., sample_blocks=...): block k = lookups [k * L, (k + 1) * L)."""
+    return int(_lib.lib().cuembed_transpose_sample_block_length(int(nnz), int(sample_blocks)))
+
+
+def recommended_sample_blocks(grad_dtype, embed_width, batch_size, nnz):
+    """How many sample blocks a transpose feeding a COMPRESSED EmbeddingBackward should use so that the part of
+    grad_y one L2 gathers from fits it (cuembed::RecommendedSampleBlocks; 1 = nothing to gain)."""
+    return int(_lib.lib().cuembed_recommended_sample_blocks(_ELEM[grad_dtype], int(embed_width), int(batch_size),
+                                                            int(nnz)))
+
+
+def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspace=None, num_categories=None,
+                            sample_blocks=1):
     """extract_row_ids_from_fixed + transpose in one call without materialising the sample ids
     (cuembed::TransposeFixedHotness, extension): returns (sorted indices, sample ids, weights).
-    num_hots=1 is the concat layout."""
+    num_hots=1 is the concat layout.  sample_blocks as in transpose()."""
     _check_dev("indices", indices)
     dev = indices.device
     it = _index_code("indices", indices)
@@ -339,9 +356,9 @@ def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspa
     bits = 0 if not num_categories else max(1, int(num_categories - 1).bit_length())
     if nnz > 0:
         with torch.cuda.device(dev):
-            _lib.lib().cuembed_transpose_fixed_hotness(_ptr(indices), _ptr(weights), batch_size, num_hots, it, wt,
-                                                       _ptr(t_idx), _ptr(t_sid), _ptr(t_w), _ptr(workspace),
-                                                       ctypes.byref(lwork), bits, _stream(indices))
+            _lib.lib().cuembed_transpose_fixed_hotness_sample_blocks(
+                _ptr(indices), _ptr(weights), batch_size, num_hots, it, wt, _ptr(t_idx), _ptr(t_sid), _ptr(t_w),
+                _ptr(workspace), ctypes.byref(lwork), bits, int(sample_blocks), _stream(indices))
     return t_idx, t_sid, t_w
 
 

@@ -220,6 +220,28 @@ void cuembed_transpose_fixed_hotness(const void* indices, const void* weights, i
                                      void* transpose_indices, void* transpose_sample_ids,
                                      void* transpose_weights, char* work, size_t* lwork, int index_bits,
                                      cuembed_stream_t stream);
+/* Extension (cuembed::Transpose / TransposeFixedHotness, `sample_blocks`): sample_blocks > 1 CHANGES the
+ * result -- the sample-major input is cut into that many consecutive blocks of equal length (whole 4096-element
+ * tiles; at most 64) and each block is transposed on its own; the output is the concatenation of the sorted
+ * blocks.  For the COMPRESSED gradient only: cuembed_compute_compressed_grad_indices and
+ * cuembed_embedding_backward then produce one gradient row per (block, table row) -- a table row looked up from
+ * several blocks appears once per block in inverse_mapping (an uncoalesced compressed gradient) -- and while a
+ * block is scattered every L2 gathers from 1 / sample_blocks of grad_y (C4: backward 0.258 -> 0.191 ms with 2
+ * blocks; 572 k -> 679 k gradient rows).  cuembed_recommended_sample_blocks picks the count (1 = no gain).
+ * Never combine with a dense gradient.  Otherwise as cuembed_transpose_hinted / cuembed_transpose_fixed_hotness. */
+void cuembed_transpose_sample_blocks(const void* rows, const void* cols, const void* weights, int nnz,
+                                     int index_type, int weight_type, void* transpose_rows,
+                                     void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
+                                     int index_bits, int row_bits, int sample_blocks, cuembed_stream_t stream);
+void cuembed_transpose_fixed_hotness_sample_blocks(const void* indices, const void* weights, int batch_size,
+                                                   int num_hots, int index_type, int weight_type,
+                                                   void* transpose_indices, void* transpose_sample_ids,
+                                                   void* transpose_weights, char* work, size_t* lwork,
+                                                   int index_bits, int sample_blocks, cuembed_stream_t stream);
+int cuembed_recommended_sample_blocks(int elem_type, int embed_width, int batch_size, int64_t nnz);
+/* Lookups per block that the two calls above use: block k = lookups [k * L, (k + 1) * L), L a multiple of 4096
+ * (inputs of up to 131,072 lookups are always ONE block). */
+int64_t cuembed_transpose_sample_block_length(int64_t nnz, int sample_blocks);
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream);

@@ -49,3 +49,6 @@ def test_gpus_1_line_has_the_contract_fields():
     for o in rl["other_kernels"]:
         assert "algorithmic_frac" in o and o["algorithmic_frac"] <= o["frac"] + 1e-9
     assert line["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True
+    ex = line["extras"]
+    assert ex["sample_blocks"] == 2 and ex["sample_blocks_gradient_equals_reference_order"] is True
+    assert ex["backward_compressed_sample_blocks_ms"] < ex["backward_compressed_ms"]

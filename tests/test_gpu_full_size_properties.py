@@ -169,3 +169,38 @@ def test_config4_backward_reference_grad_y_recipe_against_oracle(ce, oracle):
         # for the record: where no partial sum leaves the integers fp16 holds exactly, the result IS the integer sum
         small = (~short) & (scale.max(axis=1) < 2048)
         assert np.array_equal(got[small].astype(np.float64), exact[small])
+
+
+def test_config4_sample_blocks_same_gradient_at_full_size(ce):
+    """C4 through the sample-block extension (Transpose(..., sample_blocks = recommended = 2)): every block is sorted
+    and stable on its own, the compressed gradient has one row per (block, table row), and scattered into the
+    table it is the reference-order gradient bit for bit (fp32 on integers; fp16 on sparse +-1 data)."""
+    from cuembed_amd import harness
+    rows, W, B, H = 10_000_000, 256, 65536, 64
+    idx = torch.from_numpy(harness.generate_indices(rows, B, H, alpha=1.15)).cuda()
+    nnz = B * H
+    P = ce.recommended_sample_blocks(torch.float16, W, B, nnz)
+    assert P == 2
+    L = ce.transpose_sample_block_length(nnz, P)
+    assert L == nnz // 2
+    t_idx, t_sid, _ = ce.transpose_fixed_hotness(idx, B, H, num_categories=rows)
+    b_idx, b_sid, _ = ce.transpose_fixed_hotness(idx, B, H, num_categories=rows, sample_blocks=P)
+    sid = torch.arange(nnz, device="cuda", dtype=torch.int32).div(H, rounding_mode="floor")
+    for k in range(P):
+        ref_idx, order = torch.sort(idx[k * L:(k + 1) * L], stable=True)
+        assert torch.equal(b_idx[k * L:(k + 1) * L], ref_idx) and torch.equal(b_sid[k * L:(k + 1) * L], sid[k * L:(k + 1) * L][order])
+    remap, b_remap = ce.compute_compressed_grad_indices(t_idx), ce.compute_compressed_grad_indices(b_idx)
+    nu, nub = int(remap[-1].item()) + 1, int(b_remap[-1].item()) + 1
+    assert nu == 572029 and nu < nub <= 2 * nu
+    g = torch.Generator(device="cuda").manual_seed(33)
+    gy32 = torch.randint(-3, 4, (B, W), device="cuda", generator=g).float()
+    gy16 = (torch.rand((B, W), device="cuda", generator=g) < 0.02).half() * \
+        (torch.randint(0, 2, (B, W), device="cuda", generator=g).half() * 2 - 1)
+    for gy in (gy32, gy16):
+        grad, inv = ce.embedding_backward(gy, nu, t_idx, t_sid, remap)
+        gradb, invb = ce.embedding_backward(gy, nub, b_idx, b_sid, b_remap)
+        # scatter the uncoalesced rows onto the unique ids of the reference order and compare everything
+        pos = torch.searchsorted(inv, invb)
+        assert torch.equal(inv[pos], invb)
+        merged = torch.zeros((nu, W), dtype=torch.float32, device="cuda").index_add_(0, pos, gradb.float())
+        assert float(merged.abs().max()) < 2048 and torch.equal(merged, grad.float())

@@ -79,7 +79,7 @@ def entry(fetch_kb, write_kb, launches, kernel):
 def main():
     p = argparse.ArgumentParser()
     for k in ("forward-fetch", "forward-write", "forward-tcc", "pipeline-fetch", "pipeline-write",
-              "pipeline-tcc", "pipeline-trace", "c3-fetch", "c3-write", "c3-tcc"):
+              "pipeline-tcc", "pipeline-trace", "c3-fetch", "c3-write", "c3-tcc", "blocks-fetch", "blocks-write", "blocks-tcc"):
         p.add_argument("--" + k)
     p.add_argument("--iters", type=int, default=0, help="launches per pattern in the forward passes")
     p.add_argument("--expected-unique-read-bytes", type=int, default=65536 * 64 * 512)
@@ -148,6 +148,15 @@ def main():
             for name, v in tr.items():
                 if "SegmentedScatterAddKernel" in name:
                     K["backward_c4"]["kernel_ms_profiled"] = round(avg(v) / 1e6, 5)
+    if a.blocks_fetch and a.blocks_write:
+        # the same pipeline with Transpose(sample_blocks = recommended): the backward's traffic on the blocked order
+        bf = pick(read_counters(a.blocks_fetch), "SegmentedScatterAddKernel", "FETCH_SIZE")
+        bw = pick(read_counters(a.blocks_write), "SegmentedScatterAddKernel", "WRITE_SIZE")
+        K["backward_c4_sample_blocks"] = entry(avg(bf), avg(bw), len(bf), "SegmentedScatterAddKernel")
+        if a.blocks_tcc:
+            tb = read_counters(a.blocks_tcc)
+            h, m = avg(pick(tb, "SegmentedScatterAddKernel", "TCC_HIT_sum")), avg(pick(tb, "SegmentedScatterAddKernel", "TCC_MISS_sum"))
+            K["backward_c4_sample_blocks"]["l2"] = {"TCC_HIT_sum": h, "TCC_MISS_sum": m, "hit_rate": round(h / (h + m), 4)}
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
         f.write("\n")
