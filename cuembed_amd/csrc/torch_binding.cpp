@@ -140,7 +140,7 @@ at::Tensor cuembed_extract_row_ids_from_offsets_op(const at::Tensor& offsets, co
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> TransposeImpl(const at::Tensor& rows, const at::Tensor& cols,
                                                              const at::Tensor& weights, const int index_bits,
-                                                             const int row_bits) {
+                                                             const int row_bits, const int sample_blocks = 1) {
   CheckGpu(rows, "rows");
   CheckGpu(cols, "cols");
   const int idx = IndexCode(rows, "rows");
@@ -162,12 +162,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> TransposeImpl(const at::Tensor& r
   if (nnz == 0) return {t_rows, t_cols, t_w};
   size_t lwork = 0;
   const void* query_weights = w.defined() ? reinterpret_cast<const void*>(256) : nullptr;  // only its nullness matters
-  ::cuembed_transpose_hinted(nullptr, nullptr, query_weights, static_cast<int>(nnz), idx, wt, nullptr, nullptr,
-                             nullptr, nullptr, &lwork, index_bits, row_bits, nullptr);
+  ::cuembed_transpose_sample_blocks(nullptr, nullptr, query_weights, static_cast<int>(nnz), idx, wt, nullptr, nullptr,
+                                    nullptr, nullptr, &lwork, index_bits, row_bits, sample_blocks, nullptr);
   at::Tensor work = at::empty({static_cast<int64_t>(lwork)}, r.options().dtype(at::kByte));
-  ::cuembed_transpose_hinted(Ptr(r), Ptr(c), Ptr(w), static_cast<int>(nnz), idx, wt, MutPtr(t_rows), MutPtr(t_cols),
-                             w.defined() ? MutPtr(t_w) : nullptr, static_cast<char*>(work.data_ptr()), &lwork,
-                             index_bits, row_bits, CurrentStream(r));
+  ::cuembed_transpose_sample_blocks(Ptr(r), Ptr(c), Ptr(w), static_cast<int>(nnz), idx, wt, MutPtr(t_rows),
+                                    MutPtr(t_cols), w.defined() ? MutPtr(t_w) : nullptr,
+                                    static_cast<char*>(work.data_ptr()), &lwork, index_bits, row_bits, sample_blocks,
+                                    CurrentStream(r));
   return {t_rows, t_cols, t_w};
 }
 
@@ -219,6 +220,17 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> cuembed_transpose_sample_ids_op(c
                                                                             const at::Tensor& weights,
                                                                             const int64_t num_categories) {
   return TransposeImpl(sample_ids, indices, weights, IndexBits(num_categories), 31);
+}
+
+// Transpose in blocks of samples (cuembed::Transpose, sample_blocks): for the compressed gradient only -- the
+// result is an UNCOALESCED compressed gradient, one row per (block, table row).  sample_blocks <= 0: the
+// library's recommendation for a gradient of `grad_width` elements of `grad_elem_size` bytes per sample.
+std::tuple<at::Tensor, at::Tensor, at::Tensor> cuembed_transpose_sample_blocks_op(const at::Tensor& sample_ids,
+                                                                               const at::Tensor& indices,
+                                                                               const at::Tensor& weights,
+                                                                               const int64_t num_categories,
+                                                                               const int64_t sample_blocks) {
+  return TransposeImpl(sample_ids, indices, weights, IndexBits(num_categories), 31, static_cast<int>(sample_blocks));
 }
 
 at::Tensor cuembed_compute_compressed_grad_indices_op(const at::Tensor& transpose_indices) {
@@ -370,6 +382,9 @@ TORCH_LIBRARY(cuembed_pyt, m) {
   m.def(
       "cuembed_transpose_fixed_hotness(Tensor indices, Tensor weights, int num_categories, bool compressed) -> "
       "(Tensor, Tensor, Tensor, Tensor)");
+  m.def(
+      "cuembed_transpose_sample_blocks(Tensor sample_ids, Tensor indices, Tensor weights, int num_categories, int "
+      "sample_blocks) -> (Tensor, Tensor, Tensor)");
   m.def("cuembed_compute_compressed_grad_indices(Tensor transpose_indices) -> Tensor");
   m.def(
       "cuembed_embedding_backward_compressed(Tensor y_grad, int num_unique, Tensor transpose_indices, Tensor "
@@ -386,6 +401,7 @@ TORCH_LIBRARY_IMPL(cuembed_pyt, CUDA, m) {  // HIP tensors use the CUDA dispatch
   m.impl("cuembed_extract_row_ids_from_offsets", cuembed_extract_row_ids_from_offsets_op);
   m.impl("cuembed_transpose_bounded", cuembed_transpose_bounded_op);
   m.impl("cuembed_transpose_sample_ids", cuembed_transpose_sample_ids_op);
+  m.impl("cuembed_transpose_sample_blocks", cuembed_transpose_sample_blocks_op);
   m.impl("cuembed_transpose_fixed_hotness", cuembed_transpose_fixed_hotness_op);
   m.impl("cuembed_compute_compressed_grad_indices", cuembed_compute_compressed_grad_indices_op);
   m.impl("cuembed_embedding_backward_compressed", cuembed_embedding_backward_compressed_op);

@@ -194,6 +194,32 @@ def test_sparse_gradient_extension(pyt, weighted):
     assert torch.allclose(g_sparse.to_dense(), weight.grad, rtol=1e-4, atol=1e-4)
 
 
+def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt):
+    """sparse_grad="uncoalesced": the batch is transposed in the recommended number of sample blocks (2 here:
+    B = 40,000 samples of 64 lookups, 512-byte rows), a table row may appear once per block in the sparse gradient,
+    and the densified gradient equals the coalesced one bit for bit on integer data."""
+    import cuembed_amd as ce
+    k, d, B, H = 50000, 256, 40000, 64
+    assert ce.recommended_sample_blocks(torch.float16, d, B, B * H) == 2
+    weight = torch.randint(-2, 3, (k, d), device="cuda").half().requires_grad_()
+    indices = (k * torch.rand(B * H, device="cuda") ** 3).long()
+    offsets = torch.arange(0, B * H + 1, H, device="cuda")
+    up = torch.randint(-1, 2, (B, d), device="cuda").half()
+    grads = {}
+    for kind in (True, "uncoalesced"):
+        weight.grad = None
+        (pyt.cuemb_embedding(weight, indices, offsets, None, sparse_grad=kind) * up).sum().backward()
+        grads[kind] = weight.grad
+    ids = grads[True]._indices()[0]
+    assert (ids[1:] > ids[:-1]).all()                                # coalesced: ascending, no duplicates
+    assert not grads["uncoalesced"].is_coalesced()
+    n_unique = grads[True]._nnz()
+    assert n_unique < grads["uncoalesced"]._nnz() <= 2 * n_unique
+    assert float(grads[True].to_dense().abs().max()) < 2048          # exact in fp16
+    assert torch.equal(grads["uncoalesced"].to_dense(), grads[True].to_dense())
+    assert torch.equal(grads["uncoalesced"].coalesce()._values(), grads[True]._values())
+
+
 @pytest.mark.parametrize("mode", ["sum", "mean", "concat"])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_fixed_hotness_2d_indices_all_modes(pyt, mode, weighted):
@@ -257,7 +283,8 @@ def test_ops_are_the_native_extension(pyt):
         maps = f.read()
     assert "libcuembed_pyt.so" in maps and "libcuembed_amd.so" in maps
     for name in ("cuembed_embedding_forward", "cuembed_extract_row_ids_from_csr", "cuembed_transpose",
-                 "cuembed_embedding_backward", "cuembed_transpose_fixed_hotness", "cuembed_transpose_sample_ids"):
+                 "cuembed_embedding_backward", "cuembed_transpose_fixed_hotness", "cuembed_transpose_sample_ids",
+                 "cuembed_transpose_sample_blocks"):
         op = getattr(torch.ops.cuembed_pyt, name).default
         assert torch._C._dispatch_has_kernel_for_dispatch_key(op.name(), "CUDA")
 
@@ -333,6 +360,7 @@ def test_opcheck_schemas_and_fake_kernels(pyt):
             (ops.cuembed_transpose, (sid, idx, None)),
             (ops.cuembed_transpose_bounded, (sid, idx, None, k)),
             (ops.cuembed_transpose_sample_ids, (sid, idx, w, k)),
+            (ops.cuembed_transpose_sample_blocks, (sid, idx, w, k, 2)),
             (ops.cuembed_transpose_fixed_hotness, (idx.view(B, H), w.view(B, H), k, True)),
             (ops.cuembed_transpose_fixed_hotness, (idx.view(B, H), None, k, False)),
             (ops.cuembed_compute_compressed_grad_indices, (t_idx,)),
