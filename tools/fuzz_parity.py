@@ -3,7 +3,8 @@
 random table shapes, batch sizes, hotness, index distributions and types, fixed / CSR layouts,
 weights -- forward (bit-exact), row-id extraction, Transpose (bit-exact, stable; with and without the
 key / row bounds; the fused fixed-hotness variant; signed keys and arbitrary payloads), compressed-index
-remap, EmbeddingBackward dense and compressed (exact on small-integer gradients).
+remap, EmbeddingBackward dense and compressed (exact on small-integer gradients), the compressed backward with
+num_unique left on the device, and Transpose in sample blocks + the uncoalesced compressed gradient it leads to.
 
     python tools/fuzz_parity.py [--seconds 300] [--seed 0]
 
@@ -32,9 +33,9 @@ def one_case(rng, ce, O, np, torch, verbose=False):
     W = int(rng.integers(1, 40)) * (lane_bytes // es if lane_bytes >= es else 1)
     if (W * es) % 4:
         W *= 2
-    scale = rng.integers(0, 4)
-    B = int(rng.integers(1, [40, 700, 5000, 20000][scale]))
-    H = int(rng.integers(1, [70, 40, 20, 9][scale]))
+    scale = rng.integers(0, 5)
+    B = int(rng.integers(1, [40, 700, 5000, 20000, 60000][scale]))
+    H = int(rng.integers(1, [70, 40, 20, 9, 8][scale]))
     ncat = int(rng.integers(H + 1, [300, 5000, 100000, 3000000][rng.integers(0, 4)]))
     alpha = [0.0, 1.05, 1.15, 1.6][rng.integers(0, 4)]
     csr = bool(rng.integers(0, 2))
@@ -104,10 +105,40 @@ def one_case(rng, ce, O, np, torch, verbose=False):
         got_c, got_inv = ce.embedding_backward(dev(gy), nu, d_ti, d_ts, d_remap, d_tw if use_w else None)
         assert np.array_equal(got_c.float().cpu().numpy(), want_c), ("backward compressed", desc)
         assert np.array_equal(got_inv.cpu().numpy(), want_inv), ("inverse mapping", desc)
+        # the same without num_unique on the host: worst-case buffers, rows past the last id untouched
+        if rng.integers(0, 3) == 0:
+            cap = min(nnz, ncat)
+            buf = torch.full((cap, W), 77.0, dtype=got_c.dtype, device="cuda")
+            ibuf = torch.full((cap,), -3, dtype=d_ti.dtype, device="cuda")
+            ce.embedding_backward(dev(gy), None, d_ti, d_ts, d_remap, d_tw if use_w else None, grad_embedding=buf,
+                                  inverse_mapping=ibuf)
+            assert torch.equal(buf[:nu], got_c) and torch.equal(ibuf[:nu], got_inv), ("backward, num_unique on device", desc)
+            assert bool((buf[nu:] == 77.0).all()) and bool((ibuf[nu:] == -3).all()), ("rows past the last id", desc)
+        want_d = None
         if ncat * W <= 40_000_000:
             want_d, _ = O.embedding_backward(gy.astype(np.float32), W, ncat, ti, ts, None, w32)
             got_d, _ = ce.embedding_backward(dev(gy), ncat, d_ti, d_ts, None, d_tw if use_w else None)
             assert np.array_equal(got_d.float().cpu().numpy(), want_d), ("backward dense", desc)
+        # ---- transpose in sample blocks (extension): every block sorted on its own == the oracle block by block;
+        # the uncoalesced compressed gradient, scattered into the table, is the dense gradient
+        if nnz > 131072 and rng.integers(0, 2) == 0:
+            P = int(rng.integers(2, 10))
+            L = ce.transpose_sample_block_length(nnz, P)
+            parts = [O.transpose(sid[lo:lo + L], indices[lo:lo + L], None if weights is None else weights[lo:lo + L],
+                                 stable=True) for lo in range(0, nnz, L)]
+            b_ti, b_ts, b_tw = ce.transpose(d_sid, dev(indices), dev(weights), num_categories=bound, num_rows=rows_bound,
+                                            sample_blocks=P)
+            assert np.array_equal(b_ti.cpu().numpy(), np.concatenate([q[0] for q in parts])), ("block transpose keys", P, desc)
+            assert np.array_equal(b_ts.cpu().numpy(), np.concatenate([q[1] for q in parts])), ("block transpose rows", P, desc)
+            if not csr:
+                f = ce.transpose_fixed_hotness(dev(indices), B, H, dev(weights), num_categories=bound, sample_blocks=P)
+                assert torch.equal(f[0], b_ti) and torch.equal(f[1], b_ts), ("block transpose_fixed_hotness", P, desc)
+            if want_d is not None:
+                b_remap = ce.compute_compressed_grad_indices(b_ti)
+                nub = int(b_remap[-1].item()) + 1
+                bc, binv = ce.embedding_backward(dev(gy), nub, b_ti, b_ts, b_remap, b_tw if use_w else None)
+                dense = torch.zeros((ncat, W), dtype=torch.float32, device="cuda").index_add_(0, binv.long(), bc.float())
+                assert np.array_equal(dense.cpu().numpy(), want_d), ("backward over sample blocks", P, desc)
     return desc
 
 
