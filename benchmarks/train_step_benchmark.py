@@ -96,7 +96,8 @@ def main():
                                               inverse_mapping=comp_inv)
             ev[3].record()
             if a.exchange == "sparse" and use_dist:
-                D.allreduce_sparse_grad(rows, inv, a.rows, algorithm=a.sparse_algorithm, num_unique=remap[-1:] + 1)
+                D.allreduce_sparse_grad(rows, inv, a.rows, algorithm=a.sparse_algorithm, num_unique=remap[-1:] + 1,
+                                        coalesced=blocks == 1)
         ev[4].record()
 
     def sync():

@@ -160,14 +160,19 @@ def owner_bounds(num_categories, world):
     return [shard_bounds(num_categories, r, world) for r in range(world)]
 
 
-def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, algorithm="auto", num_unique=None):
+def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, algorithm="auto", num_unique=None,
+                          coalesced=True):
     """Sum compressed gradients across ranks without materialising the dense table gradient.
 
     rows[num_unique_r, W] / inverse_mapping[num_unique_r] are this rank's compressed gradient
     (EmbeddingBackward with remapped indices; ids ascending).  `num_unique` (optional, a 1-element
     device tensor, e.g. remap[-1:] + 1): only that many leading rows are valid -- for buffers that
-    were sized for the worst case because the count never left the device.  Returns
-    (unique_ids, summed_rows), identical on every rank.  Two algorithms:
+    were sized for the worst case because the count never left the device.  `coalesced=False`: the ids
+    are not ascending / not unique -- the uncoalesced gradient of a batch that was transposed in sample
+    blocks (ops.transpose(..., sample_blocks=)): the owner-partitioned exchange then merges the rank's own
+    rows first (one more Transpose + EmbeddingBackward over its rows; it also sends fewer rows), the
+    all-gather exchange takes them as they are.  Returns (unique_ids, summed_rows), identical on every
+    rank.  Two algorithms:
 
       "allgather": every rank all-gathers all (id, row) pairs and merges them locally with one
                    sort + segmented sum.  Per rank ~ G * n * (W * elem + 8) bytes come in and
@@ -183,7 +188,8 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     Either way the traffic is a few hundred MB per rank instead of num_categories * W * elem for
     the dense all-reduce (at the north-star shape 293 MB vs 5.12 GB of gradient per rank).
     Host read-backs: two per call (the ranks' row counts before the exchange of rows; the size of the
-    result), whatever the algorithm -- the sizes of the tensors exchanged and returned are host values."""
+    result), whatever the algorithm -- the sizes of the tensors exchanged and returned are host values
+    (three for coalesced=False with the owner algorithm and a device-side count)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if algorithm == "auto":
@@ -191,6 +197,14 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     if algorithm not in ("allgather", "owner"):
         raise ValueError("algorithm must be 'auto', 'allgather' or 'owner'")
     ids = inverse_mapping.to(torch.int64)
+    if not coalesced and algorithm == "owner":
+        # the owner ranges are cut out of ASCENDING ids: coalesce this rank's rows first (the ids of a sample-block
+        # order ascend only inside a block, and a row may be there once per block).  A device-side count is read
+        # back here (one more read-back than for a coalesced gradient): merging a worst-case buffer would cost far more
+        if num_unique is not None:
+            k = int(num_unique.item())
+            ids, rows = ids[:k], rows[:k]
+        ids, rows, num_unique = _merge(ids, rows, num_categories)
     if algorithm == "allgather":
         all_ids, all_vals = _gather_ragged(ids, rows, group, count=num_unique)     # read-back 1: the ranks' counts
         uniq, summed, count = _merge(all_ids, all_vals, num_categories)

@@ -84,6 +84,26 @@ def _worker(rank, world, port, csr, ret):
             rebuilt = np.zeros_like(want)
             rebuilt[ids.numpy()] = rows.numpy()
             assert np.array_equal(rebuilt, want), ("padded", algorithm)
+        # an UNCOALESCED compressed gradient (what a transpose in sample blocks leads to): ids ascend only inside a
+        # block and a row may appear once per block -- here: the rank's lookups cut in two halves
+        half = t_idx.shape[0] // 2
+        parts_rows, parts_ids = [], []
+        for lo_, hi_ in ((0, half), (half, t_idx.shape[0])):
+            o = np.argsort(idx.numpy()[lo_:hi_], kind="stable")
+            b_idx, b_sid = idx.numpy()[lo_:hi_][o], sid[lo_:hi_][o]
+            b_w = None if w is None else w.numpy()[lo_:hi_][o]
+            b_remap = O.compute_compressed_grad_indices(b_idx)
+            c_, i_ = O.embedding_backward(gy, W, int(b_remap[-1]) + 1, b_idx, b_sid, b_remap, b_w)
+            parts_rows.append(c_)
+            parts_ids.append(i_)
+        u_rows, u_ids = np.concatenate(parts_rows), np.concatenate(parts_ids)
+        for algorithm in ("allgather", "owner"):
+            ids, rows = D.allreduce_sparse_grad(torch.from_numpy(u_rows), torch.from_numpy(u_ids), ncat,
+                                                algorithm=algorithm, coalesced=False)
+            assert np.all(np.diff(ids.numpy()) > 0), ("uncoalesced", algorithm)
+            rebuilt = np.zeros_like(want)
+            rebuilt[ids.numpy()] = rows.numpy()
+            assert np.array_equal(rebuilt, want), ("uncoalesced", algorithm)
         # nothing to exchange on any rank (a batch without lookups)
         for algorithm in ("allgather", "owner"):
             ids, rows = D.allreduce_sparse_grad(torch.empty((0, W)), torch.empty((0,), dtype=torch.int64), ncat,

@@ -102,6 +102,20 @@ def main():
             rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device=dev)
             rebuilt[ids.long()] = summed
             check(algorithm + ": padded sparse exchange == dense all-reduce", torch.equal(rebuilt, dense))
+        # the shard transposed in sample blocks (forced: the shard is small): an uncoalesced gradient through both exchanges
+        b_idx, b_sid, b_w = ce.transpose(sid, idx.contiguous(), None if w is None else w.contiguous(), num_categories=ncat,
+                                         num_rows=b_loc, sample_blocks=3)
+        if idx.numel() > 131072:
+            check("sample blocks really cut the shard", not torch.equal(b_idx, t_idx))
+        b_remap = ce.compute_compressed_grad_indices(b_idx)
+        nub = int(b_remap[-1].item()) + 1
+        b_rows, b_inv = ce.embedding_backward(gy, nub, b_idx, b_sid, b_remap, b_w)
+        for algorithm in ("allgather", "owner"):
+            ids, summed = D.allreduce_sparse_grad(b_rows, b_inv, ncat, algorithm=algorithm, coalesced=False)
+            check(algorithm + ": uncoalesced exchange, ids ascending and unique", bool((ids[1:] > ids[:-1]).all()))
+            rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device=dev)
+            rebuilt[ids.long()] = summed
+            check(algorithm + ": uncoalesced sparse exchange == dense all-reduce", torch.equal(rebuilt, dense))
         for algorithm in ("allgather", "owner"):
             ids, summed = D.allreduce_sparse_grad(rows, inv, ncat, algorithm=algorithm)
             check(algorithm + ": ids ascending and unique", bool((ids[1:] > ids[:-1]).all()))
