@@ -464,6 +464,17 @@ __device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const in
   }
 }
 
+//! Tile of workgroup b in the scatter pass.  Workgroups are dealt round-robin to the 8 XCDs (b % 8), so with
+//! tile = b neighbouring tiles -- whose 64-byte runs of a bin are neighbours in the output -- land on different,
+//! non-coherent L2s and each writes its half of a 128-byte line on its own.  This map keeps runs of tiles on one
+//! XCD (tile = (b % 8) * ceil(tiles / 8) + b / 8 while that is a tile, the identity for the ragged rest), so that
+//! halves written a few workgroups apart meet in that L2 before the line leaves it.  Any bijection is correct.
+__device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles) {
+  const int per_xcd = num_tiles / 8;              // tiles of the rectangular part, per XCD
+  if (b >= per_xcd * 8) return b;                 // ragged rest (fewer than 8 tiles)
+  return (b & 7) * per_xcd + (b >> 3);
+}
+
 //! Scatter pass.  Position of a key = (keys with a smaller digit) + (equal-digit keys in
 //! earlier tiles) + (equal-digit keys of earlier waves of this tile) + (its rank in its wave).
 //! Keys and payloads are first put in digit order INSIDE the tile through LDS, so that the
@@ -530,7 +541,8 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  const int64_t tile_base = static_cast<int64_t>(blockIdx.x) * kSortTile;
+  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles);
+  const int64_t tile_base = static_cast<int64_t>(tile) * kSortTile;
   const int count = static_cast<int>(n - tile_base < kSortTile ? n - tile_base : kSortTile);
   // ---- load first (everything in flight at once): the digit bases below are computed under the loads' latency ----
   const int64_t wave_base = tile_base + wave * (64 * kSortItems);
@@ -550,9 +562,9 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     unsigned before_me, bin_sum;
     unsigned segment_start = 0;   // the tile's segment is sorted on its own: positions start at its first element
     if (bin_total != nullptr) {
-      const int segment = static_cast<int>(blockIdx.x) / segment_tiles;
+      const int segment = tile / segment_tiles;
       segment_start = static_cast<unsigned>(segment) * static_cast<unsigned>(segment_tiles) * kSortTile;
-      before_me = tile_prefix[static_cast<size_t>(tid) * num_tiles + blockIdx.x];
+      before_me = tile_prefix[static_cast<size_t>(tid) * num_tiles + tile];
       bin_sum = bin_total[segment * kSortBins + tid];
     } else {
       // few tiles: no scan launch -- thread `bin` adds up the raw tile histograms of its bin itself
@@ -561,7 +573,7 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
       bin_sum = 0;
       for (int t = 0; t < num_tiles; ++t) {
         const unsigned c = row[t];
-        if (t < static_cast<int>(blockIdx.x)) before_me += c;
+        if (t < tile) before_me += c;
         bin_sum += c;
       }
     }
