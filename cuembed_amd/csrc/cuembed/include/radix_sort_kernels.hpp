@@ -226,6 +226,18 @@ __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int wher
   }
 }
 
+//! Tile of workgroup b in the histogram and scatter passes.  Workgroups are dealt round-robin to the 8 XCDs (b % 8), so with
+//! tile = b neighbouring tiles -- whose 64-byte runs of a bin are neighbours in the output -- land on different,
+//! non-coherent L2s and each writes its half of a 128-byte line on its own.  This map keeps runs of tiles on one
+//! XCD (tile = (b % 8) * ceil(tiles / 8) + b / 8 while that is a tile, the identity for the ragged rest), so that
+//! halves written a few workgroups apart meet in that L2 before the line leaves it (the histogram pass writes ONE
+//! 4-byte word per bin and tile: 32 neighbouring tiles share a line).  Any bijection is correct.
+__device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles) {
+  const int per_xcd = num_tiles / 8;              // tiles of the rectangular part, per XCD
+  if (b >= per_xcd * 8) return b;                 // ragged rest (fewer than 8 tiles)
+  return (b & 7) * per_xcd + (b >> 3);
+}
+
 //! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
 //! Plain LDS atomics: order does not matter for counting.  In pass 0 the tile's OR and AND of
 //! its keys, and the OR of its 64-bit first payloads (`payload64`, or nullptr), go to
@@ -253,7 +265,8 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
     high = static_cast<KeyT>(plan.key_high);
     where = RouteArray(plan, narrow).src;
   }
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile + tid;
+  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles);
+  const int64_t base = static_cast<int64_t>(tile) * kSortTile + tid;
   KeyT key[kSortItems];
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
 #pragma unroll
@@ -304,7 +317,7 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   unsigned total = 0;
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) total += count[w][tid];
-  tile_hist[static_cast<size_t>(tid) * num_tiles + blockIdx.x] = total;
+  tile_hist[static_cast<size_t>(tid) * num_tiles + tile] = total;
   if (reduce_bits && tid == 0) {
     unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
 #pragma unroll
@@ -313,9 +326,9 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
       all &= wave_bits[w][1];
       pay |= wave_bits[w][2];
     }
-    tile_bits[kStateWords * blockIdx.x] = any;
-    tile_bits[kStateWords * blockIdx.x + 1] = all;
-    tile_bits[kStateWords * blockIdx.x + 2] = pay;
+    tile_bits[kStateWords * tile] = any;
+    tile_bits[kStateWords * tile + 1] = all;
+    tile_bits[kStateWords * tile + 2] = pay;
   }
 }
 
@@ -462,17 +475,6 @@ __device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const in
       slot[r] += tile_start[digit] + wave_count[wave][digit];
     }
   }
-}
-
-//! Tile of workgroup b in the scatter pass.  Workgroups are dealt round-robin to the 8 XCDs (b % 8), so with
-//! tile = b neighbouring tiles -- whose 64-byte runs of a bin are neighbours in the output -- land on different,
-//! non-coherent L2s and each writes its half of a 128-byte line on its own.  This map keeps runs of tiles on one
-//! XCD (tile = (b % 8) * ceil(tiles / 8) + b / 8 while that is a tile, the identity for the ragged rest), so that
-//! halves written a few workgroups apart meet in that L2 before the line leaves it.  Any bijection is correct.
-__device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles) {
-  const int per_xcd = num_tiles / 8;              // tiles of the rectangular part, per XCD
-  if (b >= per_xcd * 8) return b;                 // ragged rest (fewer than 8 tiles)
-  return (b & 7) * per_xcd + (b >> 3);
 }
 
 //! Scatter pass.  Position of a key = (keys with a smaller digit) + (equal-digit keys in
