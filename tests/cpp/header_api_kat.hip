@@ -173,6 +173,15 @@ void BackwardKat(hipStream_t stream) {
   HIP_OK(hipStreamSynchronize(stream));
   Expect("bwd compressed", cgrad.host(), {5, 6, 7, 8, 1, 2, 3, 4, 6, 8, 10, 12});
   ExpectInt("bwd inverse mapping", inv.host(), {0, 1, 3});
+  // extension: num_unique left on the device (num_grad_embedding_rows < 0): worst-case buffers (nnz rows),
+  // the rows past the last id keep what they held
+  DeviceArray<GradT> wgrad(Vec<GradT>({9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9}));
+  DeviceArray<IndexT> winv(std::vector<IndexT>{7, 7, 7, 7});
+  cuembed::EmbeddingBackward<GradT, IndexT>(gy.ptr, 4, -1, 4, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false, wgrad.ptr,
+                                            winv.ptr, stream);
+  HIP_OK(hipStreamSynchronize(stream));
+  Expect("bwd compressed, num_unique on the device", wgrad.host(), {5, 6, 7, 8, 1, 2, 3, 4, 6, 8, 10, 12, 9, 9, 9, 9});
+  ExpectInt("bwd inverse mapping, num_unique on the device", winv.host(), {0, 1, 3, 7});
 }
 
 // ---- this library's extensions of the header-only API (same known answers through other doors) ----
@@ -205,6 +214,38 @@ void ExtensionTransposeKat(hipStream_t stream) {
   HIP_OK(hipStreamSynchronize(stream));
   ExpectInt("signed keys", t_rows.host(), {-2, -2, 0, 3, 7});
   ExpectInt("wide payloads", t_cols.host(), {5, 6, sizeof(IndexT) == 8 ? (1ll << 40) : 70000, -9, 0});
+  // Transpose in sample blocks: 200,000 lookups in 2 blocks -- each block sorted and stable on its own
+  {
+    const int n = 200000, blocks = 2;
+    std::vector<IndexT> h_cols(n), h_rows(n);
+    for (int i = 0; i < n; ++i) {
+      h_cols[i] = static_cast<IndexT>((static_cast<int64_t>(i) * 7919) % 1000);
+      h_rows[i] = static_cast<IndexT>(i / 4);
+    }
+    DeviceArray<IndexT> b_cols(h_cols), b_rows(h_rows), o_keys(n), o_rows(n);
+    size_t lw = 0;
+    cuembed::Transpose<IndexT, WeightT>(b_rows.ptr, b_cols.ptr, no_w, n, o_keys.ptr, o_rows.ptr, nullptr, nullptr, &lw, stream,
+                                        10, 31, blocks);
+    DeviceArray<char> work3(lw);
+    cuembed::Transpose<IndexT, WeightT>(b_rows.ptr, b_cols.ptr, no_w, n, o_keys.ptr, o_rows.ptr, nullptr, work3.ptr, &lw, stream,
+                                        10, 31, blocks);
+    HIP_OK(hipStreamSynchronize(stream));
+    const int64_t L = cuembed::TransposeSampleBlockLength(n, blocks);
+    const std::vector<IndexT> k = o_keys.host(), r = o_rows.host();
+    bool ok = L % 4096 == 0 && L < n && 2 * L >= n;
+    long long sum_in = 0, sum_out = 0;
+    for (int i = 0; i < n; ++i) {
+      sum_in += static_cast<long long>(h_cols[i]) * 31 + h_rows[i];
+      sum_out += static_cast<long long>(k[i]) * 31 + r[i];
+      if (i % L != 0) ok = ok && (k[i - 1] < k[i] || (k[i - 1] == k[i] && r[i - 1] <= r[i]));   // sorted, stable inside a block
+      ok = ok && (r[i] * 4 / L == i / L || (r[i] * 4 + 3) / L == i / L);                          // the pair stayed in its block
+    }
+    ok = ok && sum_in == sum_out && cuembed::RecommendedSampleBlocks<float>(128, 65536, 65536 * 64) == 2;
+    if (!ok) {
+      std::fprintf(stderr, "FAIL: transpose in sample blocks\n");
+      ++g_failures;
+    }
+  }
   // row-cache index translation: rows 3 and 0 are cached in slots 0 and 1, cache 1000 rows above the table
   DeviceArray<int32_t> slot_of_row(std::vector<int32_t>{1, -1, -1, 0, -1});
   DeviceArray<int64_t> translated(4);
