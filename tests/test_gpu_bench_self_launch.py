@@ -52,3 +52,5 @@ def test_gpus_1_line_has_the_contract_fields():
     ex = line["extras"]
     assert ex["sample_blocks"] == 2 and ex["sample_blocks_gradient_equals_reference_order"] is True
     assert ex["backward_compressed_sample_blocks_ms"] < ex["backward_compressed_ms"]
+    ts = ex["train_step_per_gpu"]
+    assert 0 < ts["sample_blocks_2"]["ms"] < ts["sample_blocks_1"]["ms"] < 1.0
