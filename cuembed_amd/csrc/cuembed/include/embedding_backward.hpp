@@ -138,10 +138,10 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
  */
 template <typename GradT>
 inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, const int64_t nnz) {
-  using ElemT = detail::DeviceElemT<GradT>;
-  const detail::RowSplit split = detail::SplitRow<ElemT>(embed_width, nullptr, nullptr);
-  const size_t row_bytes = static_cast<size_t>(embed_width) * sizeof(GradT);
-  const int slices = detail::ChooseColumnSlices(row_bytes, split.lanes_per_row, nnz);
+  const size_t row_bytes = static_cast<size_t>(embed_width > 0 ? embed_width : 0) * sizeof(GradT);
+  if (row_bytes == 0 || row_bytes % 4 != 0 || batch_size <= 0) return 1;   // nothing EmbeddingBackward would slice
+  const int lane_bytes = row_bytes % 16 == 0 ? 16 : (row_bytes % 8 == 0 ? 8 : 4);   // as SplitRow for aligned buffers
+  const int slices = detail::ChooseColumnSlices(row_bytes, static_cast<int>(row_bytes / lane_bytes), nnz);
   if (slices <= 1) return 1;   // small problems: grad_y is not sliced (and fits the L2s anyway)
   const size_t per_l2 = static_cast<size_t>(batch_size) * (row_bytes / slices);
   const size_t budget = size_t{4} << 20;   // one XCD's L2

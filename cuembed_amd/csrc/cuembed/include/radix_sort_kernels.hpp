@@ -16,6 +16,11 @@
 //   RadixTileHistogramKernel   per 4096-key tile: 256-bin histogram of the current digit
 //   RadixScanTilesKernel       per bin: exclusive prefix over the tiles, and the bin total
 //   RadixScatterKernel         per tile: stable rank of every key among equal digits, scatter
+// The caller may ask for BLOCKS of the input to be sorted on their own (RadixSortPairs `blocks`; Transpose's
+// sample_blocks): same launches, the scan runs per (block, bin) and the scatter adds its block's start.
+// Histogram and scatter workgroups take their tile from ScatterTileOfBlock(), which keeps runs of neighbouring
+// tiles on one XCD: the 4-byte histogram words and the 64-byte runs of neighbouring tiles share 128-byte lines,
+// and the XCDs' L2s are not coherent -- what is written from one L2 leaves as one line, not as eight pieces.
 // (A single-kernel-per-pass variant with decoupled look-back was built and measured 30 % SLOWER
 // here: the per-tile status words have to bypass the XCDs' non-coherent L2s, so every look-back
 // hop is a ~1 us memory-side access, and with 1024 tiles starting together the walks are long.)
@@ -23,9 +28,11 @@
 // the lanes holding the same digit with 8 ballots (`match-any`), takes its rank from the
 // popcount of the lower peers, and the lowest peer bumps the wave's digit counter in LDS -- no
 // LDS atomics, no dependence on digit skew, and input order is preserved by construction.
-// What bounds the scatter pass (23 us for 4.19M pairs): a build that stores every tile back
+// What bounds the scatter pass (21 us for 4.19M pairs; 23 before the tile map): a build that stores every tile back
 // contiguously takes 21 us, so it is the ~110 VALU instructions per key of the ranking and the
-// dependent LDS steps, not the scattered stores.  Measured and rejected: peers through per-wave
+// dependent LDS steps, not the scattered stores.  Round 3 built two rankings WITHOUT ballots (lane-private byte
+// counters: one wavefront per tile, and a blocked 256-thread tile ranked in two 4-bit steps); both were exact and
+// both were slower (27 vs 23 us per pass, 0.123 vs 0.107 ms per transpose): DESIGN.md 3.4.  Measured and rejected earlier: peers through per-wave
 // lane bitmaps in LDS (ds_or, read back, clear: -50 VALU per round, 1-5 % slower); a one-compare
 // shortcut for wavefronts whose 64 keys share the digit (2 % slower); 2048-key tiles (10 % slower).
 #ifndef CUEMBED_INCLUDE_RADIX_SORT_KERNELS_HPP_

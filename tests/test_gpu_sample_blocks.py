@@ -96,3 +96,5 @@ def test_recommended_sample_blocks(ce):
     assert ce.recommended_sample_blocks(torch.float32, 128, 65536, 65536 * 64) == 2      # C3 rows: the same 512 bytes
     assert ce.recommended_sample_blocks(torch.float16, 256, 65536, 65536 * 8) == 1       # < 2^20 lookups: not sliced
     assert ce.recommended_sample_blocks(torch.float16, 256, 524288, 524288 * 64) == 16
+    assert ce.recommended_sample_blocks(torch.float16, 3, 65536, 65536 * 64) == 1        # a recommendation never aborts
+    assert ce.recommended_sample_blocks(torch.float32, 0, 0, 0) == 1
