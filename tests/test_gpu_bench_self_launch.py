@@ -54,3 +54,27 @@ def test_gpus_1_line_has_the_contract_fields():
     assert ex["backward_compressed_sample_blocks_ms"] < ex["backward_compressed_ms"]
     ts = ex["train_step_per_gpu"]
     assert 0 < ts["sample_blocks_2"]["ms"] < ts["sample_blocks_1"]["ms"] < 1.0
+
+
+def test_gpus_2_under_torch_distributed_run():
+    """The driver's own multi-GPU launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 --steps 20 --warmup 5` (local rank 0 walks the index stream for the node,
+    every rank meets before the shared file goes)."""
+    import glob
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    before = set(glob.glob("/dev/shm/cuembed_bench_idx_*"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-c3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 * 65536 and line["value"] > 0
+    assert set(glob.glob("/dev/shm/cuembed_bench_idx_*")) == before          # the node's stream file is gone
