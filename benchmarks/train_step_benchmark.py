@@ -50,10 +50,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ngpu = torch.cuda.device_count()
+    dev = torch.device("cuda", local % ngpu)
+    torch.cuda.set_device(dev)
     if world > 1 or "MASTER_ADDR" in os.environ:
-        dist.init_process_group("nccl", device_id=dev)
+        # one GPU per rank over RCCL; ranks that have to share a GPU (a rehearsal on a small box: RCCL refuses two
+        # ranks on one device) exchange over gloo on host copies, which cuembed_amd.distributed does by itself
+        if world > ngpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     use_dist = dist.is_initialized()
     B, H, W = a.batch, a.hotness, a.width
     table = torch.empty((a.rows, W), dtype=torch.float16, device=dev).uniform_(-1, 1)
@@ -115,7 +121,7 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     parts = {n: sum(e[i].elapsed_time(e[i + 1]) for e in events) / a.steps for i, n in enumerate(names)}
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev if not use_dist or dist.get_backend() != "gloo" else "cpu")
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -123,7 +129,8 @@ def main():
         print(json.dumps({"workload": "fp16 fwd+bwd, %dx%d table, batch %d per GPU x %d GPUs, hotness %d, alpha %g"
                                       % (a.rows, W, B, world, H, a.alpha),
                           "exchange": a.exchange, "index_path": "reference_api" if a.reference_api else "fixed_hotness_bounded",
-                          "sample_blocks": blocks,
+                          "sample_blocks": blocks, "backend": dist.get_backend() if use_dist else None,
+                          "ranks_share_gpus": world > ngpu,
                           "n_gpus": world, "ms_per_step": round(ms, 4),
                           "samples_per_s": round(world * B / (ms * 1e-3)),
                           "breakdown_ms": {k: round(v, 4) for k, v in parts.items()}}), flush=True)
