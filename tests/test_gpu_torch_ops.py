@@ -194,7 +194,8 @@ def test_sparse_gradient_extension(pyt, weighted):
     assert torch.allclose(g_sparse.to_dense(), weight.grad, rtol=1e-4, atol=1e-4)
 
 
-def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt):
+@pytest.mark.parametrize("ragged", [False, True], ids=["fixed", "ragged_weighted"])
+def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     """sparse_grad="uncoalesced": the batch is transposed in the recommended number of sample blocks (2 here:
     B = 40,000 samples of 64 lookups, 512-byte rows), a table row may appear once per block in the sparse gradient,
     and the densified gradient equals the coalesced one bit for bit on integer data."""
@@ -202,20 +203,28 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt):
     k, d, B, H = 50000, 256, 40000, 64
     assert ce.recommended_sample_blocks(torch.float16, d, B, B * H) == 2
     weight = torch.randint(-2, 3, (k, d), device="cuda").half().requires_grad_()
-    indices = (k * torch.rand(B * H, device="cuda") ** 3).long()
-    offsets = torch.arange(0, B * H + 1, H, device="cuda")
+    if ragged:   # CSR bags of 32..96 lookups with weights 0.5 / 0.25: the blocks are cut by position, mid-bag if need be
+        lens = torch.randint(32, 97, (B,), device="cuda")
+        offsets = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens.cumsum(0)])
+        n = int(offsets[-1])
+        w = (torch.randint(0, 2, (n,), device="cuda").half() * 0.25 + 0.25)
+    else:
+        offsets = torch.arange(0, B * H + 1, H, device="cuda")
+        n, w = B * H, None
+    indices = (k * torch.rand(n, device="cuda") ** 3).long()
     up = torch.randint(-1, 2, (B, d), device="cuda").half()
     grads = {}
     for kind in (True, "uncoalesced"):
         weight.grad = None
-        (pyt.cuemb_embedding(weight, indices, offsets, None, sparse_grad=kind) * up).sum().backward()
+        (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=kind) * up).sum().backward()
         grads[kind] = weight.grad
     ids = grads[True]._indices()[0]
     assert (ids[1:] > ids[:-1]).all()                                # coalesced: ascending, no duplicates
     assert not grads["uncoalesced"].is_coalesced()
     n_unique = grads[True]._nnz()
     assert n_unique < grads["uncoalesced"]._nnz() <= 2 * n_unique
-    assert float(grads[True].to_dense().abs().max()) < 2048          # exact in fp16
+    # exact in fp16: integers below 2048, or -- with weights 0.5 / 0.25 -- multiples of 0.25 below 512
+    assert float(grads[True].to_dense().abs().max()) < (512 if ragged else 2048)
     assert torch.equal(grads["uncoalesced"].to_dense(), grads[True].to_dense())
     assert torch.equal(grads["uncoalesced"].coalesce()._values(), grads[True]._values())
 
