@@ -10,7 +10,8 @@ from . import _lib  # noqa: F401
 from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBackward,  # noqa: F401
                   EmbeddingForward, ExtractRowIdsForConcat, ExtractRowIdsFromCSR,
                   ExtractRowIdsFromFixed, Transpose, compressed_grad_workspace_bytes,
-                  compute_compressed_grad_indices, embedding_backward, embedding_forward,
+                  compute_compressed_grad_indices, compute_compressed_grad_indices_blocked,
+                  compressed_grad_blocked_workspace_bytes, SHARED_ROW_BIT, embedding_backward, embedding_forward,
                   get_backward_tuning, set_backward_tuning, recommended_sample_blocks, transpose_sample_block_length,
                   embedding_weight_grad,
                   extract_row_ids_for_concat, extract_row_ids_from_csr,

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libcuembed_amd.so")
+# CUEMBED_AMD_LIB: load another build of the same sources (tuning experiments: tools/); never a fallback
+LIB_PATH = os.environ.get("CUEMBED_AMD_LIB") or os.path.join(_PKG, "lib", "libcuembed_amd.so")
 
 _lib = None
 
@@ -56,6 +57,12 @@ def _declare(L):
     L.cuembed_compute_compressed_grad_indices.restype = None
     L.cuembed_compute_compressed_grad_indices.argtypes = [_VP, _I, _I, _VP, _VP,
                                                           ctypes.POINTER(ctypes.c_size_t), _VP]
+    L.cuembed_compute_compressed_grad_indices_blocked.restype = None
+    L.cuembed_compute_compressed_grad_indices_blocked.argtypes = [_VP, _I, _I, _I, _VP, _VP, _VP, _VP,
+                                                                  ctypes.POINTER(ctypes.c_size_t), _VP]
+    L.cuembed_embedding_backward_blocked.restype = None
+    L.cuembed_embedding_backward_blocked.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP,
+                                                     _VP]
     L.cuembed_extract_row_ids_from_fixed.restype = None
     L.cuembed_extract_row_ids_from_fixed.argtypes = [_I, _I, _I, _VP, _VP]
     L.cuembed_extract_row_ids_from_csr.restype = None

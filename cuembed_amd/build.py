@@ -28,7 +28,7 @@ HIPCC_FLAGS = [
     # float atomics as hardware instructions (global_atomic_add_f32 / pk_add_f16)
     "-munsafe-fp-atomics",
     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-]
+] + os.environ.get("CUEMBED_HIPCC_EXTRA", "").split()   # experiments only (e.g. -DCUEMBED_TUNE_...): part of the build key
 
 
 def _hipcc():

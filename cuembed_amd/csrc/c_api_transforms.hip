@@ -147,6 +147,22 @@ void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int i
     CUEMBED_C_API_BAD_TYPE();
 }
 
+void cuembed_compute_compressed_grad_indices_blocked(const void* indices, int nnz, int index_type,
+                                                     int sample_blocks, void* remapped_indices,
+                                                     uint32_t* block_row_ids, uint32_t* num_unique,
+                                                     char* work, size_t* lwork, cuembed_stream_t stream) {
+  if (index_type == CUEMBED_I32)
+    cuembed::ComputeCompressedGradIndicesBlocked<int32_t>(static_cast<const int32_t*>(indices), nnz, sample_blocks,
+                                                          static_cast<int32_t*>(remapped_indices), block_row_ids,
+                                                          num_unique, work, lwork, Stream(stream));
+  else if (index_type == CUEMBED_I64)
+    cuembed::ComputeCompressedGradIndicesBlocked<int64_t>(static_cast<const int64_t*>(indices), nnz, sample_blocks,
+                                                          static_cast<int64_t*>(remapped_indices), block_row_ids,
+                                                          num_unique, work, lwork, Stream(stream));
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
 void cuembed_extract_row_ids_from_fixed(int batch_size, int num_hots, int index_type,
                                         void* row_ids, cuembed_stream_t stream) {
   if (index_type == CUEMBED_I32)

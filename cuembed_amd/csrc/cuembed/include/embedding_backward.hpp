@@ -71,6 +71,17 @@ struct ScatterShape {
   int slices, lanes, segments_per_block, segment_len;
   int64_t nz_blocks, grid_blocks;
   size_t lds;
+  //! Workgroups that walk `count` consecutive lookups (one launch), and the grid that holds them.
+  int64_t NzBlocks(const int64_t count) const {
+    const int64_t num_segments = (count + segment_len - 1) / segment_len;
+    return (num_segments + segments_per_block - 1) / segments_per_block;
+  }
+  int64_t GridBlocks(const int64_t blocks) const {
+    // one workgroup per (nz block, slice); with slices > 1 the 8 / slices XCDs that share a
+    // slice split the nz blocks, so the grid is a whole number of rounds of 8 workgroups
+    const int per_slice = slices > 1 ? 8 / slices : 1;
+    return slices > 1 ? (blocks + per_slice - 1) / per_slice * 8 : blocks;
+  }
 };
 
 template <typename GradT, typename IndexT, int N>
@@ -90,41 +101,59 @@ inline ScatterShape PlanScatter(const int width, const int64_t nnz, const RowSpl
     else break;
   }
   s.segment_len = s.segment_len < 8 ? 8 : s.segment_len & ~7;
-  const int64_t num_segments = (nnz + s.segment_len - 1) / s.segment_len;
-  s.nz_blocks = (num_segments + s.segments_per_block - 1) / s.segments_per_block;
-  // one workgroup per (nz block, slice); with slices > 1 the 8 / slices XCDs that share a
-  // slice split the nz blocks, so the grid is a whole number of rounds of 8 workgroups
-  const int per_slice = s.slices > 1 ? 8 / s.slices : 1;
-  s.grid_blocks = s.slices > 1 ? (s.nz_blocks + per_slice - 1) / per_slice * 8 : s.nz_blocks;
+  s.nz_blocks = s.NzBlocks(nnz);
+  s.grid_blocks = s.GridBlocks(s.nz_blocks);
   s.lds = ScatterStageBytes<GradT, IndexT>(s.segments_per_block, s.segment_len, s.lanes, N, weighted);
   return s;
 }
 
+//! `sample_block_len` > 0: the COO is a sample-blocked order (blocked_order.hpp) -- consecutive blocks of that many
+//! lookups, each sorted on its own, row ids from ComputeCompressedGradIndicesBlocked -- and every block gets its own
+//! stream-ordered launch (a run whose row an earlier block stored is added to it).  0: one launch over everything.
 template <typename GradT, typename IndexT, int N>
 inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const IndexT* sample_ids, const GradT* weights, int64_t nnz,
                              GradT* grad_out, RowSplit split, hipStream_t stream,
                              const bool zero_shared /* compressed gradient: zero only what needs it, see below */,
                              const int64_t zero_rows /* ... and the rows from the last id up to here (<= 0: none) */,
-                             const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */) {
+                             const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */,
+                             const int64_t sample_block_len = 0, const uint32_t* block_row_ids = nullptr) {
   const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr);
   const dim3 block(s.lanes, s.segments_per_block, 1);
   const int block_len = s.segments_per_block * s.segment_len;
+  const bool blocked = sample_block_len > 0 && sample_block_len < nnz;
+  const int64_t launch_len = blocked ? sample_block_len : nnz;
+  const int launches = static_cast<int>((nnz + launch_len - 1) / launch_len);
+  const uint32_t* pair_rows = blocked ? block_row_ids : nullptr;
   if (zero_shared) {
     const int64_t tail_blocks = zero_rows > 0 ? (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock : 0;
-    ZeroSharedAndTailRowsKernel<GradT, IndexT><<<static_cast<unsigned>(s.nz_blocks + tail_blocks), 256, 0, stream>>>(
-        rows, nnz, block_len, s.nz_blocks, width, zero_rows, grad_out);
+    const int64_t per_launch = s.NzBlocks(launch_len);
+    ZeroSharedAndTailRowsKernel<GradT, IndexT>
+        <<<static_cast<unsigned>(per_launch * launches + tail_blocks), 256, 0, stream>>>(
+            rows, nnz, block_len, per_launch, launch_len, launches, width, zero_rows, grad_out, pair_rows);
   }
   int seg_shift = -1;
   if ((s.segment_len & (s.segment_len - 1)) == 0)
     for (seg_shift = 0; (1 << seg_shift) < s.segment_len; ++seg_shift) {}
-  const dim3 grid(static_cast<unsigned>(s.grid_blocks), 1, 1);
-  if (weights != nullptr)
-    SegmentedScatterAddKernel<GradT, IndexT, N, true><<<grid, block, s.lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping);
-  else
-    SegmentedScatterAddKernel<GradT, IndexT, N, false><<<grid, block, s.lds, stream>>>(
-        grad_y, width, rows, sample_ids, weights, nnz, s.segment_len, seg_shift, grad_out, s.slices, run_ids, inverse_mapping);
+  for (int p = 0; p < launches; ++p) {
+    const int64_t first = p * launch_len;
+    const int64_t count = first + launch_len < nnz ? launch_len : nnz - first;
+    const dim3 grid(static_cast<unsigned>(s.GridBlocks(s.NzBlocks(count))), 1, 1);
+    const IndexT* run_ids_p = run_ids != nullptr ? run_ids + first : nullptr;
+#define CUEMBED_LAUNCH_SCATTER(W, BLK)                                                                            \
+  SegmentedScatterAddKernel<GradT, IndexT, N, W, BLK><<<grid, block, s.lds, stream>>>(                              \
+      grad_y, width, rows + first, sample_ids + first, (W) ? weights + first : weights, count, s.segment_len,        \
+      seg_shift, grad_out, s.slices, run_ids_p, inverse_mapping, pair_rows)
+    const bool adds_to_rows = blocked && p > 0;   // (the first block finds nothing stored yet: plain kernel)
+    if (weights != nullptr) {
+      if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(true, true);
+      else CUEMBED_LAUNCH_SCATTER(true, false);
+    } else {
+      if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(false, true);
+      else CUEMBED_LAUNCH_SCATTER(false, false);
+    }
+#undef CUEMBED_LAUNCH_SCATTER
+  }
 }
 
 }  // namespace detail
@@ -167,6 +196,15 @@ inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, 
  * the last id are left untouched.  This takes the host read-back of num_unique out of a training
  * step (the reference's benchmark reads it back between Transpose and EmbeddingBackward,
  * manual_benchmark.cu:392-394).
+ *
+ * Extension: `sample_blocks` > 1 (compressed gradient only) says that the COO comes from
+ * Transpose(..., sample_blocks) and transpose_remapped_indices + block_row_ids from
+ * ComputeCompressedGradIndicesBlocked(..., sample_blocks) (pair numbers and the pair -> gradient row table).
+ * The blocks are scattered one after the other (stream-ordered launches), so that every L2
+ * gathers from 1 / sample_blocks of grad_y at a time; the result has the REFERENCE's layout -- num_unique
+ * ascending rows, the same inverse_mapping as the fully sorted order gives -- with the sum of a table row
+ * taken block by block (fp32 partial sums per block, one GradT rounding per block: within the bound stated in
+ * include/cuembed_amd.h; exact on exactly representable data).  C4: 0.256 -> see DESIGN.md 3.3.
  */
 template <typename GradT, typename IndexT>
 void EmbeddingBackward(const GradT* grad_y,
@@ -180,7 +218,9 @@ void EmbeddingBackward(const GradT* grad_y,
                        const bool skip_grad_init,
                        GradT* grad_embedding,
                        IndexT* inverse_mapping,
-                       const hipStream_t stream = 0) {
+                       const hipStream_t stream = 0,
+                       const int sample_blocks = 1,
+                       const uint32_t* block_row_ids = nullptr) {
   static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value ||
                     std::is_same<GradT, __hip_bfloat16>::value,
                 "EmbeddingBackward: gradients must be float, __half or __hip_bfloat16");
@@ -204,6 +244,14 @@ void EmbeddingBackward(const GradT* grad_y,
   if (nnz <= 0) return;
   const bool zero_shared = !skip_grad_init && compressed;
   const int64_t zero_rows = num_grad_embedding_rows;
+  // sample-blocked order: one launch per block (the length Transpose cut the input at)
+  int64_t sample_block_len = 0;
+  if (sample_blocks > 1) {
+    CUEMBED_ASSERT(compressed);   // a dense gradient has nothing to gain and the ids carry no flags
+    sample_block_len = static_cast<int64_t>(detail::SortSegmentLength(static_cast<size_t>(nnz), sample_blocks));
+    CUEMBED_ASSERT((nnz + sample_block_len - 1) / sample_block_len <= detail::kMaxCoalescedBlocks);
+    if (sample_block_len < nnz) CUEMBED_ASSERT(block_row_ids != nullptr);
+  }
 
   const IndexT* run_ids = compressed ? transpose_indices : nullptr;  // inverse mapping is written by the scatter
   const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
@@ -212,13 +260,16 @@ void EmbeddingBackward(const GradT* grad_y,
   constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
   if (split.elems_per_lane == kMaxN)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
-                                                   stream, zero_shared, zero_rows, run_ids, inverse_mapping);
+                                                   stream, zero_shared, zero_rows, run_ids, inverse_mapping,
+                                                   sample_block_len, block_row_ids);
   else if (split.elems_per_lane == kMaxN / 2)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
-                                                       split, stream, zero_shared, zero_rows, run_ids, inverse_mapping);
+                                                       split, stream, zero_shared, zero_rows, run_ids, inverse_mapping,
+                                                       sample_block_len, block_row_ids);
   else
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
-                                                       split, stream, zero_shared, zero_rows, run_ids, inverse_mapping);
+                                                       split, stream, zero_shared, zero_rows, run_ids, inverse_mapping,
+                                                       sample_block_len, block_row_ids);
 }
 
 }  // namespace cuembed

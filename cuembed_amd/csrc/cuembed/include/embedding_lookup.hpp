@@ -21,20 +21,10 @@
 #include <iostream>
 #include <type_traits>
 
+#include "cuembed/include/cuembed_assert.hpp"
 #include "cuembed/include/embedding_types.hpp"
 #include "cuembed/include/gather_reduce_kernels.hpp"
 #include "cuembed/include/scatter_add_kernels.hpp"
-
-//! Contract violations print the failed condition and abort, exactly like the
-//! reference (embedding_lookup.cuh:151-158).
-#define CUEMBED_ASSERT(condition)                                           \
-  do {                                                                      \
-    if (!(condition)) {                                                     \
-      std::cerr << "Check failed: " #condition << " at " << __FILE__ << ":" \
-                << __LINE__ << std::endl;                                   \
-      std::abort();                                                         \
-    }                                                                       \
-  } while (0)
 
 namespace cuembed {
 

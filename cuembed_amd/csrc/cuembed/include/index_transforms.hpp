@@ -9,6 +9,7 @@
 //   ExtractRowIdsForConcat       <-> index_transforms.cuh:85-93
 //   Transpose                    <-> index_transforms.cuh:224-250
 //   ComputeCompressedGradIndices <-> index_transforms.cuh:278-323
+//   ComputeCompressedGradIndicesBlocked: extension (the same ids for a sample-blocked order, blocked_order.hpp)
 // Every result is integer (or a permutation of the inputs) and bit-exact.
 #ifndef CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_
 #define CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_
@@ -21,6 +22,8 @@
 #include <cstring>
 #include <type_traits>
 
+#include "cuembed/include/blocked_remap_kernels.hpp"
+#include "cuembed/include/cuembed_assert.hpp"
 #include "cuembed/include/index_kernels.hpp"
 #include "cuembed/include/radix_sort_kernels.hpp"
 
@@ -282,6 +285,57 @@ void ComputeCompressedGradIndices(const IndexT* indices,
   }
   assert(*lwork >= need);
   detail::RunHeadScan<IndexT>(indices, n, remapped_indices, work, stream);
+}
+
+/**
+ * @brief ComputeCompressedGradIndices for the output of Transpose(..., sample_blocks) (extension).
+ *
+ * `indices` holds `sample_blocks` blocks of TransposeSampleBlockLength(nnz, sample_blocks) lookups, each block
+ * sorted on its own.  Two outputs that EmbeddingBackward(..., sample_blocks, block_row_ids) consumes together:
+ *   remapped_indices[i] = the number of the (block, table row) pair of lookup i: ids count up through the array, a
+ *                         new one wherever the index changes or a block begins (M <= nnz pairs in all);
+ *   block_row_ids[pair] = the dense id the REFERENCE's fully sorted order assigns to that table row -- its rank
+ *                         among all distinct rows of the batch -- with bit 30 (detail::kSharedRowBit) set when the
+ *                         same row also occurs in an EARLIER block.  Room for nnz entries always suffices.
+ * so that the gradient row of lookup i is block_row_ids[remapped_indices[i]] & 0x3fffffff, exactly the reference's
+ * transpose_remapped_indices value for that lookup, and EmbeddingBackward produces the reference's compressed gradient
+ * (num_unique ascending rows, the same inverse_mapping) while gathering grad_y block by block.
+ * `num_unique` (device pointer, may be null) receives the number of distinct rows.
+ * At most 8 blocks (detail::kMaxCoalescedBlocks), nnz < 2^30.  One block (sample_blocks <= 1, or an input of up
+ * to 131,072 lookups): remapped_indices is exactly ComputeCompressedGradIndices' (the gradient rows themselves);
+ * block_row_ids is neither written here nor read by EmbeddingBackward.
+ * Two-phase workspace query as for Transpose().
+ */
+template <typename IndexT>
+void ComputeCompressedGradIndicesBlocked(const IndexT* indices,
+                                         const int nnz,
+                                         const int sample_blocks,
+                                         IndexT* remapped_indices,
+                                         uint32_t* block_row_ids,
+                                         uint32_t* num_unique,
+                                         char* work,
+                                         size_t* lwork,
+                                         const hipStream_t stream = 0) {
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 0);
+  const size_t block_len = detail::SortSegmentLength(n, sample_blocks);
+  const int blocks = n == 0 ? 1 : static_cast<int>((n + block_len - 1) / block_len);
+  CUEMBED_ASSERT(blocks <= detail::kMaxCoalescedBlocks);
+  CUEMBED_ASSERT(blocks == 1 || n < (size_t{1} << 30));
+  const size_t need = blocks == 1 ? detail::RunHeadScanWorkBytes(n) : detail::BlockedRemapPlan<IndexT>(n, blocks).total;
+  if (work == nullptr) {
+    *lwork = need;
+    return;
+  }
+  assert(*lwork >= need);
+  if (n == 0) return;
+  if (blocks == 1) {
+    detail::RunHeadScan<IndexT>(indices, n, remapped_indices, work, stream);
+    if (num_unique != nullptr)
+      detail::LastIdPlusOneKernel<IndexT><<<1, 1, 0, stream>>>(remapped_indices, static_cast<int64_t>(n), num_unique);
+    return;
+  }
+  detail::BlockedRunHeadRemap<IndexT>(indices, n, blocks, block_len, remapped_indices, block_row_ids, num_unique, work,
+                                      stream);
 }
 
 }  // namespace cuembed

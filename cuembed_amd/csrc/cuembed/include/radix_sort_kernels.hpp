@@ -44,13 +44,15 @@
 #include <cstdint>
 #include <type_traits>
 
+#include "cuembed/include/blocked_order.hpp"
+
 namespace cuembed {
 namespace detail {
 
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kSortItems = 16;                          // keys per lane (8 measured 10 % slower)
-constexpr int kSortTile = kSortThreads * kSortItems;    // 4096 keys per workgroup
+static_assert(kSortTile == kSortThreads * kSortItems, "4096 keys per workgroup (blocked_order.hpp)");
 constexpr int kSortBins = 256;                          // 8-bit digits
 
 struct NoPayload {};
@@ -104,8 +106,6 @@ __device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
 // with 0x80 (`sign_pass`).  A caller-supplied bound (index_bits < all bits) promises keys in
 // [0, 2^index_bits); no digit is flipped then.
 constexpr int kStaticRoutePasses = 3;
-constexpr int kFoldScanTiles = 32;  // up to 131072 keys the tile scan is done inside the scatter kernel
-constexpr int kMaxSortSegments = 64; // input blocks that can be sorted on their own in one call (see RadixSortPairs)
 constexpr int kSelfSumTiles = 4096; // up to 16.7M keys every run-head scan workgroup sums the earlier tiles itself
 enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
@@ -760,16 +760,6 @@ struct RadixSortPlan {
   }
 };
 
-//! Elements per block when n elements are sorted in `blocks` blocks (RadixSortPairs): a whole number of tiles,
-//! ceil(tiles / blocks) of them; the last block takes what is left.  Inputs of up to kFoldScanTiles tiles are
-//! always ONE block (the result is then the full sort).
-inline size_t SortSegmentLength(const size_t n, const int blocks) {
-  const size_t tiles = n == 0 ? 1 : (n + kSortTile - 1) / kSortTile;
-  size_t want = blocks < 1 ? 1 : (blocks > kMaxSortSegments ? kMaxSortSegments : blocks);
-  if (tiles <= static_cast<size_t>(kFoldScanTiles)) want = 1;
-  return (tiles + want - 1) / want * kSortTile;
-}
-
 //! Stable sort of n (key, v1[, v2]) by the low `key_bits` bits of the key.  Inputs are not
 //! modified; outputs and `work` (at least RadixSortPlan::total bytes) must not overlap the inputs.
 //!   signed_keys: the keys are two's-complement numbers; with key_bits = all bits they are put in
@@ -843,6 +833,8 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
 // Run-head scan: remapped[i] = number of positions k in (0, i] with indices[k] != indices[k-1].
 // Two launches over 4096-element tiles: count the run heads per tile, then scan inside every tile
 // on top of the sum of the earlier tiles' counts (which every workgroup adds up itself).
+// For a sample-blocked array (blocked_order.hpp) `block_tiles` > 0 makes the first element of every block a
+// run head whatever its neighbour holds (blocks are whole tiles, so only a tile's first element can be one).
 // ---------------------------------------------------------------------------
 template <typename IndexT>
 __device__ __forceinline__ unsigned RunHead(const IndexT* __restrict__ indices, const int64_t i,
@@ -850,18 +842,26 @@ __device__ __forceinline__ unsigned RunHead(const IndexT* __restrict__ indices, 
   return (i > 0 && i < n && indices[i] != indices[i - 1]) ? 1u : 0u;
 }
 
+//! The tile of this workgroup starts a block of a sample-blocked array.
+__device__ __forceinline__ bool TileStartsBlock(const int block_tiles) {
+  return block_tiles > 0 && blockIdx.x > 0 && static_cast<int>(blockIdx.x) % block_tiles == 0;
+}
+
 //! Flags are 0/1, so a wavefront counts and scans 64 of them with one ballot and a popcount.
 template <typename IndexT>
 __global__ void __launch_bounds__(kSortThreads)
-RunHeadCountKernel(const IndexT* __restrict__ indices, const int64_t n, unsigned* __restrict__ tile_sum) {
+RunHeadCountKernel(const IndexT* __restrict__ indices, const int64_t n, unsigned* __restrict__ tile_sum,
+                   const int block_tiles) {
   __shared__ unsigned wave_sum[kSortWaves];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int64_t wave_base = static_cast<int64_t>(blockIdx.x) * kSortTile + wave * (64 * kSortItems);
+  const bool forced = TileStartsBlock(block_tiles) && threadIdx.x == 0;   // (the tile's first element is in range)
   unsigned c = 0;
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r)
-    c += static_cast<unsigned>(__popcll(__ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0)));
+    c += static_cast<unsigned>(
+        __popcll(__ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0 || (forced && r == 0))));
   if (lane == 0) wave_sum[wave] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -887,21 +887,31 @@ RunHeadTilePrefixKernel(unsigned* __restrict__ tile_count, const int num_tiles) 
   }
 }
 
-template <typename IndexT>
+//! What RunHeadScanKernel does with u[i] = the number of run heads in (0, i]:
+//!   kIds       remapped[i] = u[i]                       (ComputeCompressedGradIndices)
+//!   kCompact   the same, and unique_keys[u[i]] = indices[i] at every run head (and i = 0); block_start[b] =
+//!              u[first element of block b], block_start[number of blocks] = u[n - 1] + 1.
+enum class RunHeadOutput { kIds, kCompact };
+
+template <typename IndexT, RunHeadOutput kOut>
 __global__ void __launch_bounds__(kSortThreads)
 RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
                   const unsigned* __restrict__ tile_count /* run heads per tile; null: one tile */,
                   const bool tile_count_is_prefix,
-                  IndexT* __restrict__ remapped) {
+                  IndexT* __restrict__ remapped,
+                  const int block_tiles,
+                  IndexT* __restrict__ unique_keys, unsigned* __restrict__ block_start) {
   __shared__ unsigned wave_sum[kSortWaves];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int64_t wave_base = static_cast<int64_t>(blockIdx.x) * kSortTile + wave * (64 * kSortItems);
+  const bool starts_block = TileStartsBlock(block_tiles);
+  const bool forced = starts_block && threadIdx.x == 0;
   unsigned long long heads[kSortItems];
   unsigned c = 0;
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
-    heads[r] = __ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0);
+    heads[r] = __ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0 || (forced && r == 0));
     c += static_cast<unsigned>(__popcll(heads[r]));
   }
   // run heads in all earlier tiles: every workgroup adds up the raw per-tile counts itself (at
@@ -930,7 +940,17 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const int64_t i = wave_base + r * 64 + lane;
-    if (i < n) remapped[i] = static_cast<IndexT>(running + static_cast<unsigned>(__popcll(heads[r] & upto)));
+    const unsigned u = running + static_cast<unsigned>(__popcll(heads[r] & upto));
+    if (i < n) {
+      remapped[i] = static_cast<IndexT>(u);
+      if constexpr (kOut == RunHeadOutput::kCompact) {
+        if (((heads[r] >> lane) & 1ull) != 0 || i == 0) unique_keys[u] = indices[i];
+        if (r == 0 && threadIdx.x == 0 && (starts_block || i == 0))
+          block_start[block_tiles > 0 ? static_cast<int>(blockIdx.x) / block_tiles : 0] = u;
+        if (i == n - 1)
+          block_start[block_tiles > 0 ? (static_cast<int>(blockIdx.x) / block_tiles) + 1 : 1] = u + 1;
+      }
+    }
     running += static_cast<unsigned>(__popcll(heads[r]));
   }
 }
@@ -940,25 +960,34 @@ inline size_t RunHeadScanWorkBytes(const size_t n) {
   return SortAlign((tiles ? tiles : 1) * sizeof(unsigned));
 }
 
-template <typename IndexT>
-inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped, char* work,
-                        hipStream_t stream) {
+//! The launches of one run-head scan; `tile_sum` holds one word per tile.
+template <typename IndexT, RunHeadOutput kOut>
+inline void RunHeadScanLaunch(const IndexT* indices, const size_t n, IndexT* remapped, unsigned* tile_sum,
+                              const int block_tiles, IndexT* unique_keys, unsigned* block_start,
+                              hipStream_t stream) {
   if (n == 0) return;
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
-  unsigned* tile_sum = reinterpret_cast<unsigned*>(work);
   if (tiles == 1) {  // one launch instead of two
-    RunHeadScanKernel<IndexT><<<1, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), nullptr, false,
-                                                              remapped);
+    RunHeadScanKernel<IndexT, kOut><<<1, kSortThreads, 0, stream>>>(
+        indices, static_cast<int64_t>(n), nullptr, false, remapped, block_tiles, unique_keys, block_start);
     return;
   }
-  RunHeadCountKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum);
   // every workgroup of the scan adds up the counts of the earlier tiles itself: tiles^2 / 2 words
   // in total -- 2 MB at 1024 tiles, but 5e11 bytes at the API's limit of 2^31 lookups; beyond
   // kSelfSumTiles a single-workgroup prefix pass (one more launch) replaces it
   const bool prefix = tiles > kSelfSumTiles;
+  RunHeadCountKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum,
+                                                                  block_tiles);
   if (prefix) RunHeadTilePrefixKernel<<<1, kSortThreads, 0, stream>>>(tile_sum, tiles);
-  RunHeadScanKernel<IndexT><<<tiles, kSortThreads, 0, stream>>>(indices, static_cast<int64_t>(n), tile_sum,
-                                                               prefix, remapped);
+  RunHeadScanKernel<IndexT, kOut><<<tiles, kSortThreads, 0, stream>>>(
+      indices, static_cast<int64_t>(n), tile_sum, prefix, remapped, block_tiles, unique_keys, block_start);
+}
+
+template <typename IndexT>
+inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped, char* work,
+                        hipStream_t stream) {
+  RunHeadScanLaunch<IndexT, RunHeadOutput::kIds>(indices, n, remapped, reinterpret_cast<unsigned*>(work),
+                                                 /*block_tiles=*/0, nullptr, nullptr, stream);
 }
 
 }  // namespace detail

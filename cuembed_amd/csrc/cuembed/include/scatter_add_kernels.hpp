@@ -21,13 +21,14 @@
 #ifndef CUEMBED_INCLUDE_SCATTER_ADD_KERNELS_HPP_
 #define CUEMBED_INCLUDE_SCATTER_ADD_KERNELS_HPP_
 
+#include "cuembed/include/blocked_order.hpp"
 #include "cuembed/include/embedding_types.hpp"
 #include "cuembed/include/gather_reduce_kernels.hpp"
 
 namespace cuembed {
 namespace detail {
 
-constexpr int kBackwardUnroll = 8;
+constexpr int kBackwardUnroll = 4;
 
 template <int N>
 __device__ __forceinline__ void FlushAtomic(float* dst, const float (&acc)[N]) {
@@ -79,6 +80,8 @@ __device__ __forceinline__ void FlushStore(GradT* dst, const float (&acc)[N]) {
 constexpr int kPackedPad = 4;
 //! Bit 31 of a staged sample id: "this lookup is the last one of its run".
 constexpr uint32_t kRunEndBit = 0x80000000u;
+//! Bit 30 of a staged sample id (sample-blocked order only): "an earlier block already stored the row of this run".
+constexpr uint32_t kSharedRunBit = 0x40000000u;
 
 //! LDS needed by SegmentedScatterAddKernel for `segments_per_block` segments of
 //! `segment_len` lookups handled by `lanes_per_row` lanes each:
@@ -136,7 +139,15 @@ enum : int { kPartHead = 1, kPartTail = 2, kPartWhole = 4 };
 //!    Device-scope atomics to one address serialise at roughly 0.5 us each on MI355X (the
 //!    XCD L2s are not coherent, so they execute memory-side); a row with a 65,528-lookup run
 //!    would otherwise be hit by 512 of them and alone take longer than the rest of the kernel.
-template <typename GradT, typename IndexT, int N, bool kWeighted>
+//! 4. Sample-blocked order (block_row_ids != nullptr; blocked_order.hpp): `rows` holds (block, table row) pair
+//!    numbers and block_row_ids[pair] the gradient row, with kSharedRowBit when an EARLIER block -- an earlier launch
+//!    on the same stream -- already stored that row (ComputeCompressedGradIndicesBlocked); the staging translates.
+//!    The first block has no such rows and runs the plain kernel; the later ones run the kBlocked variant, in which
+//!    a run with the bit is ADDED to what is there: a read-modify-write when the run lies inside this workgroup (nobody else
+//!    touches the row during this launch), the usual float atomics when it crosses workgroups.  The rows to be read
+//!    are requested once while staging (they were written by another launch and come from HBM; that brings their
+//!    lines into this XCD's L2) and again with the gather of the run's last lookup (see `old` below).
+template <typename GradT, typename IndexT, int N, bool kWeighted, bool kBlocked = false>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int width,
@@ -149,7 +160,11 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           GradT* __restrict__ grad_out,
                           const int column_slices,  // 1, 2, 4 or 8: see ColumnSlice
                           const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
-                          IndexT* __restrict__ inverse_mapping) {    // ... and where the id of every run goes
+                          IndexT* __restrict__ inverse_mapping,      // ... and where the id of every run goes
+                          const uint32_t* __restrict__ block_row_ids) {  // sample-blocked order: pair number -> row | bit
+  // (a template parameter, not a run-time flag: the registers of the read-modify-write would cost the
+  // reference-order kernel a wavefront per SIMD)
+  constexpr uint32_t shared_row_bit = kBlocked ? kSharedRowBit : 0u;
   using A = Arith<float>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane_x = threadIdx.x;
@@ -161,6 +176,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const int64_t block_begin = cs.block * block_len;
   if (block_begin >= nnz) return;  // the grid is rounded up to whole rounds of 8 workgroups
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * lanes + lane_x) * N;
+  const uint32_t id_mask = ~shared_row_bit;   // staged ids keep the bit (equal inside a run); addresses drop it
 
   // ---- LDS carve-up (must match ScatterStageBytes) ----
   // per segment: rows [segment_len + 2] = (lookup before, the segment's row ids, lookup after);
@@ -194,20 +210,78 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     // hold sample 0 without the bit: their lanes gather a valid row and never flush it.
     const int tid = seg * lanes + lane_x;
     const int threads = lanes * segments_per_block;
-    for (int e = tid; e < block_len; e += threads) {
-      const int64_t g = block_begin + e;
-      const int s = segment_shift >= 0 ? e >> segment_shift : e / segment_len;
-      const int i = e - s * segment_len;
-      int32_t r = -1;
-      uint32_t pk = 0;
-      if (g < nnz) {
-        r = static_cast<int32_t>(rows[g]);
-        const int32_t r_next = g + 1 < nnz ? static_cast<int32_t>(rows[g + 1]) : -1;
-        pk = static_cast<uint32_t>(static_cast<int32_t>(sample_ids[g])) | (r_next != r ? kRunEndBit : 0u);
-        if constexpr (kWeighted) st_w[s * w_stride + i] = weights[g];
+    // kStageBatch lookups per thread and round: all their loads are requested before the first one is used (the
+    // blocked order adds a dependent table lookup per lookup; one at a time, a thread's 8 lookups at C4 would pay
+    // 8 x 2 memory latencies before the walk can start)
+    constexpr int kStageBatch = 4;
+    for (int e0 = tid; e0 < block_len; e0 += threads * kStageBatch) {
+      int32_t r[kStageBatch], r_next[kStageBatch];
+      uint32_t sid[kStageBatch];
+      GradT wv[kStageBatch];
+#pragma unroll
+      for (int q = 0; q < kStageBatch; ++q) {
+        const int64_t g = block_begin + e0 + q * threads;
+        const bool in = e0 + q * threads < block_len && g < nnz;
+        r[q] = in ? static_cast<int32_t>(rows[g]) : -1;
+        r_next[q] = (in && g + 1 < nnz) ? static_cast<int32_t>(rows[g + 1]) : -1;
+        sid[q] = in ? static_cast<uint32_t>(static_cast<int32_t>(sample_ids[g])) : 0u;
+        if constexpr (kWeighted) wv[q] = in ? weights[g] : static_cast<GradT>(0);
       }
-      st_rows[s * row_stride + 1 + i] = r;
-      st_pk[s * pk_stride + i] = pk;
+      int32_t row[kStageBatch];
+#pragma unroll
+      for (int q = 0; q < kStageBatch; ++q) {
+        row[q] = r[q];
+        if (block_row_ids != nullptr && r[q] >= 0)   // sample-blocked order: pair number -> gradient row | kSharedRowBit
+          row[q] = static_cast<int32_t>(block_row_ids[r[q]]);
+      }
+#pragma unroll
+      for (int q = 0; q < kStageBatch; ++q) {
+        const int e = e0 + q * threads;
+        if (e < block_len) {
+          const int s = segment_shift >= 0 ? e >> segment_shift : e / segment_len;
+          const int i = e - s * segment_len;
+          uint32_t pk = 0;
+          if (r[q] >= 0) {
+            pk = sid[q] | (r_next[q] != r[q] ? kRunEndBit : 0u);
+            if constexpr (kBlocked) {   // (sample ids are < 2^30 in a blocked order)
+              if (static_cast<uint32_t>(row[q]) & shared_row_bit) pk |= kSharedRunBit;
+            }
+            if constexpr (kWeighted) st_w[s * w_stride + i] = wv[q];
+          }
+          st_rows[s * row_stride + 1 + i] = row[q];
+          st_pk[s * pk_stride + i] = pk;
+        }
+      }
+    }
+    if constexpr (kBlocked) {
+      // The rows that will be read and added to were written by another launch and come from HBM.  Touch this
+      // slice's lines of them now -- all requests of the workgroup in flight together, one wait -- so that the reads
+      // in the walk, which sit in the in-order return queue of the gathers, find them in L2.  Every thread looks at
+      // the lookups it staged itself (no barrier needed); lookups without such a row touch line 0 of the gradient.
+      uint32_t warmed = 0;
+      const int slice_bytes = lanes * N * static_cast<int>(sizeof(GradT));
+      const char* slice0 = reinterpret_cast<const char*>(grad_out + static_cast<int64_t>(cs.slice) * lanes * N);
+      for (int e0 = tid; e0 < block_len; e0 += threads * kStageBatch) {
+        const char* line[kStageBatch];
+#pragma unroll
+        for (int q = 0; q < kStageBatch; ++q) {
+          const int e = e0 + q * threads;
+          line[q] = slice0;
+          if (e < block_len) {
+            const int s = segment_shift >= 0 ? e >> segment_shift : e / segment_len;
+            const int i = e - s * segment_len;
+            const uint32_t pk = st_pk[s * pk_stride + i];
+            if ((pk & (kRunEndBit | kSharedRunBit)) == (kRunEndBit | kSharedRunBit))
+              line[q] = slice0 + static_cast<int64_t>(static_cast<uint32_t>(st_rows[s * row_stride + 1 + i]) & id_mask) *
+                                     (static_cast<int64_t>(width) * static_cast<int64_t>(sizeof(GradT)));
+          }
+        }
+        for (int b = 0; b < slice_bytes; b += 128) {
+#pragma unroll
+          for (int q = 0; q < kStageBatch; ++q) warmed |= *reinterpret_cast<const uint32_t*>(line[q] + b);
+        }
+      }
+      asm volatile("" ::"v"(warmed));   // (keeps the loads; the barrier below waits for them)
     }
     if (lane_x == 0) part_flags[seg] = 0;
     __syncthreads();
@@ -216,11 +290,15 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     if (lane_x == 0) {
       int32_t* seg_rows = st_rows + seg * row_stride;
       const int64_t before = block_begin - 1, after = block_begin + block_len;
+      auto row_at = [&](const int64_t g) {
+        const int32_t r = static_cast<int32_t>(rows[g]);
+        return block_row_ids != nullptr ? static_cast<int32_t>(block_row_ids[r]) : r;
+      };
       seg_rows[0] = seg > 0 ? st_rows[(seg - 1) * row_stride + segment_len]
-                            : ((before >= 0 && before < nnz) ? static_cast<int32_t>(rows[before]) : -1);
+                            : ((before >= 0 && before < nnz) ? row_at(before) : -1);
       seg_rows[segment_len + 1] = seg + 1 < segments_per_block
                                       ? st_rows[(seg + 1) * row_stride + 1]
-                                      : (after < nnz ? static_cast<int32_t>(rows[after]) : -1);
+                                      : (after < nnz ? row_at(after) : -1);
     }
   }
   __syncthreads();
@@ -233,7 +311,8 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     const int64_t seg_begin = block_begin + static_cast<int64_t>(seg) * segment_len;
     for (int i = lane_x; i < segment_len; i += lanes) {
       const int64_t g = seg_begin + i;
-      if (g < nnz && seg_rows[1 + i] != seg_rows[i]) inverse_mapping[seg_rows[1 + i]] = run_ids[g];
+      if (g < nnz && seg_rows[1 + i] != seg_rows[i])
+        inverse_mapping[static_cast<uint32_t>(seg_rows[1 + i]) & id_mask] = run_ids[g];
     }
   }
   const int seg_off = seg * segment_len;  // offset of this segment inside the block
@@ -292,8 +371,23 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     // rows in flight are held as raw dwords (one register tuple per lookup, re-used by the
     // request that replaces it), not as N separate elements
     typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
+    constexpr uint32_t kSampleMask = kBlocked ? ~(kRunEndBit | kSharedRunBit) : ~kRunEndBit;
     auto gather = [&](const uint32_t packed) {
-      return *reinterpret_cast<const raw_t*>(RowPtr(lane_src, static_cast<int64_t>(packed & ~kRunEndBit), width));
+      return *reinterpret_cast<const raw_t*>(RowPtr(lane_src, static_cast<int64_t>(packed & kSampleMask), width));
+    };
+    // Sample-blocked order: a run whose row an earlier block (an earlier launch) already stored is ADDED to it -- a
+    // read-modify-write, not an atomic (13.7 M dword atomics at C4 cost 0.1 ms; the 55 MB they touch are 10 us of
+    // traffic).  The old row is requested TOGETHER with the gather of the run's last lookup, kBackwardUnroll
+    // lookups ahead of its use, into a register tuple of its own per window slot: loads return in order, so it is
+    // there when that lookup is consumed and the window never drains for it (a read issued at the run's end and
+    // awaited at the next one made the compiler wait for vmcnt(1): 0.177 instead of 0.119 ms per block).
+    raw_t old[kBlocked ? K : 1];
+    auto request_old = [&](const uint32_t packed, const int pos, raw_t& into) {
+      if constexpr (kBlocked) {
+        if ((packed & (kRunEndBit | kSharedRunBit)) == (kRunEndBit | kSharedRunBit))
+          into = *reinterpret_cast<const raw_t*>(
+              RowPtr(lane_dst, static_cast<int64_t>(static_cast<uint32_t>(my_rows[pos]) & id_mask), width));
+      }
     };
 
     // kBackwardUnroll gathers stay in flight for the whole walk: the row of lookup i + K is
@@ -303,7 +397,10 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     uint32_t cur[K], nxt[K];
     fetch_ids(cur, 0);
 #pragma unroll
-    for (int u = 0; u < K; ++u) g[u] = gather(cur[u]);
+    for (int u = 0; u < K; ++u) {
+      g[u] = gather(cur[u]);
+      request_old(cur[u], u, old[kBlocked ? u : 0]);
+    }
     auto batch = [&](const int i, auto more_tag) {
       constexpr bool kMore = decltype(more_tag)::value;
       if constexpr (kMore) fetch_ids(nxt, i + K);
@@ -336,18 +433,27 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
           for (int j = 0; j < kPairs; ++j) acc[j] = acc[j] + f[j];
         }
         if (static_cast<int32_t>(cur[u]) < 0) {   // kRunEndBit: the run ends with this lookup
-          const int64_t row = WidenIndex(my_rows[i + u]);
+          const uint32_t flagged = static_cast<uint32_t>(my_rows[i + u]);
           if (first_pending) {
-            park_head(row);   // its first lookups are in earlier segments
+            park_head(static_cast<int64_t>(flagged));   // its first lookups are in earlier segments
           } else {
+            GradT* dst = const_cast<GradT*>(RowPtr(lane_dst, static_cast<int64_t>(flagged & id_mask), width));
             float a[N];
             unpair(a);
-            FlushStore<GradT, N>(const_cast<GradT*>(RowPtr(lane_dst, row, width)), a);
+            if constexpr (kBlocked) {
+              if (flagged & shared_row_bit) {   // an earlier block stored this row: add what it holds
+                const Pack<GradT, N> was = __builtin_bit_cast(Pack<GradT, N>, old[u]);
+#pragma unroll
+                for (int e = 0; e < N; ++e) a[e] = A::add(static_cast<float>(was.v[e]), a[e]);
+              }
+            }
+            FlushStore<GradT, N>(dst, a);
           }
           first_pending = false;
 #pragma unroll
           for (int j = 0; j < kPairs; ++j) asm("v_mov_b64 %0, 0" : "=v"(acc[j]));   // one move per pair
         }
+        if constexpr (kBlocked && kMore) request_old(nxt[u], i + K + u, old[u]);   // (the slot is free again)
       }
       if constexpr (kMore) {
 #pragma unroll
@@ -360,7 +466,8 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     // The segment's last run goes on into the next segment (kPartWhole: it also came in): its
     // partial stays in registers until every walk of the workgroup is over, then it is parked on
     // top of the staged ids, which nobody reads any more.
-    if (tail_shared) note(1, WidenIndex(my_rows[segment_len - 1]), kPartTail | (first_pending ? kPartWhole : 0));
+    if (tail_shared)
+      note(1, static_cast<int64_t>(static_cast<uint32_t>(my_rows[segment_len - 1])), kPartTail | (first_pending ? kPartWhole : 0));
     __syncthreads();
     if (tail_shared) {
       float a[N];
@@ -392,8 +499,11 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     const bool from_previous_block = k < 0;
     for (int m = from_previous_block ? 0 : k; m < seg; ++m) add_part(sum, m, 1);
     add_part(sum, seg, 0);
-    GradT* dst = lane_dst + part_row[seg * 2 + 0] * width;
-    if (from_previous_block) FlushAtomic<N>(dst, sum);
+    const uint32_t flagged = static_cast<uint32_t>(part_row[seg * 2 + 0]);
+    GradT* dst = lane_dst + static_cast<int64_t>(flagged & id_mask) * width;
+    // (sample-blocked order: an earlier block stored this row -> add to it.  An atomic, not a read-modify-write: this
+    // is the end of the workgroup, a read would be waited for in full, and there is at most one chain per segment)
+    if (from_previous_block || (flagged & shared_row_bit)) FlushAtomic<N>(dst, sum);
     else FlushStore<GradT, N>(dst, sum);
   }
   if ((flags & kPartTail) && seg == last_seg) {
@@ -404,7 +514,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     int k = seg;
     while (k >= 0 && (part_flags[k] & kPartWhole)) --k;
     for (int m = k < 0 ? 0 : k; m <= seg; ++m) add_part(sum, m, 1);
-    FlushAtomic<N>(lane_dst + part_row[seg * 2 + 1] * width, sum);
+    FlushAtomic<N>(lane_dst + static_cast<int64_t>(static_cast<uint32_t>(part_row[seg * 2 + 1]) & id_mask) * width, sum);
   }
 }
 
@@ -414,28 +524,48 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 //! lookup of every workgroup -- the only ones that can receive atomics -- and (b) rows beyond
 //! the last id, should the caller have over-allocated, must be zero beforehand.  That is a few
 //! MB instead of a memset of the whole buffer (293 MB, ~45 us, at the north-star shape).
-//!   grid = num_blocks + ceil(num_rows / kZeroTailRowsPerBlock), block = 256
+//!   grid = sample_blocks * blocks_per_sample_block + ceil(num_rows / kZeroTailRowsPerBlock), block = 256
+//! Sample-blocked order (sample_blocks > 1): the COO is `sample_blocks` arrays of `sample_block_len` lookups that
+//! are scattered one after the other, each cut into workgroup ranges from its own start; ONE call zeroes the edge
+//! rows of all of them up front (a row that block 0 stores and block 1 adds to must not be zeroed in between), and
+//! the last id is the largest of the blocks' last ids.  A row with kSharedRowBit that an EARLIER block never wrote
+//! does not exist, so zeroing it here and letting block 0 store it afterwards is always right.
 constexpr int kZeroTailRowsPerBlock = 64;
 
 template <typename GradT, typename IndexT>
 __global__ void __launch_bounds__(256)
 ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, const int block_len,
-                            const int64_t num_blocks, const int width, const int64_t num_rows,
-                            GradT* __restrict__ grad_out) {
+                            const int64_t blocks_per_sample_block, const int64_t sample_block_len,
+                            const int sample_blocks, const int width, const int64_t num_rows,
+                            GradT* __restrict__ grad_out, const uint32_t* __restrict__ block_row_ids) {
+  // sample-blocked order: `rows` holds pair numbers, block_row_ids[pair] the gradient row | kSharedRowBit
+  auto row_of = [&](const int64_t g) -> int64_t {
+    const uint32_t r = static_cast<uint32_t>(rows[g]);
+    return static_cast<int64_t>(block_row_ids != nullptr ? (block_row_ids[r] & ~kSharedRowBit) : r);
+  };
   const int64_t b = blockIdx.x;
+  const int64_t num_blocks = blocks_per_sample_block * sample_blocks;
   if (b < num_blocks) {
-    const int64_t first = b * block_len;
-    if (first >= nnz) return;
-    const int64_t last = (first + block_len < nnz ? first + block_len : nnz) - 1;
-    const int64_t r0 = static_cast<int64_t>(rows[first]);
-    const int64_t r1 = static_cast<int64_t>(rows[last]);
+    const int64_t p = b / blocks_per_sample_block;
+    const int64_t origin = p * sample_block_len;
+    const int64_t end = origin + sample_block_len < nnz ? origin + sample_block_len : nnz;
+    const int64_t first = origin + (b - p * blocks_per_sample_block) * block_len;
+    if (first >= end) return;
+    const int64_t last = (first + block_len < end ? first + block_len : end) - 1;
+    const int64_t r0 = row_of(first);
+    const int64_t r1 = row_of(last);
     for (int c = threadIdx.x; c < width; c += blockDim.x) {
       grad_out[r0 * width + c] = static_cast<GradT>(0);
       grad_out[r1 * width + c] = static_cast<GradT>(0);
     }
     return;
   }
-  const int64_t last_id = static_cast<int64_t>(rows[nnz - 1]);
+  int64_t last_id = 0;
+  for (int p = 0; p < sample_blocks; ++p) {
+    const int64_t end = (p + 1) * sample_block_len < nnz ? (p + 1) * sample_block_len : nnz;
+    const int64_t id = row_of(end - 1);
+    last_id = id > last_id ? id : last_id;
+  }
   const int64_t begin = last_id + 1 + (b - num_blocks) * kZeroTailRowsPerBlock;
   const int64_t end = begin + kZeroTailRowsPerBlock < num_rows ? begin + kZeroTailRowsPerBlock : num_rows;
   for (int64_t i = begin * width + threadIdx.x; i < end * width; i += blockDim.x)

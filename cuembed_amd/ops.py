@@ -187,7 +187,8 @@ def get_backward_tuning():
 
 def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, transpose_sample_ids,
                        transpose_remapped_indices=None, transpose_weights=None,
-                       skip_grad_init=False, grad_embedding=None, inverse_mapping=None):
+                       skip_grad_init=False, grad_embedding=None, inverse_mapping=None, sample_blocks=1,
+                       block_row_ids=None):
     """Scatter-add grad_y rows into the table gradient from index-sorted COO lookups.
 
     Full gradient: transpose_remapped_indices=None, num_grad_embedding_rows = table rows.
@@ -197,8 +198,17 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
 
     Extension (compressed only): num_grad_embedding_rows=None = "num_unique is only known on the device"
     (it is transpose_remapped_indices[-1] + 1).  grad_embedding and inverse_mapping must then be given
-    with at least that many rows (min(nnz, table rows) always suffices); rows past the last id are
-    left untouched and no host read-back is needed before the call."""
+    with at least that many rows; rows past the last id are left untouched and no host read-back is
+    needed before the call.  Capacity that always suffices: nnz; min(nnz, table rows) when the ids
+    are those of a fully sorted COO or of compute_compressed_grad_indices_blocked (one id per distinct
+    table row); min(nnz, sample_blocks * table rows) for the UNCOALESCED gradient that
+    compute_compressed_grad_indices yields on a sample-blocked transpose (one id per (block, row)).
+
+    Extension (compressed only): sample_blocks > 1 = the COO is transpose(..., sample_blocks=...) and
+    (transpose_remapped_indices, block_row_ids) come from compute_compressed_grad_indices_blocked(...,
+    sample_blocks): the blocks are scattered one after the other (every L2 gathers from 1 / sample_blocks of
+    grad_y at a time) and the result has the reference's layout: num_unique ascending rows, the fully sorted
+    order's inverse_mapping."""
     _check_dev("grad_y", grad_y)
     dev = grad_y.device
     if grad_y.dim() != 2:
@@ -250,11 +260,23 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
                 raise TypeError("inverse_mapping must have the index dtype")
     else:
         inverse_mapping = None
+    if sample_blocks > 1 and not compressed:
+        raise ValueError("sample_blocks > 1 is for the compressed gradient only")
+    if _check_coalesced_blocks(nnz, sample_blocks) > 1:
+        if block_row_ids is None:
+            raise ValueError("a sample-blocked compressed gradient needs block_row_ids "
+                             "(compute_compressed_grad_indices_blocked)")
+        _check_dev("block_row_ids", block_row_ids, dev)
+        if block_row_ids.dtype != torch.int32:
+            raise TypeError("block_row_ids must be int32 (uint32 bit patterns)")
+    else:
+        block_row_ids = None
     with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
-        _lib.lib().cuembed_embedding_backward(
+        _lib.lib().cuembed_embedding_backward_blocked(
             _ptr(grad_y), et, width, -1 if unknown_rows else num_grad_embedding_rows, nnz, _ptr(transpose_indices),
             _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
-            int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), _stream(grad_y))
+            int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), int(sample_blocks),
+            _ptr(block_row_ids), _stream(grad_y))
     return grad_embedding, inverse_mapping
 
 
@@ -387,6 +409,72 @@ def compute_compressed_grad_indices(indices, workspace=None):
                                                                _ptr(workspace), ctypes.byref(lwork),
                                                                _stream(indices))
     return out
+
+
+SHARED_ROW_BIT = 1 << 30   # detail::kSharedRowBit of compute_compressed_grad_indices_blocked
+MAX_COALESCED_BLOCKS = 8    # detail::kMaxCoalescedBlocks
+
+
+def _check_coalesced_blocks(nnz, sample_blocks):
+    """The number of blocks the library cuts nnz lookups into.  The C++ entry points abort on what is rejected
+    here; raise instead."""
+    if sample_blocks <= 1 or nnz <= 0:
+        return 1
+    length = transpose_sample_block_length(nnz, sample_blocks)
+    blocks = -(-nnz // length)
+    if blocks > MAX_COALESCED_BLOCKS:
+        raise ValueError("the coalesced compressed gradient supports at most %d sample blocks" % MAX_COALESCED_BLOCKS)
+    if blocks > 1 and nnz >= (1 << 30):
+        raise ValueError("a sample-blocked coalesced gradient needs nnz < 2^30")
+    return blocks
+
+
+def compressed_grad_blocked_workspace_bytes(nnz, index_dtype, sample_blocks):
+    lwork = ctypes.c_size_t(0)
+    _lib.lib().cuembed_compute_compressed_grad_indices_blocked(None, nnz, _INDEX[index_dtype], int(sample_blocks), None,
+                                                               None, None, None, ctypes.byref(lwork), None)
+    return lwork.value
+
+
+def compute_compressed_grad_indices_blocked(indices, sample_blocks, workspace=None, num_unique=None,
+                                            block_row_ids=None):
+    """compute_compressed_grad_indices for the output of transpose(..., sample_blocks=...) (extension).
+    Returns (remapped, block_row_ids, num_unique) -- what embedding_backward(..., sample_blocks=...) consumes:
+    remapped[i] numbers the (block, table row) pair of lookup i; block_row_ids[pair] (int32 tensor holding uint32
+    bit patterns, nnz entries of room) is the id the reference's fully sorted order assigns to that table row (its
+    rank among all distinct rows of the batch), with SHARED_ROW_BIT set when the row also occurs in an earlier
+    block; num_unique is a one-element int32 device tensor.  With one block (sample_blocks <= 1 or at most 131,072
+    lookups) remapped is compute_compressed_grad_indices' and block_row_ids is the identity."""
+    _check_dev("indices", indices)
+    it = _index_code("indices", indices)
+    nnz = indices.numel()
+    blocks = _check_coalesced_blocks(nnz, sample_blocks)
+    out = torch.empty_like(indices)
+    need = compressed_grad_blocked_workspace_bytes(nnz, indices.dtype, sample_blocks)
+    if workspace is None:
+        workspace = torch.empty((max(need, 1),), dtype=torch.uint8, device=indices.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("workspace too small: need %d bytes" % need)
+    if num_unique is None:
+        num_unique = torch.zeros((1,), dtype=torch.int32, device=indices.device)
+    else:
+        _check_dev("num_unique", num_unique, indices.device)
+        if num_unique.dtype != torch.int32 or num_unique.numel() < 1:
+            raise ValueError("num_unique must be an int32 tensor with one element")
+    if block_row_ids is None:
+        block_row_ids = (torch.empty((max(nnz, 1),), dtype=torch.int32, device=indices.device) if blocks > 1 else
+                         torch.arange(max(nnz, 1), dtype=torch.int32, device=indices.device))
+    else:
+        _check_dev("block_row_ids", block_row_ids, indices.device)
+        if block_row_ids.dtype != torch.int32 or block_row_ids.numel() < nnz:
+            raise ValueError("block_row_ids must be an int32 tensor with nnz entries")
+    lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
+    if nnz > 0:
+        with torch.cuda.device(indices.device):
+            _lib.lib().cuembed_compute_compressed_grad_indices_blocked(
+                _ptr(indices), nnz, it, int(sample_blocks), _ptr(out), _ptr(block_row_ids), _ptr(num_unique),
+                _ptr(workspace), ctypes.byref(lwork), _stream(indices))
+    return out, block_row_ids, num_unique
 
 
 def extract_row_ids_from_fixed(batch_size, num_hots, dtype=torch.int32, device="cuda"):

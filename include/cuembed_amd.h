@@ -245,6 +245,35 @@ int64_t cuembed_transpose_sample_block_length(int64_t nnz, int sample_blocks);
 void cuembed_compute_compressed_grad_indices(const void* indices, int nnz, int index_type,
                                              void* remapped_indices, char* work, size_t* lwork,
                                              cuembed_stream_t stream);
+/* Extension (cuembed::ComputeCompressedGradIndicesBlocked + cuembed::EmbeddingBackward(..., sample_blocks,
+ * block_row_ids)): the REFERENCE's compressed gradient -- num_unique ascending rows, the inverse_mapping of the
+ * fully sorted order (embedding_lookup.cuh:423-483, index_transforms.cuh:278-323) -- computed from a
+ * sample-blocked order, so that the backward gathers grad_y block by block (see cuembed_transpose_sample_blocks).
+ *   cuembed_compute_compressed_grad_indices_blocked: `indices` = transpose_rows of a transpose with the SAME nnz
+ *     and sample_blocks.  remapped_indices[i] = number of the (block, table row) pair of lookup i (ids count up
+ *     through the array; a new one where the index changes or a block begins).  block_row_ids[pair] (room for nnz
+ *     uint32 always suffices) = rank of that table row among all distinct rows of the array (= the id the fully
+ *     sorted order assigns), with bit 30 set when the row also occurs in an earlier block.  *num_unique (device
+ *     word, may be NULL) = number of distinct rows.  At most 8 blocks, nnz < 2^30.  With one block (sample_blocks
+ *     <= 1 or nnz <= 131072) remapped_indices is cuembed_compute_compressed_grad_indices' and block_row_ids is
+ *     left alone.  Two-phase workspace query.
+ *   cuembed_embedding_backward_blocked: as cuembed_embedding_backward with a compressed gradient, for that COO,
+ *     those remapped indices and that table: one stream-ordered launch per block; a run whose row an earlier block
+ *     already stored is added to it (read-modify-write; float atomic when the run crosses workgroups).
+ *     num_grad_embedding_rows = num_unique, or negative when it is only known on the device (buffers of
+ *     min(nnz, table rows) rows then suffice).  fp32: the sum of a table row is taken block by block; fp16 /
+ *     bf16: one rounding per block (ARITHMETIC note above applies per block). */
+void cuembed_compute_compressed_grad_indices_blocked(const void* indices, int nnz, int index_type,
+                                                     int sample_blocks, void* remapped_indices,
+                                                     uint32_t* block_row_ids, uint32_t* num_unique,
+                                                     char* work, size_t* lwork, cuembed_stream_t stream);
+void cuembed_embedding_backward_blocked(const void* grad_y, int elem_type, int embed_width,
+                                        int num_grad_embedding_rows, int nnz,
+                                        const void* transpose_indices, const void* transpose_sample_ids,
+                                        const void* transpose_remapped_indices, int index_type,
+                                        const void* transpose_weights, int skip_grad_init,
+                                        void* grad_embedding, void* inverse_mapping, int sample_blocks,
+                                        const uint32_t* block_row_ids, cuembed_stream_t stream);
 void cuembed_extract_row_ids_from_fixed(int batch_size, int num_hots, int index_type,
                                         void* row_ids, cuembed_stream_t stream);
 void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int batch_size,
