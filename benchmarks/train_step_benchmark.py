@@ -5,10 +5,11 @@ replicated, gradient combined over RCCL (xGMI).  One process per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port 29500 benchmarks/train_step_benchmark.py --exchange sparse
 
-One step on every rank = EmbeddingForward on its 65,536-sample shard, TransposeFixedHotness (row ids
-derived inside the first radix pass, index_bits from the table size; --reference_api runs
-ExtractRowIdsFromFixed + Transpose over all key bits instead, i.e. only what the reference's API
-offers), ComputeCompressedGradIndices, EmbeddingBackward into a compressed gradient, then the exchange:
+One step on every rank (benchmarks/c5_train_step.py, shared with bench.py's c5_train_step leg) =
+EmbeddingForward on its 65,536-sample shard, TransposeFixedHotness (row ids derived inside the first radix
+pass, index_bits from the table size; --reference_api runs ExtractRowIdsFromFixed + Transpose over all key bits
+instead, i.e. only what the reference's API offers), ComputeCompressedGradIndices[Blocked], EmbeddingBackward
+into a compressed gradient, then the exchange:
   sparse : all-gather of the compressed rows + local merge (~293 MB per rank at this shape)
   dense  : scatter into the dense table gradient + RCCL all-reduce (5.12 GB per rank)
   none   : no exchange (upper bound / single GPU)
@@ -20,6 +21,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -33,10 +35,13 @@ def main():
     p.add_argument("--alpha", type=float, default=1.15)
     p.add_argument("--exchange", default="sparse", choices=["sparse", "dense", "none"])
     p.add_argument("--sparse_algorithm", default="auto", choices=["auto", "allgather", "owner"])
+    p.add_argument("--order", default="blocked_uncoalesced", choices=["reference", "blocked", "blocked_uncoalesced"],
+                   help="order of the transposed COO (benchmarks/c5_train_step.py): reference = fully sorted; blocked = "
+                        "sample blocks + the reference's compressed gradient (ComputeCompressedGradIndicesBlocked); "
+                        "blocked_uncoalesced = sample blocks, one gradient row per (block, table row) -- the fastest, and "
+                        "the sparse exchange merges by id anyway.  --reference_api and --exchange dense use reference")
     p.add_argument("--sample_blocks", default="auto",
-                   help="transpose the batch in this many blocks of samples (extension: an uncoalesced compressed gradient, "
-                        "every L2 gathers from 1 / blocks of grad_y at a time); auto = cuembed_recommended_sample_blocks, "
-                        "1 = the reference's fully sorted order.  Ignored with --reference_api and with --exchange dense")
+                   help="blocks of the blocked orders; auto = cuembed_recommended_sample_blocks")
     p.add_argument("--reference_api", action="store_true",
                    help="index work through the reference's entry points only (row-id kernel + unbounded Transpose)")
     a = p.parse_args()
@@ -46,6 +51,7 @@ def main():
     import cuembed_amd as ce
     from cuembed_amd import distributed as D
     from cuembed_amd import harness
+    from c5_train_step import TrainStep
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -63,47 +69,32 @@ def main():
     use_dist = dist.is_initialized()
     B, H, W = a.batch, a.hotness, a.width
     table = torch.empty((a.rows, W), dtype=torch.float16, device=dev).uniform_(-1, 1)
-    idx_all = harness.generate_indices(a.rows, world * B, H, alpha=a.alpha)
-    idx = torch.from_numpy(np.ascontiguousarray(idx_all.reshape(world, B * H)[rank])).to(dev)
+    idx = torch.from_numpy(shard_of_stream(np, harness, dist if use_dist else None, a, world, rank, local)).to(dev)
     gy = torch.from_numpy(harness.allocate_grad_y(B * W, np.float16).reshape(B, W)).to(dev)
-    out = torch.empty((B, W), dtype=torch.float16, device=dev)
-    nnz = B * H
-    work = torch.empty(max(ce.transpose_workspace_bytes(nnz, torch.int32), 1), dtype=torch.uint8, device=dev)
-    dense = torch.zeros((a.rows, W), dtype=torch.float16, device=dev) if a.exchange == "dense" else None
-    # compressed gradient: buffers for the largest possible number of unique rows, allocated once like a trainer
-    # would; num_unique stays on the device (remap[-1] + 1) -- no host read-back inside the step
-    cap = min(nnz, a.rows)
-    comp_rows = torch.empty((cap, W), dtype=torch.float16, device=dev) if a.exchange != "dense" else None
-    comp_inv = torch.empty((cap,), dtype=torch.int32, device=dev) if a.exchange != "dense" else None
-    blocks = 1
-    if not a.reference_api and a.exchange != "dense":
-        blocks = ce.recommended_sample_blocks(torch.float16, W, B, nnz) if a.sample_blocks == "auto" else int(a.sample_blocks)
+    order = a.order
+    if a.exchange == "dense" or a.reference_api:
+        order = "reference"
+    blocks = None if a.sample_blocks == "auto" else int(a.sample_blocks)
+    ts = TrainStep(ce, table, idx, gy, B, H, order=order, sample_blocks=blocks, dense=a.exchange == "dense")
+    if a.reference_api:            # only what the reference's API offers: row-id kernel + Transpose over all key bits
+        def reference_index_work():
+            sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, dev)
+            ts.t_idx, ts.t_sid, _ = ce.transpose(sid, idx, workspace=ts.work)
+            ts.remap = ce.compute_compressed_grad_indices(ts.t_idx)
+            ts.count = ts.remap[-1:] + 1
+        ts.index_work = reference_index_work
     names = ["forward", "transpose", "backward", "exchange"]
 
     def step(ev):
         ev[0].record()
-        ce.embedding_forward(table, idx, num_hots=H, out=out)
+        ts.forward()
         ev[1].record()
-        if a.reference_api:
-            sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, dev)
-            t_idx, t_sid, _ = ce.transpose(sid, idx, workspace=work)
-        else:
-            t_idx, t_sid, _ = ce.transpose_fixed_hotness(idx, B, H, workspace=work, num_categories=a.rows,
-                                                         sample_blocks=blocks)
-        remap = ce.compute_compressed_grad_indices(t_idx)
+        ts.index_work()
         ev[2].record()
-        if a.exchange == "dense":
-            ce.embedding_backward(gy, a.rows, t_idx, t_sid, skip_grad_init=False, grad_embedding=dense)
-            ev[3].record()
-            if use_dist:
-                D.allreduce_dense_grad(dense)
-        else:
-            rows, inv = ce.embedding_backward(gy, None, t_idx, t_sid, remap, grad_embedding=comp_rows,
-                                              inverse_mapping=comp_inv)
-            ev[3].record()
-            if a.exchange == "sparse" and use_dist:
-                D.allreduce_sparse_grad(rows, inv, a.rows, algorithm=a.sparse_algorithm, num_unique=remap[-1:] + 1,
-                                        coalesced=blocks == 1)
+        ts.backward()
+        ev[3].record()
+        if use_dist and a.exchange != "none":
+            ts.exchange(D, algorithm=a.sparse_algorithm)
         ev[4].record()
 
     def sync():
@@ -129,13 +120,39 @@ def main():
         print(json.dumps({"workload": "fp16 fwd+bwd, %dx%d table, batch %d per GPU x %d GPUs, hotness %d, alpha %g"
                                       % (a.rows, W, B, world, H, a.alpha),
                           "exchange": a.exchange, "index_path": "reference_api" if a.reference_api else "fixed_hotness_bounded",
-                          "sample_blocks": blocks, "backend": dist.get_backend() if use_dist else None,
+                          "order": ts.order, "sample_blocks": ts.blocks, "backend": dist.get_backend() if use_dist else None,
                           "ranks_share_gpus": world > ngpu,
                           "n_gpus": world, "ms_per_step": round(ms, 4),
                           "samples_per_s": round(world * B / (ms * 1e-3)),
                           "breakdown_ms": {k: round(v, 4) for k, v in parts.items()}}), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def shard_of_stream(np, harness, dist, a, world, rank, local):
+    """This rank's shard of ONE generator stream of world x batch samples.  The stream cannot be skipped ahead
+    (rejection sampling), so it is walked once per node: local rank 0 walks it and leaves it in /dev/shm, the others
+    read their shard (bench.py does the same); every rank meets before the file goes."""
+    B, H = a.batch, a.hotness
+    if world == 1:
+        return harness.generate_indices(a.rows, B, H, alpha=a.alpha)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(base, "cuembed_train_idx_%d_%s.npy" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    if local == 0:
+        tmp = path + ".tmp.%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            np.save(f, harness.generate_indices(a.rows, world * B, H, alpha=a.alpha))
+        os.replace(tmp, path)
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > 900:
+            raise SystemExit("train_step_benchmark.py: index stream %s did not appear" % path)
+        time.sleep(0.05)
+    mine = np.ascontiguousarray(np.load(path, mmap_mode="r").reshape(world, B * H)[rank])
+    dist.barrier()
+    if local == 0 and os.path.exists(path):
+        os.remove(path)
+    return mine
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBack
                   embedding_weight_grad,
                   extract_row_ids_for_concat, extract_row_ids_from_csr,
                   extract_row_ids_from_fixed, forward_launch_shape, get_forward_reduction_order,
-                  set_forward_reduction_order, transpose, transpose_fixed_hotness,
+                  set_forward_reduction_order, set_forward_row_load_policy, get_forward_row_load_policy, transpose, transpose_fixed_hotness,
                   transpose_workspace_bytes)
 
 __version__ = "0.1.0"

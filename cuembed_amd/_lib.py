@@ -23,6 +23,13 @@ class CuembedLibraryError(RuntimeError):
 def _declare(L):
     L.cuembed_embedding_forward.restype = None
     L.cuembed_embedding_forward.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _VP]
+    L.cuembed_embedding_forward_with_options.restype = None
+    L.cuembed_embedding_forward_with_options.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I,
+                                                         _VP]
+    L.cuembed_set_forward_row_load_policy.restype = None
+    L.cuembed_set_forward_row_load_policy.argtypes = [_I]
+    L.cuembed_get_forward_row_load_policy.restype = _I
+    L.cuembed_get_forward_row_load_policy.argtypes = []
     L.cuembed_embedding_backward.restype = None
     L.cuembed_embedding_backward.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP]
     L.cuembed_set_backward_tuning.restype = None

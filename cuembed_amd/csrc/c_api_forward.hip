@@ -12,7 +12,12 @@ namespace {
 template <typename ElemT, typename IndexT, typename OffsetT>
 void Forward(const void* params, int embed_width, const IndexT* indices, const OffsetT* offsets,
              const void* weights, int batch_size, int num_hots, int mode, int fp16_math,
-             void* ret, cuembed_stream_t stream) {
+             void* ret, cuembed_stream_t stream, int reduction_order = -1, int row_load_policy = -1) {
+  // per-call options (cuembed_embedding_forward_with_options); < 0 = the process-wide default
+  cuembed::ForwardOptions options = cuembed::DefaultForwardOptions();
+  CUEMBED_ASSERT(reduction_order <= 1 && row_load_policy <= 1);
+  if (reduction_order >= 0) options.reduction_order = static_cast<cuembed::ReductionOrder>(reduction_order);
+  if (row_load_policy >= 0) options.row_loads = static_cast<cuembed::RowLoadPolicy>(row_load_policy);
   CUEMBED_ASSERT(mode == CUEMBED_SUM || mode == CUEMBED_MEAN || mode == CUEMBED_CONCAT);
   const CombineMode m = mode == CUEMBED_SUM    ? CombineMode::kSum
                         : mode == CUEMBED_MEAN ? CombineMode::kMean
@@ -22,10 +27,10 @@ void Forward(const void* params, int embed_width, const IndexT* indices, const O
   ElemT* r = static_cast<ElemT*>(ret);
   if (fp16_math)
     cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, true>(
-        p, embed_width, indices, offsets, w, batch_size, num_hots, m, r, Stream(stream));
+        p, embed_width, indices, offsets, w, batch_size, num_hots, m, r, Stream(stream), options);
   else
     cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, false>(
-        p, embed_width, indices, offsets, w, batch_size, num_hots, m, r, Stream(stream));
+        p, embed_width, indices, offsets, w, batch_size, num_hots, m, r, Stream(stream), options);
 }
 }  // namespace
 
@@ -58,10 +63,20 @@ void cuembed_embedding_forward(const void* params, int elem_type, int embed_widt
                                int offset_type, const void* weights, int batch_size,
                                int num_hots, int mode, int fp16_math, void* ret,
                                cuembed_stream_t stream) {
+  cuembed_embedding_forward_with_options(params, elem_type, embed_width, indices, index_type, offsets, offset_type,
+                                         weights, batch_size, num_hots, mode, fp16_math, ret, -1, -1, stream);
+}
+
+void cuembed_embedding_forward_with_options(const void* params, int elem_type, int embed_width,
+                                            const void* indices, int index_type, const void* offsets,
+                                            int offset_type, const void* weights, int batch_size,
+                                            int num_hots, int mode, int fp16_math, void* ret,
+                                            int reduction_order, int row_load_policy,
+                                            cuembed_stream_t stream) {
 #define FWD(E, I, O)                                                                          \
   Forward<E, I, O>(params, embed_width, static_cast<const I*>(indices),                       \
                    static_cast<const O*>(offsets), weights, batch_size, num_hots, mode,       \
-                   fp16_math, ret, stream)
+                   fp16_math, ret, stream, reduction_order, row_load_policy)
   const int key = (elem_type << 2) | (index_type << 1) | (offsets ? offset_type : 0);
   switch (key) {
     case 0: FWD(float, int32_t, int32_t); break;
@@ -144,6 +159,13 @@ void cuembed_set_forward_reduction_order(int order) {
 }
 int cuembed_get_forward_reduction_order(void) {
   return static_cast<int>(cuembed::GetForwardReductionOrder());
+}
+void cuembed_set_forward_row_load_policy(int policy) {
+  CUEMBED_ASSERT(policy == 0 || policy == 1);
+  cuembed::SetForwardRowLoadPolicy(static_cast<cuembed::RowLoadPolicy>(policy));
+}
+int cuembed_get_forward_row_load_policy(void) {
+  return static_cast<int>(cuembed::GetForwardRowLoadPolicy());
 }
 
 int cuembed_peek_last_error(void) { return static_cast<int>(hipPeekAtLastError()); }

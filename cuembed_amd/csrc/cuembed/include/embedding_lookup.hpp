@@ -35,14 +35,41 @@ namespace cuembed {
 //!     sample may be split over several wavefronts and the partial rows combined through
 //!     LDS (GatherReduceSplitKernel).  Same result up to fp rounding (<= 1e-3 relative in
 //!     fp32, 1e-2 in fp16), several times faster for batches of a few thousand samples.
-//! Process-wide, read at every call; also settable with CUEMBED_FORWARD_ORDER=split.
 enum class ReductionOrder { kSequential = 0, kAllowSplit = 1 };
 
+//! How EmbeddingForward (sum / mean) loads table rows.  Never changes a result.
+//!   kDefault: ordinary loads -- rows stay in L2 and the Infinity Cache as long as the hardware
+//!     keeps them; right whenever some rows are looked up more than once (any skewed index
+//!     distribution: at C2, alpha = 1.15, 86 % of the lookups are repeats).
+//!   kStreaming: non-temporal loads -- for batches in which (nearly) every lookup hits a different
+//!     row (uniform indices over a table far larger than the caches): the kernel is then bound by
+//!     HBM and rows that will not be re-used no longer pass through the L2's replacement
+//!     (C2 shape, alpha = 0: 0.379 -> 0.355 ms).  With re-use it is much SLOWER (alpha = 1.15:
+//!     0.136 -> 0.222 ms); the launcher cannot see the distribution, so it is the caller's choice.
+//! (Extension: the reference has no such knob, embedding_lookup_kernels.cuh:34-77.)
+enum class RowLoadPolicy { kDefault = 0, kStreaming = 1 };
+
+//! Per-call options of EmbeddingForward (the overload that takes them keeps NO state anywhere).
+struct ForwardOptions {
+  ReductionOrder reduction_order = ReductionOrder::kSequential;
+  RowLoadPolicy row_loads = RowLoadPolicy::kDefault;
+};
+
 namespace detail {
+//! Process-wide DEFAULTS for callers of the reference signature, which has no room for options
+//! (initial values from CUEMBED_FORWARD_ORDER=split / CUEMBED_FORWARD_ROW_LOADS=streaming, read once).
+//! Code that shares a process with other users of the library should pass ForwardOptions instead.
 inline std::atomic<int>& ForwardOrderCell() {
   static std::atomic<int> cell{[] {
     const char* env = std::getenv("CUEMBED_FORWARD_ORDER");
     return (env != nullptr && std::strcmp(env, "split") == 0) ? 1 : 0;
+  }()};
+  return cell;
+}
+inline std::atomic<int>& ForwardRowLoadCell() {
+  static std::atomic<int> cell{[] {
+    const char* env = std::getenv("CUEMBED_FORWARD_ROW_LOADS");
+    return (env != nullptr && std::strcmp(env, "streaming") == 0) ? 1 : 0;
   }()};
   return cell;
 }
@@ -53,6 +80,19 @@ inline void SetForwardReductionOrder(ReductionOrder order) {
 }
 inline ReductionOrder GetForwardReductionOrder() {
   return static_cast<ReductionOrder>(detail::ForwardOrderCell().load(std::memory_order_relaxed));
+}
+inline void SetForwardRowLoadPolicy(RowLoadPolicy policy) {
+  detail::ForwardRowLoadCell().store(static_cast<int>(policy), std::memory_order_relaxed);
+}
+inline RowLoadPolicy GetForwardRowLoadPolicy() {
+  return static_cast<RowLoadPolicy>(detail::ForwardRowLoadCell().load(std::memory_order_relaxed));
+}
+//! The process-wide defaults as per-call options.
+inline ForwardOptions DefaultForwardOptions() {
+  ForwardOptions o;
+  o.reduction_order = GetForwardReductionOrder();
+  o.row_loads = GetForwardRowLoadPolicy();
+  return o;
 }
 
 namespace detail {
@@ -137,11 +177,12 @@ template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int 
 inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indices,
                                const OffsetT* offsets, const ElemT* weights, int batch,
                                int num_hots, bool is_mean, ElemT* out, const ForwardLaunch& f,
-                               hipStream_t stream) {
+                               hipStream_t stream, const ForwardOptions& options) {
   const bool weighted = weights != nullptr;
+  const bool stream_rows = options.row_loads == RowLoadPolicy::kStreaming;
   const int lanes = f.split.lanes_per_row;
   const bool lanes_fit_waves = (lanes <= 64 && 64 % lanes == 0) || lanes == 128;
-  if (GetForwardReductionOrder() == ReductionOrder::kAllowSplit && lanes_fit_waves &&
+  if (options.reduction_order == ReductionOrder::kAllowSplit && lanes_fit_waves &&
       static_cast<int64_t>(batch) * lanes / 64 < kSplitBelowWaves &&
       (offsets != nullptr || num_hots >= 8)) {
     const dim3 sblock(lanes, kSplitBlockThreads / lanes, 1);
@@ -159,7 +200,7 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
 #define CUEMBED_LAUNCH_GR(W, SRC)                                                         \
   GatherReduceKernel<ElemT, AccT, IndexT, OffsetT, N, W, SRC>                             \
       <<<grid, block, f.stage_bytes, stream>>>(table, width, batch, indices, offsets,     \
-                                               num_hots, weights, is_mean, out, 1)
+                                               num_hots, weights, is_mean, out, 1, stream_rows)
   if (f.staged) {
     if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kLdsStaged);
     else CUEMBED_LAUNCH_GR(false, IndexSource::kLdsStaged);
@@ -207,6 +248,8 @@ inline void LaunchGatherConcat(const ElemT* table, int width, const IndexT* indi
  * @param mode        kSum, kMean or kConcat (concat: fixed hotness, unweighted)
  * @param ret         output: [batch x width] (sum/mean), [batch x num_hots x width] (concat)
  * @param stream      HIP stream
+ * @param options     (extension, second overload) per-call ForwardOptions; the reference signature uses
+ *                    DefaultForwardOptions(), i.e. the process-wide defaults
  */
 template <typename InputT,
           typename OutputT,
@@ -222,7 +265,8 @@ void EmbeddingForward(const InputT* params,
                       const int num_hots,
                       const CombineMode mode,
                       OutputT* ret,
-                      const hipStream_t stream = 0) {
+                      const hipStream_t stream,
+                      const ForwardOptions& options) {
   static_assert(std::is_same<InputT, OutputT>::value,
                 "EmbeddingForward: OutputT must equal InputT");
   using HostElemT = GetElemT<InputT>;
@@ -263,13 +307,34 @@ void EmbeddingForward(const InputT* params,
   const bool is_mean = mode == CombineMode::kMean;
   if (elems_per_lane == kMaxN)
     detail::LaunchGatherReduce<ElemT, AccT, IndexT, OffsetT, kMaxN>(
-        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
+        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream, options);
   else if (elems_per_lane == kMaxN / 2)
     detail::LaunchGatherReduce<ElemT, AccT, IndexT, OffsetT, kMaxN / 2>(
-        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
+        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream, options);
   else
     detail::LaunchGatherReduce<ElemT, AccT, IndexT, OffsetT, kMaxN / 4>(
-        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream);
+        table, embed_width, indices, offsets, w, batch_size, num_hots, is_mean, out, split, stream, options);
+}
+
+//! The reference's signature (embedding_lookup.cuh:245-259): options = the process-wide defaults.
+template <typename InputT,
+          typename OutputT,
+          typename IndexT,
+          typename OffsetT,
+          bool fp16_math = false>
+void EmbeddingForward(const InputT* params,
+                      const int embed_width,
+                      const IndexT* indices,
+                      const OffsetT* offsets,
+                      const GetElemT<InputT>* weights,
+                      const int batch_size,
+                      const int num_hots,
+                      const CombineMode mode,
+                      OutputT* ret,
+                      const hipStream_t stream = 0) {
+  EmbeddingForward<InputT, OutputT, IndexT, OffsetT, fp16_math>(params, embed_width, indices, offsets, weights,
+                                                                batch_size, num_hots, mode, ret, stream,
+                                                                DefaultForwardOptions());
 }
 
 /**

@@ -108,6 +108,17 @@ __device__ __forceinline__ const ElemT* RowPtr(const ElemT* base, const int64_t 
   return reinterpret_cast<const ElemT*>(reinterpret_cast<const char*>(base) + r * row_bytes);
 }
 
+//! Table-row load for RowLoadPolicy::kStreaming: non-temporal (`global_load_dwordx4 ... nt`), i.e. the row does not
+//! stay in L2.  Right when nothing is looked up twice (uniform indices at the C2 shape: 0.379 -> 0.355 ms, the
+//! rows no longer evict each other for nothing); wrong when rows are re-used (alpha = 1.15: 0.136 -> 0.222 ms,
+//! the hot rows lose their residency) -- which the launcher cannot know, hence a caller's option.
+template <typename ElemT, int N>
+__device__ __forceinline__ Pack<ElemT, N> LoadPackStreaming(const ElemT* p) {
+  typedef unsigned __attribute__((ext_vector_type(sizeof(Pack<ElemT, N>) / 4))) raw_t;
+  const raw_t raw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
+  return *reinterpret_cast<const Pack<ElemT, N>*>(&raw);
+}
+
 template <typename ElemT, int N>
 __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
 #if defined(CUEMBED_TUNE_ROW_LOAD_ASM)   // tools/tune_forward.py --policies: cache-policy bits by inline asm
@@ -193,9 +204,14 @@ struct RowPool {
   //! wave always has kUnroll..2*kUnroll loads in flight instead of draining to zero
   //! between batches.  `sched_barrier` pins "all loads first, then the adds": without it
   //! the compiler splits a batch (e.g. 5 + 3) to save registers.
-  template <int kUnroll, bool kPipelined, typename IndexFn, typename WeightFn>
+  //! kStream: non-temporal row loads (RowLoadPolicy::kStreaming).
+  template <int kUnroll, bool kPipelined, bool kStream = false, typename IndexFn, typename WeightFn>
   __device__ __forceinline__ void Gather(const ElemT* lane_base, const int width, const int count,
                                          IndexFn index_at, WeightFn weight_at) {
+    auto load_row = [](const ElemT* p) {
+      if constexpr (kStream) return LoadPackStreaming<ElemT, N>(p);
+      else return LoadPack<ElemT, N>(p);
+    };
     int j = 0;
     if constexpr (kPipelined) {
       if (count >= 2 * kUnroll) {
@@ -206,7 +222,7 @@ struct RowPool {
           for (int u = 0; u < kUnroll; ++u) {
             const int64_t r = index_at(base + u);
             if constexpr (kWeighted) w[u] = weight_at(base + u);
-            row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
+            row[u] = load_row(RowPtr(lane_base, r, width));
           }
         };
         auto consume = [&](Pack<ElemT, N>(&row)[kUnroll], ElemT(&w)[kUnroll]) {
@@ -243,7 +259,7 @@ struct RowPool {
       for (int u = 0; u < kUnroll; ++u) {
         const int64_t r = index_at(j + u);
         if constexpr (kWeighted) w[u] = weight_at(j + u);
-        row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
+        row[u] = load_row(RowPtr(lane_base, r, width));
       }
       TuneWaitRowLoads();
       __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +279,7 @@ struct RowPool {
         if (u < rem) {
           const int64_t r = index_at(j + u);
           if constexpr (kWeighted) w[u] = weight_at(j + u);
-          row[u] = LoadPack<ElemT, N>(RowPtr(lane_base, r, width));
+          row[u] = load_row(RowPtr(lane_base, r, width));
         }
       }
       TuneWaitRowLoads();
@@ -302,7 +318,8 @@ GatherReduceKernel(const ElemT* __restrict__ table,
                    const ElemT* __restrict__ weights,
                    const bool is_mean,
                    ElemT* __restrict__ out,
-                   const int column_slices) {  // 1, 2, 4 or 8 (see ColumnSlice)
+                   const int column_slices,    // 1, 2, 4 or 8 (see ColumnSlice)
+                   const bool stream_rows) {   // RowLoadPolicy::kStreaming: table rows are not kept in L2
   using A = Arith<AccT>;
   const int lane_x = threadIdx.x;
   const int slot = threadIdx.y;
@@ -336,9 +353,10 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     if (sample >= batch) return;
     const IndexT* my_idx = stage_idx + slot * num_hots;
     const ElemT* my_w = stage_w + slot * num_hots;
-    pool.template Gather<kUnroll, kPipelined>(lane_base, width, hot,
-                [&](int j) { return WidenIndex(my_idx[j]); },
-                [&](int j) { return my_w[j]; });
+    const auto idx_at = [&](int j) { return WidenIndex(my_idx[j]); };
+    const auto w_at = [&](int j) { return my_w[j]; };
+    if (stream_rows) pool.template Gather<kUnroll, kPipelined, true>(lane_base, width, hot, idx_at, w_at);
+    else pool.template Gather<kUnroll, kPipelined, false>(lane_base, width, hot, idx_at, w_at);
   } else {
     if (sample >= batch) return;
     int64_t begin;
@@ -370,18 +388,20 @@ GatherReduceKernel(const ElemT* __restrict__ table,
           if constexpr (kWeighted) next_w = my_w[c + group + lane_x];
         }
         const int n = (hot - c < group) ? hot - c : group;
-        pool.template Gather<kUnroll, kPipelined>(lane_base, width, n,
-                    [&](int j) { return WidenIndex(__shfl(cur_i, j, group)); },
-                    [&](int j) { return ShuffleElem(cur_w, j, group); });
+        const auto idx_at = [&](int j) { return WidenIndex(__shfl(cur_i, j, group)); };
+        const auto w_at = [&](int j) { return ShuffleElem(cur_w, j, group); };
+        if (stream_rows) pool.template Gather<kUnroll, kPipelined, true>(lane_base, width, n, idx_at, w_at);
+        else pool.template Gather<kUnroll, kPipelined, false>(lane_base, width, n, idx_at, w_at);
         cur_i = next_i;
         cur_w = next_w;
       }
     } else {
       // ---- any row split: every lane reads its sample's index straight from global
       // memory (one address per sample: a broadcast load that mostly hits L1).
-      pool.template Gather<kUnroll, kPipelined>(lane_base, width, hot,
-                  [&](int j) { return WidenIndex(my_idx[j]); },
-                  [&](int j) { return my_w[j]; });
+      const auto idx_at = [&](int j) { return WidenIndex(my_idx[j]); };
+      const auto w_at = [&](int j) { return my_w[j]; };
+      if (stream_rows) pool.template Gather<kUnroll, kPipelined, true>(lane_base, width, hot, idx_at, w_at);
+      else pool.template Gather<kUnroll, kPipelined, false>(lane_base, width, hot, idx_at, w_at);
     }
   }
 
@@ -466,7 +486,7 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
   const ElemT* my_w = weights + begin + j0;
 
   RowPool<ElemT, AccT, N, kWeighted> pool;
-  pool.template Gather<kForwardUnroll, false>(
+  pool.template Gather<kForwardUnroll, false, false>(
       table + static_cast<int64_t>(lane_x) * N, width, j1 - j0,
       [&](int j) { return WidenIndex(my_idx[j]); }, [&](int j) { return my_w[j]; });
 

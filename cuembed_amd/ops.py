@@ -66,6 +66,24 @@ def get_forward_reduction_order():
     return "split" if _lib.lib().cuembed_get_forward_reduction_order() else "sequential"
 
 
+_ORDERS = {None: -1, "sequential": 0, "split": 1}
+_ROW_LOADS = {None: -1, "default": 0, "streaming": 1}
+
+
+def set_forward_row_load_policy(policy):
+    """Process-wide default of how embedding_forward (sum / mean) loads table rows: "default" (rows stay in L2 /
+    Infinity Cache: right whenever rows are re-used) or "streaming" (non-temporal loads: for batches in which nearly
+    every lookup hits a different row of a table far larger than the caches).  Never changes a result.  Prefer the
+    per-call `row_loads=` argument of embedding_forward."""
+    if policy not in ("default", "streaming"):
+        raise ValueError("policy must be 'default' or 'streaming'")
+    _lib.lib().cuembed_set_forward_row_load_policy(_ROW_LOADS[policy])
+
+
+def get_forward_row_load_policy():
+    return "streaming" if _lib.lib().cuembed_get_forward_row_load_policy() else "default"
+
+
 def forward_launch_shape(elem_dtype, index_dtype, embed_width, batch_size, num_hots, is_csr=False,
                          is_weighted=False, mode="sum"):
     """Launch shape the forward kernel would use (pure host arithmetic)."""
@@ -78,14 +96,18 @@ def forward_launch_shape(elem_dtype, index_dtype, embed_width, batch_size, num_h
 
 
 def embedding_forward(params, indices, offsets=None, weights=None, batch_size=None, num_hots=0,
-                      mode="sum", fp16_math=False, out=None):
+                      mode="sum", fp16_math=False, out=None, reduction_order=None, row_loads=None):
     """out[s] = combine_j weights[s,j] * params[indices[s,j]].
 
     Fixed hotness: offsets=None, num_hots>0 (indices holds batch_size*num_hots ids).
     CSR: offsets[batch_size+1], num_hots=0.  mode: "sum" | "mean" | "concat".
-    Returns [batch, width] (sum/mean) or [batch, num_hots, width] (concat)."""
+    Returns [batch, width] (sum/mean) or [batch, num_hots, width] (concat).
+    Per-call options (extension; None = the process-wide default): reduction_order "sequential" | "split"
+    (set_forward_reduction_order), row_loads "default" | "streaming" (set_forward_row_load_policy)."""
     if mode not in _MODES:
         raise ValueError("mode must be 'sum', 'mean' or 'concat'")
+    if reduction_order not in _ORDERS or row_loads not in _ROW_LOADS:
+        raise ValueError("reduction_order: None, 'sequential' or 'split'; row_loads: None, 'default' or 'streaming'")
     m = _MODES[mode]
     _check_dev("params", params)
     dev = params.device
@@ -135,9 +157,10 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
             raise ValueError("out has the wrong dtype or size")
     if batch_size > 0:
         with torch.cuda.device(params.device):   # the launch must happen on the tensors' device
-            _lib.lib().cuembed_embedding_forward(
+            _lib.lib().cuembed_embedding_forward_with_options(
                 _ptr(params), et, width, _ptr(indices), it, _ptr(offsets), ot, _ptr(weights),
-                batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _stream(params))
+                batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _ORDERS[reduction_order],
+                _ROW_LOADS[row_loads], _stream(params))
     return out
 
 

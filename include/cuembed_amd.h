@@ -309,6 +309,25 @@ void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_
  *     partial rows through LDS (same result up to fp rounding, much faster for small batches). */
 void cuembed_set_forward_reduction_order(int order);
 int cuembed_get_forward_reduction_order(void);
+/* cuembed::SetForwardRowLoadPolicy / GetForwardRowLoadPolicy (extension; the reference has no such knob,
+ * embedding_lookup_kernels.cuh:34-77).  Never changes a result.
+ * 0 = default: ordinary table-row loads (rows stay in L2 / Infinity Cache; right whenever rows are re-used),
+ * 1 = streaming: non-temporal row loads for batches in which (nearly) every lookup hits a different row of a table
+ *     far larger than the caches -- the HBM-bound case (C2 shape with uniform indices: 0.379 -> 0.355 ms); with
+ *     re-use it is much slower (alpha = 1.15: 0.136 -> 0.222 ms).  sum / mean only.
+ * Both setters change PROCESS-WIDE defaults used by the reference-shaped entry points (initial values:
+ * CUEMBED_FORWARD_ORDER=split, CUEMBED_FORWARD_ROW_LOADS=streaming).  A caller that shares its process with
+ * other users of the library passes the options per call instead: */
+void cuembed_set_forward_row_load_policy(int policy);
+int cuembed_get_forward_row_load_policy(void);
+/* cuembed_embedding_forward with per-call options (cuembed::ForwardOptions): reduction_order 0 / 1,
+ * row_load_policy 0 / 1, or -1 = the process-wide default.  No state is read or written when both are >= 0. */
+void cuembed_embedding_forward_with_options(const void* params, int elem_type, int embed_width,
+                                            const void* indices, int index_type, const void* offsets,
+                                            int offset_type, const void* weights, int batch_size,
+                                            int num_hots, int mode, int fp16_math, void* ret,
+                                            int reduction_order, int row_load_policy,
+                                            cuembed_stream_t stream);
 /* cuembed::SetBackwardTuning / GetBackwardTuning (tuning and tests; 0 = built-in heuristic):
  * lookups per nz-segment (rounded down to a multiple of 8), XCD column slices of the gather
  * (1, 2, 4, 8).  Process-wide; initial values from CUEMBED_BWD_SEGMENT_LEN / CUEMBED_BWD_SLICES,

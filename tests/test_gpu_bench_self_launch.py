@@ -34,26 +34,52 @@ def test_gpus_2_as_typed():
     assert line["value"] > 0 and line["roofline"]["achieved"] > 0
     # two ranks time-sharing one GPU deliver about one GPU's worth; two GPUs about twice that
     assert line["ms_per_step"] > 0.1
+    # N > 1: the step time is the max over ranks of the rank's own HIP-event time; the wall figure sits next to it
+    assert "HIP-event" in line["timing"] and line["ms_per_step"] == line["ms_per_step_events"]
+    assert line["wall_ms_per_step"] >= line["ms_per_step"] * 0.98 and line["value_wall"] > 0
+    assert line["config"]["index_batches_cycled"] == 4            # the same at every N
+    # BASELINE config 5 ran on ALL ranks and the gradient really went through the exchange
+    c5 = line["extras"]["c5_train_step"]
+    assert c5["n_gpus"] == 2 and c5["backend"] in ("gloo", "nccl")
+    assert c5["exchange_ms"] > 0 and c5["sparse"]["exchange_ms"] > 0 and c5["dense"]["exchange_ms"] > 0
+    assert c5["sparse"]["algorithm"] == "owner" and c5["sparse"]["gradient_bytes_per_rank"] > 100e6
+    assert c5["dense"]["gradient_bytes_per_rank"] == 10_000_000 * 256 * 2
+    assert c5["sparse"]["step_ms"] > c5["compute_by_order"]["blocked_uncoalesced"]["compute_ms"]
 
 
 def test_gpus_1_line_has_the_contract_fields():
     line = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-c3"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_reference_protocol",
-              "pct_of_hbm_peak", "preroll_ms"):
+              "pct_of_hbm_peak", "preroll_ms", "steady_state", "timing"):
         assert k in line, k
+    assert line["preroll_ms"] == 0 and line["preroll_launches"] == 0      # `value` is the caller's protocol, nothing else
+    assert line["timing"].startswith("wall clock") and line["config"]["index_batches_cycled"] == 4
+    assert line["steady_state"]["preroll_ms"] == 100 and 0 < line["steady_state"]["ms_per_step"] < line["ms_per_step"] * 1.05
     rl = line["roofline"]
     assert rl["bound"] == "l2+fabric" and 0 < rl["frac"] <= 1.0 and rl["traffic"] > 0
     assert abs(line["pct_of_hbm_peak"] - 100 * rl["frac"]) < 0.02
     assert "protocol" in line["config"] and line["value_reference_protocol"]["value"] > 0
     for o in rl["other_kernels"]:
-        assert "algorithmic_frac" in o and o["algorithmic_frac"] <= o["frac"] + 1e-9
-    assert line["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True
+        assert o["frac"] == o["algorithmic_frac"] and o["frac"] <= o["traffic_frac"] + 1e-9
+    c3 = [o for o in rl["other_kernels"] if "C3" in o["kernel"]]
+    assert not c3 or (c3[0]["compulsory_bytes_per_launch"] > 0 and c3[0]["hbm_bound_companion"]["row_loads_streaming"]["ms"] > 0)
+    comp = rl["hbm_bound_companion"]
+    assert comp["row_loads"] == "default" and comp["row_loads_streaming"]["ms"] > 0
+    assert line["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and line["cpu_baseline"]["cpu_model"]
     ex = line["extras"]
     assert ex["sample_blocks"] == 2 and ex["sample_blocks_gradient_equals_reference_order"] is True
     assert ex["backward_compressed_sample_blocks_ms"] < ex["backward_compressed_ms"]
     ts = ex["train_step_per_gpu"]
     assert 0 < ts["sample_blocks_2"]["ms"] < ts["sample_blocks_1"]["ms"] < 1.0
+    # the reference's compressed gradient from the blocked order: same rows, same inverse mapping
+    assert ex["blocked_coalesced_num_unique_equals_reference_order"] is True
+    assert ex["blocked_coalesced_inverse_mapping_equals_reference_order"] is True
+    assert ex["blocked_coalesced_max_rel_diff_vs_reference_order"] < 1e-2
+    assert ex["backward_compressed_blocked_coalesced_ms"] < ex["backward_compressed_ms"]
+    c5 = ex["c5_train_step"]                                            # N = 1: no exchange, but the leg runs
+    assert c5["n_gpus"] == 1 and c5["backend"] is None and c5["exchange_ms"] == 0
+    assert c5["compute_by_order"]["blocked_uncoalesced"]["compute_ms"] < c5["compute_by_order"]["reference"]["compute_ms"]
 
 
 def test_gpus_2_under_torch_distributed_run():

@@ -81,10 +81,29 @@ def test_forward_sweep_against_oracle(ce, oracle, elem, fp16_math, idx, shape):
         w = a["weights"] if weighted else None
         want = oracle.embedding_forward(a["table"], a["indices"], offsets, w, batch_size=B,
                                         num_hots=0 if csr else H, mode=mode, fp16_math=fp16_math)
-        got = ce.embedding_forward(dev(a["table"]), dev(a["indices"]), dev(offsets), dev(w), batch_size=B,
-                                   num_hots=0 if csr else H, mode=mode, fp16_math=fp16_math)
-        got = got.cpu().numpy().reshape(want.shape)
-        assert (bits(got) == bits(want)).all(), (mode, csr, weighted)
+        for row_loads in (None, "streaming"):       # the row-load policy never changes a bit
+            got = ce.embedding_forward(dev(a["table"]), dev(a["indices"]), dev(offsets), dev(w), batch_size=B,
+                                       num_hots=0 if csr else H, mode=mode, fp16_math=fp16_math, row_loads=row_loads)
+            got = got.cpu().numpy().reshape(want.shape)
+            assert (bits(got) == bits(want)).all(), (mode, csr, weighted, row_loads)
+
+
+def test_forward_row_load_policy_default_and_per_call(ce, oracle):
+    """process-wide default (SetForwardRowLoadPolicy) vs the per-call option; both bit-identical to the oracle"""
+    a = oracle.allocate_forward(50_000, 128, 4099, 37, alpha=0.0, elem=np.float16)
+    want = oracle.embedding_forward(a["table"], a["indices"], num_hots=37)
+    t, i = dev(a["table"]), dev(a["indices"])
+    assert ce.get_forward_row_load_policy() == "default"
+    try:
+        ce.set_forward_row_load_policy("streaming")
+        assert ce.get_forward_row_load_policy() == "streaming"
+        for per_call in (None, "default", "streaming"):
+            got = ce.embedding_forward(t, i, num_hots=37, row_loads=per_call).cpu().numpy()
+            assert (bits(got) == bits(want)).all(), per_call
+    finally:
+        ce.set_forward_row_load_policy("default")
+    with pytest.raises(ValueError):
+        ce.embedding_forward(t, i, num_hots=37, row_loads="nt")
 
 
 @pytest.mark.parametrize("off_t", [np.int32, np.int64], ids=["o32", "o64"])
