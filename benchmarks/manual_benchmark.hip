@@ -13,8 +13,10 @@
 //               -o benchmarks/manual_benchmark
 // run:    benchmarks/manual_benchmark --num_categories 10000000 --embed_width 256 \
 //               --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true --iterations 100
+#include <dlfcn.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -95,6 +97,84 @@ Flags ParseFlags(int argc, char** argv) {
     std::exit(1);
   }
   return f;
+}
+
+// ---- --check_result: the CPU checker (reference: ValidateResult + the CPU runs, manual_benchmark.cu:85-90,
+// :278-285, :373-386, :495-507).  The checker is this repository's oracle (oracle/libcuembed_oracle.so, a
+// restatement of utils/include/embedding_lookup_cpu.hpp / index_transforms_cpu.hpp), loaded with dlopen ONLY when
+// the flag is given and called only after the timed loops: nothing of it is linked into or timed by the benchmark.
+struct Checker {
+  void* lib = nullptr;
+  int (*forward)(const void*, int, int, int, int, const void*, int, const void*, int, const void*, void*, int, int, int) = nullptr;
+  int (*backward)(const void*, int, int, int64_t, int64_t, const void*, const void*, const void*, int, const void*, int,
+                  void*, void*) = nullptr;
+  int (*transpose)(const void*, const void*, const void*, int64_t, int, int, void*, void*, void*, int) = nullptr;
+  int (*row_ids_fixed)(int, int, int, void*) = nullptr;
+  int (*row_ids_csr)(const void*, int, int, int, void*) = nullptr;
+  int (*remap)(const void*, int64_t, int, void*) = nullptr;
+  int (*max_threads)() = nullptr;
+  int failures = 0;
+
+  void Load(const char* argv0) {
+    std::string path;
+    if (const char* env = std::getenv("CUEMBED_ORACLE_LIB")) path = env;
+    if (path.empty()) {
+      char exe[4096];
+      const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+      std::string dir = n > 0 ? std::string(exe, static_cast<size_t>(n)) : std::string(argv0);
+      dir = dir.substr(0, dir.find_last_of('/'));
+      path = dir + "/../oracle/libcuembed_oracle.so";
+    }
+    lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (lib == nullptr) {
+      std::fprintf(stderr, "--check_result: cannot load the CPU checker %s (%s); build it with `make -C oracle` or "
+                           "point CUEMBED_ORACLE_LIB at it\n", path.c_str(), dlerror());
+      std::exit(3);
+    }
+    auto sym = [&](const char* name) {
+      void* p = dlsym(lib, name);
+      if (p == nullptr) {
+        std::fprintf(stderr, "--check_result: %s has no %s\n", path.c_str(), name);
+        std::exit(3);
+      }
+      return p;
+    };
+    forward = reinterpret_cast<decltype(forward)>(sym("oracle_embedding_forward"));
+    backward = reinterpret_cast<decltype(backward)>(sym("oracle_embedding_backward"));
+    transpose = reinterpret_cast<decltype(transpose)>(sym("oracle_transpose"));
+    row_ids_fixed = reinterpret_cast<decltype(row_ids_fixed)>(sym("oracle_extract_row_ids_from_fixed"));
+    row_ids_csr = reinterpret_cast<decltype(row_ids_csr)>(sym("oracle_extract_row_ids_from_csr"));
+    remap = reinterpret_cast<decltype(remap)>(sym("oracle_compute_compressed_grad_indices"));
+    max_threads = reinterpret_cast<decltype(max_threads)>(sym("oracle_max_threads"));
+  }
+
+  //! exact equality, like the reference's ValidateResult (manual_benchmark.cu:85-90) -- for floats too
+  template <typename T>
+  void Expect(const char* what, const std::vector<T>& got, const std::vector<T>& want) {
+    size_t bad = got.size() == want.size() ? 0 : 1;
+    size_t first = 0;
+    for (size_t i = 0; bad == 0 && i < got.size(); ++i)
+      if (std::memcmp(&got[i], &want[i], sizeof(T)) != 0) {
+        bad = 1;
+        first = i;
+      }
+    if (bad == 0) {
+      std::fprintf(stderr, "check_result: %s matches the CPU result (%zu values, exact)\n", what, got.size());
+      return;
+    }
+    size_t count = 0;
+    for (size_t i = 0; i < got.size() && i < want.size(); ++i) count += std::memcmp(&got[i], &want[i], sizeof(T)) != 0;
+    std::fprintf(stderr, "check_result: %s MISMATCH: %zu of %zu values differ (first at %zu)\n", what, count,
+                 got.size(), first);
+    ++failures;
+  }
+};
+
+template <typename T>
+std::vector<T> Download(const T* dev, size_t n) {
+  std::vector<T> h(n);
+  if (n) HIP_OK(hipMemcpy(h.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost));
+  return h;
 }
 
 // ---- device helpers ----------------------------------------------------------------------
@@ -261,8 +341,11 @@ void CsvLine(const Flags& f, const char* name, double ms, double bw_l2, double b
 }
 
 template <typename ElemT, typename IndexT, typename OffsetT, bool fp16_math>
-void EmbeddingLookupBenchmark(const Flags& f) {
+int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
   using DevT = typename DevElem<ElemT>::type;
+  Checker check;
+  if (f.check_result) check.Load(argv0);
+  const int etype = sizeof(ElemT) == 2 ? 1 : 0, itype = sizeof(IndexT) == 8 ? 1 : 0, otype = sizeof(OffsetT) == 8 ? 1 : 0;
   constexpr bool kHalf = sizeof(ElemT) == 2;
   constexpr bool kIdx64 = sizeof(IndexT) == 8;
   Workload<ElemT, IndexT, OffsetT> w;
@@ -307,10 +390,20 @@ void EmbeddingLookupBenchmark(const Flags& f) {
                        "rate -- bench.py's roofline block has the measured fabric traffic)\n",
                f.iterations, ms, ms / it, bw);
   CsvLine(f, "forward", ms, bw, 0.0);
-  if (f.check_result)
-    std::fprintf(stderr, "check_result: results are checked against the CPU oracle by `pytest -m gpu` and "
-                         "benchmarks/manual_benchmark.py --check_result, not by this binary\n");
-  if (f.forward_only) return;
+  if (f.check_result) {   // (manual_benchmark.cu:278-285)
+    const std::vector<ElemT> table = device_fill ? Download(w.table.ptr, static_cast<size_t>(cells)) : h_table;
+    std::vector<ElemT> want(static_cast<size_t>(f.batch_size) * f.embed_width);
+    const int rc = check.forward(table.data(), etype, f.embed_width, f.batch_size, f.csr_input ? 0 : f.hotness,
+                                 h_indices.data(), itype, f.csr_input ? h_off.data() : nullptr, otype,
+                                 f.weighted_sum ? h_weights.data() : nullptr, want.data(), /*sum*/ 0, fp16_math ? 1 : 0,
+                                 check.max_threads());
+    if (rc != 0) {
+      std::fprintf(stderr, "check_result: the CPU forward rejected the arguments\n");
+      ++check.failures;
+    }
+    check.Expect("forward", Download(w.result.ptr, want.size()), want);
+  }
+  if (f.forward_only) return check.failures;
 
   // ---- transpose (+ compressed remap) ----
   w.sample_ids.Resize(w.nnz);
@@ -333,6 +426,35 @@ void EmbeddingLookupBenchmark(const Flags& f) {
   std::fprintf(stderr, "Transpose. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
                        "Application BW [GB/s]: %.2f\n", f.iterations, ms, ms / it, bw);
   CsvLine(f, "transpose", ms, 0.0, bw);
+  std::vector<IndexT> c_idx, c_sid, c_remap;
+  std::vector<ElemT> c_w;
+  if (f.check_result) {   // (manual_benchmark.cu:373-386; the device contract: a STABLE sort by index)
+    int blocks = 1;
+    if (f.compressed_grad)
+      blocks = f.sample_blocks > 0 ? f.sample_blocks
+                                   : cuembed::RecommendedSampleBlocks<ElemT>(f.embed_width, f.batch_size, w.nnz);
+    if (cuembed::TransposeSampleBlockLength(w.nnz, blocks) < w.nnz) {
+      std::fprintf(stderr, "check_result: --sample_blocks > 1 changes the order on purpose; transpose and backward are "
+                           "not checked (tests/test_gpu_sample_blocks.py checks them block by block)\n");
+      return check.failures;
+    }
+    std::vector<IndexT> sid(w.nnz);
+    if (f.csr_input) check.row_ids_csr(h_off.data(), otype, f.batch_size, itype, sid.data());
+    else check.row_ids_fixed(f.batch_size, f.hotness, itype, sid.data());
+    c_idx.resize(w.nnz);
+    c_sid.resize(w.nnz);
+    c_w.resize(f.weighted_sum ? w.nnz : 0);
+    check.transpose(sid.data(), h_indices.data(), f.weighted_sum ? h_weights.data() : nullptr, w.nnz, itype, etype,
+                    c_idx.data(), c_sid.data(), f.weighted_sum ? c_w.data() : nullptr, /*stable=*/1);
+    check.Expect("transpose indices", Download(w.transpose_indices.ptr, w.nnz), c_idx);
+    check.Expect("transpose sample ids", Download(w.transpose_sample_ids.ptr, w.nnz), c_sid);
+    if (f.weighted_sum) check.Expect("transpose weights", Download(w.transpose_weights.ptr, w.nnz), c_w);
+    if (f.compressed_grad) {
+      c_remap.resize(w.nnz);
+      check.remap(c_idx.data(), w.nnz, itype, c_remap.data());
+      check.Expect("remapped indices", Download(w.transpose_remapped_indices.ptr, w.nnz), c_remap);
+    }
+  }
 
   // ---- backward ----
   int num_unique = 0;
@@ -360,6 +482,24 @@ void EmbeddingLookupBenchmark(const Flags& f) {
                        "Application DRAM BW [GB/s]: %.2f , Application L2 BW [GB/s]: %.2f\n",
                f.iterations, ms, ms / it, dram * it / 1e6 / ms, l2 * it / 1e6 / ms);
   CsvLine(f, "backward", ms, l2 * it / 1e6 / ms, dram * it / 1e6 / ms);
+  if (f.check_result) {   // (manual_benchmark.cu:495-507)
+    // the timed iterations may have run with skip_grad_init onto a buffer that earlier iterations had written
+    // (only their time means anything): one more call into a zeroed buffer is what is compared
+    HIP_OK(hipMemset(w.grad_embedding.ptr, 0, w.grad_embedding.n * sizeof(ElemT)));
+    RunBackward<ElemT, IndexT, OffsetT>(w, num_unique);
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<ElemT> want(w.grad_embedding.n);
+    std::memset(want.data(), 0, want.size() * sizeof(ElemT));
+    std::vector<IndexT> want_inv(f.compressed_grad ? num_unique : 0);
+    check.backward(h_gy.data(), etype, f.embed_width, grad_rows, w.nnz, c_idx.data(), c_sid.data(),
+                   f.compressed_grad ? c_remap.data() : nullptr, itype, f.weighted_sum ? c_w.data() : nullptr,
+                   /*skip_grad_init=*/1, want.data(), f.compressed_grad ? want_inv.data() : nullptr);
+    check.Expect(kHalf ? "backward (fp16: exact while every partial sum is exactly representable, the reference's "
+                         "own test data; see include/cuembed_amd.h)" : "backward",
+                 Download(w.grad_embedding.ptr, want.size()), want);
+    if (f.compressed_grad) check.Expect("inverse mapping", Download(w.inverse_mapping.ptr, want_inv.size()), want_inv);
+  }
+  return check.failures;
 }
 
 }  // namespace
@@ -367,10 +507,11 @@ void EmbeddingLookupBenchmark(const Flags& f) {
 int main(int argc, char** argv) {
   const Flags f = ParseFlags(argc, argv);
   // type dispatch as in manual_benchmark.cu:563-659
-#define DISPATCH(ELEM, MATH)                                                            \
-  do {                                                                                  \
-    if (f.use_int64_indices) EmbeddingLookupBenchmark<ELEM, int64_t, int, MATH>(f);     \
-    else EmbeddingLookupBenchmark<ELEM, int32_t, int, MATH>(f);                         \
+  int failures = 0;
+#define DISPATCH(ELEM, MATH)                                                                             \
+  do {                                                                                                   \
+    if (f.use_int64_indices) failures = EmbeddingLookupBenchmark<ELEM, int64_t, int, MATH>(f, argv[0]);  \
+    else failures = EmbeddingLookupBenchmark<ELEM, int32_t, int, MATH>(f, argv[0]);                      \
   } while (0)
   if (f.half_embedding_type) {
     if (f.fp16_math) DISPATCH(__half, true);
@@ -378,5 +519,5 @@ int main(int argc, char** argv) {
   } else {
     DISPATCH(float, false);
   }
-  return 0;
+  return failures == 0 ? 0 : 4;   // --check_result: a mismatch is an error
 }

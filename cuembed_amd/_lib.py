@@ -84,6 +84,12 @@ def _declare(L):
     L.cuembed_set_forward_reduction_order.argtypes = [_I]
     L.cuembed_get_forward_reduction_order.restype = _I
     L.cuembed_get_forward_reduction_order.argtypes = []
+    L.cuembed_device_shape.restype = None
+    L.cuembed_device_shape.argtypes = [ctypes.POINTER(_I)]
+    L.cuembed_backward_launch_shape.restype = None
+    L.cuembed_backward_launch_shape.argtypes = [_I, _I, _I, ctypes.c_int64, _I, _I, _I, ctypes.POINTER(_I)]
+    L.cuembed_recommended_sample_blocks_on.restype = _I
+    L.cuembed_recommended_sample_blocks_on.argtypes = [_I, _I, _I, ctypes.c_int64, _I, _I, ctypes.c_int64]
     L.cuembed_peek_last_error.restype = _I
     L.cuembed_peek_last_error.argtypes = []
     L.cuembed_version.restype = ctypes.c_char_p

@@ -205,7 +205,7 @@ def build_manual_benchmark(force=False):
             if f.read().strip() == digest:
                 return exe
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I" + CSRC,
-           src, gen, "-o", exe]
+           src, gen, "-ldl", "-o", exe]     # (-ldl: --check_result loads the CPU checker with dlopen)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for benchmarks/manual_benchmark.hip:\n" + r.stdout)

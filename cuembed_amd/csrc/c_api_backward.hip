@@ -19,6 +19,26 @@ void Backward(const void* grad_y, int embed_width, int num_rows, int nnz, const 
 }
 }  // namespace
 
+namespace {
+cuembed::detail::DeviceShape ShapeFrom(int compute_units, int xcds, int64_t l2_bytes_per_xcd) {
+  cuembed::detail::DeviceShape dev =
+      compute_units > 0 ? cuembed::detail::Mi355xShape() : cuembed::detail::CurrentDeviceShape();
+  if (compute_units > 0) dev.compute_units = compute_units;
+  if (xcds > 0) dev.xcds = xcds;
+  if (l2_bytes_per_xcd > 0) dev.l2_bytes_per_xcd = static_cast<size_t>(l2_bytes_per_xcd);
+  return dev;
+}
+
+template <typename ElemT, int N>
+cuembed::detail::ScatterShape PlanFor(int index_type, int width, int64_t nnz, bool weighted,
+                                      const cuembed::detail::RowSplit& split,
+                                      const cuembed::detail::DeviceShape& dev) {
+  return index_type == CUEMBED_I32
+             ? cuembed::detail::PlanScatter<ElemT, int32_t, N>(width, nnz, split, weighted, dev)
+             : cuembed::detail::PlanScatter<ElemT, int64_t, N>(width, nnz, split, weighted, dev);
+}
+}  // namespace
+
 extern "C" {
 
 #define CUEMBED_DEFINE_BACKWARD(SUFFIX, CELEM, ELEM, INDEX)                                  \
@@ -85,6 +105,51 @@ int cuembed_recommended_sample_blocks(int elem_type, int embed_width, int batch_
     case 0: return cuembed::RecommendedSampleBlocks<float>(embed_width, batch_size, nnz);
     case 1: return cuembed::RecommendedSampleBlocks<__half>(embed_width, batch_size, nnz);
     case 2: return cuembed::RecommendedSampleBlocks<__hip_bfloat16>(embed_width, batch_size, nnz);
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+  return 1;
+}
+
+void cuembed_device_shape(int* out) {
+  const cuembed::detail::DeviceShape dev = cuembed::detail::CurrentDeviceShape();
+  out[0] = dev.compute_units;
+  out[1] = dev.xcds;
+  out[2] = dev.lanes_per_cu;
+  out[3] = static_cast<int>(dev.l2_bytes_per_xcd);
+}
+
+void cuembed_backward_launch_shape(int elem_type, int index_type, int embed_width, int64_t nnz, int is_weighted,
+                                   int compute_units, int xcds, int* out) {
+  const cuembed::detail::DeviceShape dev = ShapeFrom(compute_units, xcds, 0);
+  cuembed::detail::ScatterShape s;
+  if (elem_type == CUEMBED_F32) {
+    const auto split = cuembed::detail::SplitRow<float>(embed_width, nullptr, nullptr);
+    s = split.elems_per_lane == 4   ? PlanFor<float, 4>(index_type, embed_width, nnz, is_weighted != 0, split, dev)
+        : split.elems_per_lane == 2 ? PlanFor<float, 2>(index_type, embed_width, nnz, is_weighted != 0, split, dev)
+                                    : PlanFor<float, 1>(index_type, embed_width, nnz, is_weighted != 0, split, dev);
+  } else {  // 2-byte elements (fp16 and bf16 plan identically)
+    const auto split = cuembed::detail::SplitRow<_Float16>(embed_width, nullptr, nullptr);
+    s = split.elems_per_lane == 8   ? PlanFor<_Float16, 8>(index_type, embed_width, nnz, is_weighted != 0, split, dev)
+        : split.elems_per_lane == 4 ? PlanFor<_Float16, 4>(index_type, embed_width, nnz, is_weighted != 0, split, dev)
+                                    : PlanFor<_Float16, 2>(index_type, embed_width, nnz, is_weighted != 0, split, dev);
+  }
+  out[0] = s.slices;
+  out[1] = s.lanes;
+  out[2] = s.segments_per_block;
+  out[3] = s.segment_len;
+  out[4] = static_cast<int>(s.nz_blocks);
+  out[5] = static_cast<int>(s.grid_blocks);
+  out[6] = static_cast<int>(s.lds);
+  out[7] = s.xcds;
+}
+
+int cuembed_recommended_sample_blocks_on(int elem_type, int embed_width, int batch_size, int64_t nnz,
+                                         int compute_units, int xcds, int64_t l2_bytes_per_xcd) {
+  const cuembed::detail::DeviceShape dev = ShapeFrom(compute_units, xcds, l2_bytes_per_xcd);
+  switch (elem_type) {
+    case 0: return cuembed::RecommendedSampleBlocks<float>(embed_width, batch_size, nnz, dev);
+    case 1: return cuembed::RecommendedSampleBlocks<__half>(embed_width, batch_size, nnz, dev);
+    case 2: return cuembed::RecommendedSampleBlocks<__hip_bfloat16>(embed_width, batch_size, nnz, dev);
     default: CUEMBED_C_API_BAD_TYPE();
   }
   return 1;

@@ -3,6 +3,7 @@
 #ifndef CUEMBED_INCLUDE_EMBEDDING_BACKWARD_HPP_
 #define CUEMBED_INCLUDE_EMBEDDING_BACKWARD_HPP_
 
+#include "cuembed/include/device_shape.hpp"
 #include "cuembed/include/embedding_lookup.hpp"
 
 namespace cuembed {
@@ -38,37 +39,40 @@ namespace detail {
 constexpr int kMaxSegmentLen = 128;
 constexpr int kMinSegmentLen = 8;
 constexpr int kMaxScatterStageBytes = 32 * 1024;   // five workgroups per CU (160 KiB of LDS)
-//! Lanes wanted in flight on the whole chip before segments are shortened:
-//! 256 CUs x 2048 lanes x 0.4 (the reference's 40 % target,
-//! embedding_lookup.cuh:312, :365-375, evaluated for MI355X without a device query).
-constexpr int64_t kBackwardTargetLanes = static_cast<int64_t>(256) * 2048 * 4 / 10;
+//! Lanes wanted in flight on the device before segments are shortened: CUs x resident lanes per CU x 0.4 (the
+//! reference's 40 % target, embedding_lookup.cuh:312, :365-375; 256 x 2048 x 0.4 on a full MI355X).
+inline int64_t BackwardTargetLanes(const DeviceShape& dev) {
+  return static_cast<int64_t>(dev.compute_units) * dev.lanes_per_cu * 4 / 10;
+}
 
-inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row) {
+inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row, const DeviceShape& dev) {
   int len = kMaxSegmentLen;
   const int forced = BackwardTuningCell(0).load(std::memory_order_relaxed);
   if (forced >= kMinSegmentLen && forced <= 4096) return forced & ~7;  // the walk is unrolled by 8
-  while (len > kMinSegmentLen && (nnz / len) * lanes_per_row < kBackwardTargetLanes) len /= 2;
+  while (len > kMinSegmentLen && (nnz / len) * lanes_per_row < BackwardTargetLanes(dev)) len /= 2;
   return len;
 }
 
 //! Column slices for the backward gather (see SegmentedScatterAddKernel 2b): slices of at
-//! least 128 bytes (one L2 line), at most 8 (one per XCD: rows of 1 KiB and more; measured at the
+//! least 128 bytes (one L2 line), at most one per XCD and a divisor of the XCD count (8 on a full chip: rows of
+//! 1 KiB and more; a single-XCD partition never slices; measured at the
 //! C4 index set: fp32 W = 256 0.579 -> 0.540 ms, fp16 W = 512 0.580 -> 0.546 ms against 4 slices).
 //! Only for >= 1M lookups: EmbeddingBackward is not told the batch size, and with few lookups
 //! grad_y fits the L2s anyway (measured: 0.340 -> 0.290 ms at C4, but 25 -> 28 us at nnz = 262k).
-inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row, const int64_t nnz) {
+inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row, const int64_t nnz,
+                              const DeviceShape& dev) {
   int slices = 1;
-  while (nnz >= (int64_t{1} << 20) && slices < 8 && row_bytes / (slices * 2) >= 128 &&
-         lanes_per_row % (slices * 2) == 0)
+  while (nnz >= (int64_t{1} << 20) && slices * 2 <= dev.xcds && dev.xcds % (slices * 2) == 0 &&
+         row_bytes / (slices * 2) >= 128 && lanes_per_row % (slices * 2) == 0)
     slices *= 2;
   const int v = BackwardTuningCell(1).load(std::memory_order_relaxed);
-  if ((v == 1 || v == 2 || v == 4 || v == 8) && lanes_per_row % v == 0) slices = v;
+  if (v >= 1 && v <= dev.xcds && dev.xcds % v == 0 && lanes_per_row % v == 0) slices = v;
   return slices;
 }
 
 //! Launch shape of SegmentedScatterAddKernel (host arithmetic only).
 struct ScatterShape {
-  int slices, lanes, segments_per_block, segment_len;
+  int slices, lanes, segments_per_block, segment_len, xcds;
   int64_t nz_blocks, grid_blocks;
   size_t lds;
   //! Workgroups that walk `count` consecutive lookups (one launch), and the grid that holds them.
@@ -77,20 +81,22 @@ struct ScatterShape {
     return (num_segments + segments_per_block - 1) / segments_per_block;
   }
   int64_t GridBlocks(const int64_t blocks) const {
-    // one workgroup per (nz block, slice); with slices > 1 the 8 / slices XCDs that share a
-    // slice split the nz blocks, so the grid is a whole number of rounds of 8 workgroups
-    const int per_slice = slices > 1 ? 8 / slices : 1;
-    return slices > 1 ? (blocks + per_slice - 1) / per_slice * 8 : blocks;
+    // one workgroup per (nz block, slice); with slices > 1 the xcds / slices XCDs that share a
+    // slice split the nz blocks, so the grid is a whole number of rounds of `xcds` workgroups
+    const int per_slice = slices > 1 ? xcds / slices : 1;
+    return slices > 1 ? (blocks + per_slice - 1) / per_slice * xcds : blocks;
   }
 };
 
 template <typename GradT, typename IndexT, int N>
-inline ScatterShape PlanScatter(const int width, const int64_t nnz, const RowSplit split, const bool weighted) {
+inline ScatterShape PlanScatter(const int width, const int64_t nnz, const RowSplit split, const bool weighted,
+                                const DeviceShape& dev) {
   ScatterShape s;
-  s.slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row, nnz);
+  s.xcds = dev.xcds;
+  s.slices = ChooseColumnSlices(static_cast<size_t>(width) * sizeof(GradT), split.lanes_per_row, nnz, dev);
   s.lanes = split.lanes_per_row / s.slices;  // lanes of one column slice
   s.segments_per_block = s.lanes >= kDefaultBlockThreads ? 1 : kDefaultBlockThreads / s.lanes;
-  s.segment_len = ChooseSegmentLen(nnz, split.lanes_per_row);
+  s.segment_len = ChooseSegmentLen(nnz, split.lanes_per_row, dev);
   // Keep the staged COO triples of one workgroup within the LDS budget: shorten the
   // segments first (down to 32 lookups), then put fewer segments in a workgroup.
   while (ScatterStageBytes<GradT, IndexT>(s.segments_per_block, s.segment_len, s.lanes, N, weighted) >
@@ -118,7 +124,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const int64_t zero_rows /* ... and the rows from the last id up to here (<= 0: none) */,
                              const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */,
                              const int64_t sample_block_len = 0, const uint32_t* block_row_ids = nullptr) {
-  const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr);
+  const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr, CurrentDeviceShape());
   const dim3 block(s.lanes, s.segments_per_block, 1);
   const int block_len = s.segments_per_block * s.segment_len;
   const bool blocked = sample_block_len > 0 && sample_block_len < nnz;
@@ -143,7 +149,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
 #define CUEMBED_LAUNCH_SCATTER(W, BLK)                                                                            \
   SegmentedScatterAddKernel<GradT, IndexT, N, W, BLK><<<grid, block, s.lds, stream>>>(                              \
       grad_y, width, rows + first, sample_ids + first, (W) ? weights + first : weights, count, s.segment_len,        \
-      seg_shift, grad_out, s.slices, run_ids_p, inverse_mapping, pair_rows)
+      seg_shift, grad_out, s.slices, s.xcds, run_ids_p, inverse_mapping, pair_rows)
     const bool adds_to_rows = blocked && p > 0;   // (the first block finds nothing stored yet: plain kernel)
     if (weights != nullptr) {
       if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(true, true);
@@ -166,18 +172,25 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
  * batch_size x slice bytes -- 8.4 MB at C4 for 4 MiB of L2.  Returns 1 when nothing is to be gained.
  */
 template <typename GradT>
-inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, const int64_t nnz) {
+inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, const int64_t nnz,
+                                   const detail::DeviceShape& dev) {
   const size_t row_bytes = static_cast<size_t>(embed_width > 0 ? embed_width : 0) * sizeof(GradT);
   if (row_bytes == 0 || row_bytes % 4 != 0 || batch_size <= 0) return 1;   // nothing EmbeddingBackward would slice
   const int lane_bytes = row_bytes % 16 == 0 ? 16 : (row_bytes % 8 == 0 ? 8 : 4);   // as SplitRow for aligned buffers
-  const int slices = detail::ChooseColumnSlices(row_bytes, static_cast<int>(row_bytes / lane_bytes), nnz);
-  if (slices <= 1) return 1;   // small problems: grad_y is not sliced (and fits the L2s anyway)
+  if (nnz < (int64_t{1} << 20)) return 1;   // small problems: grad_y fits the L2s anyway
+  const int slices = detail::ChooseColumnSlices(row_bytes, static_cast<int>(row_bytes / lane_bytes), nnz, dev);
+  if (slices <= 1 && dev.xcds > 1) return 1;   // rows too narrow to slice: not measured, nothing recommended
   const size_t per_l2 = static_cast<size_t>(batch_size) * (row_bytes / slices);
-  const size_t budget = size_t{4} << 20;   // one XCD's L2
+  const size_t budget = dev.l2_bytes_per_xcd;   // one XCD's L2 (4 MiB on MI355X)
   size_t blocks = (per_l2 + budget - 1) / budget;
   if (blocks < 1) blocks = 1;
   if (blocks > 64) blocks = 64;   // what one Transpose call sorts separately (detail::kMaxSortSegments)
   return static_cast<int>(blocks);
+}
+//! ... for the current device.
+template <typename GradT>
+inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, const int64_t nnz) {
+  return RecommendedSampleBlocks<GradT>(embed_width, batch_size, nnz, detail::CurrentDeviceShape());
 }
 
 /**

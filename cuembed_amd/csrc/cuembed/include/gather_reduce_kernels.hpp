@@ -55,26 +55,26 @@ __device__ __forceinline__ _Float16 ShuffleElem(_Float16 v, int src, int width) 
   return __builtin_bit_cast(_Float16, static_cast<unsigned short>(bits));
 }
 
-//! XCD-aware work placement.  MI355X has 8 XCDs with private 4 MiB L2s and dispatches
-//! workgroup b to XCD b % 8 (observed, not contractual: only speed depends on it).  With
-//! `slices` > 1 a row is cut into `slices` column slices and workgroup b works on slice
-//! (b % 8) % slices of its samples, so that every L2 only ever caches 1/slices of each
-//! table row: the set of hot rows that fits an L2 grows `slices`-fold and a row that is
-//! needed by samples on different XCDs is fetched from the fabric once per slice instead
-//! of once per XCD.  The 8 / slices XCDs that share a slice split the samples.
+//! XCD-aware work placement.  An MI355X has 8 XCDs with private 4 MiB L2s and deals workgroup b of a 1-D grid to
+//! XCD b % xcds (observed, not contractual: only speed depends on it; `xcds` comes from the device,
+//! device_shape.hpp).  With `slices` > 1 (a divisor of xcds) a row is cut into `slices` column slices and
+//! workgroup b works on slice (b % xcds) % slices of its samples, so that every L2 only ever caches 1/slices of
+//! each row: the set of rows that fits an L2 grows `slices`-fold and a row that is needed by samples on different
+//! XCDs is fetched from the fabric once per slice instead of once per XCD.  The xcds / slices XCDs that share a
+//! slice split the samples.
 struct ColumnSlice {
   int slice;      //!< which column slice of the row this workgroup owns
   int64_t block;  //!< index of the workgroup's group of samples
-  static __device__ __forceinline__ ColumnSlice Of(unsigned block_idx, int slices) {
+  static __device__ __forceinline__ ColumnSlice Of(unsigned block_idx, int slices, int xcds = 8) {
     ColumnSlice c;
     if (slices <= 1) {
       c.slice = 0;
       c.block = block_idx;
     } else {
-      const int xcd = block_idx & 7;
-      const int per_slice = 8 / slices;  // XCDs sharing one slice
+      const int xcd = static_cast<int>(block_idx % static_cast<unsigned>(xcds));
+      const int per_slice = xcds / slices;  // XCDs sharing one slice
       c.slice = xcd % slices;
-      c.block = static_cast<int64_t>(block_idx >> 3) * per_slice + xcd / slices;
+      c.block = static_cast<int64_t>(block_idx / static_cast<unsigned>(xcds)) * per_slice + xcd / slices;
     }
     return c;
   }

@@ -45,6 +45,7 @@
 #include <type_traits>
 
 #include "cuembed/include/blocked_order.hpp"
+#include "cuembed/include/device_shape.hpp"
 
 namespace cuembed {
 namespace detail {
@@ -233,16 +234,17 @@ __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int wher
   }
 }
 
-//! Tile of workgroup b in the histogram and scatter passes.  Workgroups are dealt round-robin to the 8 XCDs (b % 8), so with
+//! Tile of workgroup b in the histogram and scatter passes.  Workgroups are dealt round-robin to the XCDs (b % xcds; 8 on a
+//! full MI355X, from the device: device_shape.hpp), so with
 //! tile = b neighbouring tiles -- whose 64-byte runs of a bin are neighbours in the output -- land on different,
 //! non-coherent L2s and each writes its half of a 128-byte line on its own.  This map keeps runs of tiles on one
 //! XCD (tile = (b % 8) * ceil(tiles / 8) + b / 8 while that is a tile, the identity for the ragged rest), so that
 //! halves written a few workgroups apart meet in that L2 before the line leaves it (the histogram pass writes ONE
 //! 4-byte word per bin and tile: 32 neighbouring tiles share a line).  Any bijection is correct.
-__device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles) {
-  const int per_xcd = num_tiles / 8;              // tiles of the rectangular part, per XCD
-  if (b >= per_xcd * 8) return b;                 // ragged rest (fewer than 8 tiles)
-  return (b & 7) * per_xcd + (b >> 3);
+__device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles, const int xcds) {
+  const int per_xcd = num_tiles / xcds;           // tiles of the rectangular part, per XCD
+  if (b >= per_xcd * xcds) return b;              // ragged rest (fewer than `xcds` tiles)
+  return (b % xcds) * per_xcd + (b / xcds);
 }
 
 //! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
@@ -255,7 +257,7 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
                          const SortMode mode, unsigned* __restrict__ tile_hist, const int num_tiles,
                          unsigned long long* __restrict__ tile_bits,
                          const unsigned long long* __restrict__ state,
-                         const unsigned long long* __restrict__ payload64) {
+                         const unsigned long long* __restrict__ payload64, const int xcds) {
   __shared__ unsigned count[kSortWaves][kSortBins];  // one sub-histogram per wave: 4x less contention
   __shared__ unsigned long long wave_bits[kSortWaves][kStateWords];
   const int tid = threadIdx.x;
@@ -272,7 +274,7 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
     high = static_cast<KeyT>(plan.key_high);
     where = RouteArray(plan, narrow).src;
   }
-  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles);
+  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles, xcds);
   const int64_t base = static_cast<int64_t>(tile) * kSortTile + tid;
   KeyT key[kSortItems];
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
@@ -529,7 +531,8 @@ __global__ void __launch_bounds__(kSortThreads, 4)
 RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
                    const int64_t n, const int pass, const int passes, const SortMode mode,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
-                   const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles) {
+                   const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles,
+                   const int xcds) {
   // which of (caller's input, caller's output, scratch) this pass reads and writes follows from
   // the passes that run at all and from how each array is stored in the scratch
   const PassPlan plan = PlanPass(state, pass, passes, mode);
@@ -550,7 +553,7 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles);
+  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles, xcds);
   const int64_t tile_base = static_cast<int64_t>(tile) * kSortTile;
   const int count = static_cast<int>(n - tile_base < kSortTile ? n - tile_base : kSortTile);
   // ---- load first (everything in flight at once): the digit bases below are computed under the loads' latency ----
@@ -816,16 +819,17 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   // segments (blocks sorted on their own): whole tiles each; one segment unless the caller asked for more
   const int segment_tiles = static_cast<int>(SortSegmentLength(n, blocks) / kSortTile);
   const int segments = (plan.num_tiles + segment_tiles - 1) / segment_tiles;
+  const int xcds = CurrentDeviceShape().xcds;   // tile maps keep runs of tiles on one XCD
   for (int p = 0; p < plan.passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
-        keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64);
+        keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64, xcds);
     const int scan_blocks = (fold_scan ? 0 : kSortBins * segments) + (p == 0 && device_state ? 1 : 0);
     if (scan_blocks > 0)
       RadixScanTilesKernel<<<scan_blocks, kSortThreads, 0, stream>>>(
           tile_hist, plan.num_tiles, bin_total, p, plan.passes, mode, tile_bits, state, segment_tiles);
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, v1, v2, count, p, plan.passes, mode, tile_hist, fold_scan ? nullptr : bin_total,
-        plan.num_tiles, state, segment_tiles);
+        plan.num_tiles, state, segment_tiles, xcds);
   }
 }
 

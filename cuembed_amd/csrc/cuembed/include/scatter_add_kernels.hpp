@@ -158,7 +158,8 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int segment_len,
                           const int segment_shift,  // log2(segment_len), or -1 when it is not a power of two
                           GradT* __restrict__ grad_out,
-                          const int column_slices,  // 1, 2, 4 or 8: see ColumnSlice
+                          const int column_slices,  // a divisor of xcds (1, 2, 4 or 8 on a full chip): see ColumnSlice
+                          const int xcds,           // XCDs of the device (workgroup b runs on XCD b % xcds)
                           const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
                           IndexT* __restrict__ inverse_mapping,      // ... and where the id of every run goes
                           const uint32_t* __restrict__ block_row_ids) {  // sample-blocked order: pair number -> row | bit
@@ -172,9 +173,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const int seg = threadIdx.y;
   const int segments_per_block = blockDim.y;
   const int block_len = segments_per_block * segment_len;
-  const ColumnSlice cs = ColumnSlice::Of(blockIdx.x, column_slices);
+  const ColumnSlice cs = ColumnSlice::Of(blockIdx.x, column_slices, xcds);
   const int64_t block_begin = cs.block * block_len;
-  if (block_begin >= nnz) return;  // the grid is rounded up to whole rounds of 8 workgroups
+  if (block_begin >= nnz) return;  // the grid is rounded up to whole rounds of `xcds` workgroups
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * lanes + lane_x) * N;
   const uint32_t id_mask = ~shared_row_bit;   // staged ids keep the bit (equal inside a run); addresses drop it
 

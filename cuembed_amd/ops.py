@@ -95,6 +95,24 @@ def forward_launch_shape(elem_dtype, index_dtype, embed_width, batch_size, num_h
                 grid=out[3], lds_bytes=out[4], staged=bool(out[5]))
 
 
+def device_shape():
+    """What the launch heuristics know about the current device (needs a GPU): compute units, XCDs, resident lanes
+    per compute unit, L2 bytes per XCD."""
+    out = (ctypes.c_int * 4)()
+    _lib.lib().cuembed_device_shape(out)
+    return dict(compute_units=out[0], xcds=out[1], lanes_per_cu=out[2], l2_bytes_per_xcd=out[3])
+
+
+def backward_launch_shape(elem_dtype, index_dtype, embed_width, nnz, is_weighted=False, compute_units=0, xcds=0):
+    """Launch shape EmbeddingBackward would use (pure host arithmetic when compute_units > 0 describes the device:
+    e.g. compute_units=32, xcds=1 for a CPX partition; 0 = ask the current device)."""
+    out = (ctypes.c_int * 8)()
+    _lib.lib().cuembed_backward_launch_shape(_ELEM[elem_dtype], _INDEX[index_dtype], embed_width, int(nnz),
+                                             int(is_weighted), int(compute_units), int(xcds), out)
+    return dict(column_slices=out[0], lanes=out[1], segments_per_block=out[2], segment_len=out[3], nz_blocks=out[4],
+                grid=out[5], lds_bytes=out[6], xcds=out[7])
+
+
 def embedding_forward(params, indices, offsets=None, weights=None, batch_size=None, num_hots=0,
                       mode="sum", fp16_math=False, out=None, reduction_order=None, row_loads=None):
     """out[s] = combine_j weights[s,j] * params[indices[s,j]].
@@ -364,11 +382,13 @@ def transpose_sample_block_length(nnz, sample_blocks):
     return int(_lib.lib().cuembed_transpose_sample_block_length(int(nnz), int(sample_blocks)))
 
 
-def recommended_sample_blocks(grad_dtype, embed_width, batch_size, nnz):
+def recommended_sample_blocks(grad_dtype, embed_width, batch_size, nnz, compute_units=0, xcds=0, l2_bytes_per_xcd=0):
     """How many sample blocks a transpose feeding a COMPRESSED EmbeddingBackward should use so that the part of
-    grad_y one L2 gathers from fits it (cuembed::RecommendedSampleBlocks; 1 = nothing to gain)."""
-    return int(_lib.lib().cuembed_recommended_sample_blocks(_ELEM[grad_dtype], int(embed_width), int(batch_size),
-                                                            int(nnz)))
+    grad_y one L2 gathers from fits it (cuembed::RecommendedSampleBlocks; 1 = nothing to gain).  For the current
+    device, or (compute_units > 0) for a described one."""
+    return int(_lib.lib().cuembed_recommended_sample_blocks_on(_ELEM[grad_dtype], int(embed_width), int(batch_size),
+                                                               int(nnz), int(compute_units), int(xcds),
+                                                               int(l2_bytes_per_xcd)))
 
 
 def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspace=None, num_categories=None,

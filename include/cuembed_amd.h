@@ -342,6 +342,19 @@ void cuembed_get_backward_tuning(int* out2);
 void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width, int batch_size,
                                   int num_hots, int is_csr, int is_weighted, int mode,
                                   int* out);
+/* What the launch heuristics know about the current device (read once per device id, cuembed::detail::DeviceShape;
+ * the reference queries the runtime per call, embedding_lookup.cuh:355-363): out[0] = compute units, out[1] = XCDs,
+ * out[2] = resident lanes per compute unit, out[3] = L2 bytes per XCD. */
+void cuembed_device_shape(int* out);
+/* Launch shape EmbeddingBackward would use (no launch): out[0] = XCD column slices, out[1] = lanes per slice,
+ * out[2] = nz-segments per workgroup, out[3] = lookups per segment, out[4] = workgroup ranges, out[5] = grid size,
+ * out[6] = dynamic LDS bytes, out[7] = XCDs assumed.  compute_units <= 0: the current device; > 0: a device of that
+ * many compute units in `xcds` XCDs (host arithmetic only: e.g. 32 CUs in 1 XCD = a CPX partition). */
+void cuembed_backward_launch_shape(int elem_type, int index_type, int embed_width, int64_t nnz, int is_weighted,
+                                   int compute_units, int xcds, int* out);
+/* cuembed_recommended_sample_blocks for a described device (compute_units <= 0: the current one). */
+int cuembed_recommended_sample_blocks_on(int elem_type, int embed_width, int batch_size, int64_t nnz,
+                                         int compute_units, int xcds, int64_t l2_bytes_per_xcd);
 /* hipPeekAtLastError() as an int (0 = hipSuccess); launches themselves never
  * report errors, exactly like the reference. */
 int cuembed_peek_last_error(void);

@@ -60,6 +60,34 @@ def test_launch_shapes_of_baseline_configs():
     assert ce.forward_launch_shape(torch.float32, torch.int32, 3, 8, 4)["elems_per_lane"] == 1
 
 
+def test_backward_planner_follows_the_device_it_is_told_about():
+    """The launch heuristics take the chip's shape from the device (cuembed::detail::DeviceShape; the reference asks
+    the runtime per call, embedding_lookup.cuh:348-395) instead of assuming a full MI355X.  Host arithmetic only:
+    a full chip (256 CUs, 8 XCDs), a CPX partition (32 CUs, 1 XCD) and a DPX half (128 CUs, 4 XCDs)."""
+    import torch
+    import cuembed_amd as ce
+    nnz = 65536 * 64
+    full = ce.backward_launch_shape(torch.float16, torch.int32, 256, nnz, compute_units=256, xcds=8)
+    assert (full["column_slices"], full["lanes"], full["segment_len"], full["xcds"]) == (4, 8, 64, 8)
+    assert full["grid"] % 8 == 0 and full["grid"] == full["nz_blocks"] * 4       # one workgroup per (nz block, slice)
+    cpx = ce.backward_launch_shape(torch.float16, torch.int32, 256, nnz, compute_units=32, xcds=1)
+    assert (cpx["column_slices"], cpx["lanes"], cpx["xcds"]) == (1, 32, 1)       # one L2: XCD slicing is meaningless
+    assert cpx["grid"] == cpx["nz_blocks"] and cpx["segment_len"] == 128         # 1/8 of the lanes to fill: long segments
+    dpx = ce.backward_launch_shape(torch.float16, torch.int32, 256, nnz, compute_units=128, xcds=4)
+    assert dpx["column_slices"] == 4 and dpx["grid"] % 4 == 0 and dpx["xcds"] == 4
+    wide = ce.backward_launch_shape(torch.float32, torch.int32, 256, nnz, compute_units=256, xcds=8)
+    assert wide["column_slices"] == 8                                             # 1 KiB rows: one slice per XCD
+    assert ce.backward_launch_shape(torch.float32, torch.int32, 256, nnz, compute_units=128, xcds=4)["column_slices"] == 4
+    # few lookups: segments shrink until 40 % of the DEVICE's lanes are busy -- sooner on a small device
+    few = 32768
+    assert ce.backward_launch_shape(torch.float16, torch.int32, 256, few, compute_units=256, xcds=8)["segment_len"] < \
+        ce.backward_launch_shape(torch.float16, torch.int32, 256, few, compute_units=32, xcds=1)["segment_len"]
+    # sample blocks: what one L2 fronts while a block is scattered must fit it
+    assert ce.recommended_sample_blocks(torch.float16, 256, 65536, nnz, 256, 8, 4 << 20) == 2
+    assert ce.recommended_sample_blocks(torch.float16, 256, 65536, nnz, 32, 1, 4 << 20) == 8   # unsliced: 33.5 MB / 4 MiB
+    assert ce.recommended_sample_blocks(torch.float16, 256, 65536, nnz, 256, 8, 16 << 20) == 1
+
+
 def test_host_layer_refuses_cpu_tensors_and_bad_contracts():
     import torch
     import cuembed_amd as ce
