@@ -169,6 +169,16 @@ inline ForwardLaunch PlanForward(const int embed_width, const void* params, cons
       f.stage_bytes = rows * per_sample;
     }
   }
+  if (is_csr && !concat && f.split.lanes_per_row <= 64 && 64 % f.split.lanes_per_row == 0) {
+    // CSR bags differ in length and nothing is shared inside a workgroup (no LDS, no barrier: the lanes of a bag hand
+    // indices to each other across lanes): ONE wavefront per workgroup, so that a wavefront's slot is free as soon as
+    // ITS bags are pooled instead of when the longest of a 256-thread workgroup's 8 bags is (C3: 0.187 -> 0.175 ms;
+    // two wavefronts measure the same, four are the old shape).  Giving a wavefront SEVERAL bags per lane group and
+    // pooling them in order of length (ranked in registers) was measured and loses: 4 / 8 / 16 / 32 bags per
+    // wavefront 0.180 / 0.198 / 0.199 / 0.292 ms -- fewer, longer-lived wavefronts and one exposed offset + index
+    // latency per bag in sequence cost more than the lockstep of two unequal bags (docs/EXPERIMENTS.md).
+    f.split.rows_per_block = 64 / f.split.lanes_per_row;
+  }
   f.grid = static_cast<unsigned>((batch + f.split.rows_per_block - 1) / f.split.rows_per_block);
   return f;
 }

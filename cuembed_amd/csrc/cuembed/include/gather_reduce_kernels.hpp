@@ -292,6 +292,26 @@ struct RowPool {
   }
 };
 
+//! Epilogue of one pooled row: mean scaling (reference combiner, embedding_lookup_ops.cuh:273-285: scale by the
+//! reciprocal of the accumulated weight; zeros when that is 0), conversion, non-temporal store.
+template <typename ElemT, typename AccT, int N, bool kWeighted>
+__device__ __forceinline__ void FinishPooledRow(RowPool<ElemT, AccT, N, kWeighted>& pool, const int hot,
+                                                const bool is_mean, ElemT* dst) {
+  using A = Arith<AccT>;
+  if (is_mean) {
+    float weight_sum = pool.weight_sum;
+    if constexpr (!kWeighted) weight_sum = static_cast<float>(hot);
+    const float inv = (weight_sum == 0.f) ? 0.f : 1.0f / weight_sum;
+    const AccT scale = static_cast<AccT>(inv);
+#pragma unroll
+    for (int e = 0; e < N; ++e) pool.acc[e] = A::mul(pool.acc[e], scale);
+  }
+  Pack<ElemT, N> result;
+#pragma unroll
+  for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
+  StorePackStreaming<ElemT, N>(dst, result);
+}
+
 // ---------------------------------------------------------------------------
 // Sum / mean.
 //   block = (lanes_per_row, samples_per_block); grid = ceil(batch / samples_per_block)
@@ -406,20 +426,7 @@ GatherReduceKernel(const ElemT* __restrict__ table,
   }
 
   // ---- epilogue -----------------------------------------------------------
-  if (is_mean) {
-    // Reference combiner (embedding_lookup_ops.cuh:273-285): scale by the
-    // reciprocal of the accumulated weight; zeros when that is 0.
-    float weight_sum = pool.weight_sum;
-    if constexpr (!kWeighted) weight_sum = static_cast<float>(hot);
-    const float inv = (weight_sum == 0.f) ? 0.f : 1.0f / weight_sum;
-    const AccT scale = static_cast<AccT>(inv);
-#pragma unroll
-    for (int e = 0; e < N; ++e) pool.acc[e] = A::mul(pool.acc[e], scale);
-  }
-  Pack<ElemT, N> result;
-#pragma unroll
-  for (int e = 0; e < N; ++e) result.v[e] = static_cast<ElemT>(pool.acc[e]);
-  StorePackStreaming<ElemT, N>(out + sample * width + column0, result);
+  FinishPooledRow<ElemT, AccT, N, kWeighted>(pool, hot, is_mean, out + sample * width + column0);
 }
 
 // ---------------------------------------------------------------------------

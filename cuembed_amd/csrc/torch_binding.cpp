@@ -222,9 +222,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> cuembed_transpose_sample_ids_op(c
   return TransposeImpl(sample_ids, indices, weights, IndexBits(num_categories), 31);
 }
 
-// Transpose in blocks of samples (cuembed::Transpose, sample_blocks): for the compressed gradient only -- the
-// result is an UNCOALESCED compressed gradient, one row per (block, table row).  sample_blocks <= 0: the
-// library's recommendation for a gradient of `grad_width` elements of `grad_elem_size` bytes per sample.
+// Transpose in blocks of samples (cuembed::Transpose, sample_blocks): for the compressed gradient only -- with the
+// plain remap the result is an UNCOALESCED compressed gradient, one row per (block, table row).  sample_blocks is
+// forwarded as given (<= 1: one block, the reference's fully sorted order); the caller asks
+// cuembed_recommended_sample_blocks for a recommendation (cuembed_pyt.py does).
 std::tuple<at::Tensor, at::Tensor, at::Tensor> cuembed_transpose_sample_blocks_op(const at::Tensor& sample_ids,
                                                                                const at::Tensor& indices,
                                                                                const at::Tensor& weights,

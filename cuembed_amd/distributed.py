@@ -15,6 +15,8 @@ tests (with the compute injected) and on RCCL in production.  When the process g
 cannot take device tensors (gloo; e.g. several ranks sharing one GPU, where RCCL refuses to build
 a communicator) device tensors are staged through host copies around each collective.
 """
+import os
+
 import torch
 
 
@@ -171,7 +173,8 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     are not ascending / not unique -- the uncoalesced gradient of a batch that was transposed in sample
     blocks (ops.transpose(..., sample_blocks=)): the owner-partitioned exchange then merges the rank's own
     rows first (one more Transpose + EmbeddingBackward over its rows; it also sends fewer rows), the
-    all-gather exchange takes them as they are.  Returns (unique_ids, summed_rows), identical on every
+    all-gather exchange takes them as they are.  (CUEMBED_DEBUG_CHECKS=1 makes the owner algorithm verify
+    that ids passed as coalesced really ascend.)  Returns (unique_ids, summed_rows), identical on every
     rank.  Two algorithms:
 
       "allgather": every rank all-gathers all (id, row) pairs and merges them locally with one
@@ -219,6 +222,12 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     if num_unique is not None:       # rows past the count hold nothing: give them an id beyond every range
         valid = torch.arange(ids.numel(), device=ids.device) < num_unique.reshape(1).to(ids.device)
         ids = torch.where(valid, ids, torch.full_like(ids, num_categories))
+    if os.environ.get("CUEMBED_DEBUG_CHECKS") == "1" and ids.numel() > 1:
+        # the owner ranges are cut out of ASCENDING ids; an uncoalesced gradient (sample blocks) passed with the
+        # default coalesced=True would be split wrongly without any error (one host read-back, debug only)
+        if not bool((ids[1:] >= ids[:-1]).all().item()):
+            raise ValueError("allreduce_sparse_grad(algorithm='owner'): ids are not ascending; pass coalesced=False "
+                             "for the gradient of a batch that was transposed in sample blocks")
     pos = torch.searchsorted(ids, cuts)                      # ids ascend: range r = [pos[r], pos[r+1])
     send = (pos[1:] - pos[:-1]).to(torch.int64)
     # every rank learns the whole world x world split matrix with ONE collective and ONE host read-back

@@ -64,11 +64,7 @@ def pick(disp, substr, counter):
     return [c[counter] for _, n, c in disp if substr in n and counter in c]
 
 
-ROWS = []   # (kernel tag, FETCH_SIZE KiB, WRITE_SIZE KiB, dispatches) of every entry, for --rows-out
-
-
 def entry(fetch_kb, write_kb, launches, kernel):
-    ROWS.append((kernel, fetch_kb, write_kb, launches))
     e = {"kernel": kernel, "launches_averaged": launches,
          "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb}
     if fetch_kb is not None and write_kb is not None:
@@ -161,11 +157,13 @@ def main():
         json.dump(res, f, indent=1)
         f.write("\n")
     if a.rows_out:
-        names = [k for k in K]                    # entries were created in the order of ROWS
-        with open(a.rows_out, "a") as f:
-            for name, (kernel, fk, wk, n) in zip(names, ROWS):
+        with open(a.rows_out, "a") as f:          # (from the entries themselves: no reliance on creation order)
+            for name, e in K.items():
+                if not isinstance(e, dict) or e.get("fetch_size_kb_per_launch") is None:
+                    continue
                 f.write("traffic_row %s %s FETCH_SIZE_KiB=%.4f WRITE_SIZE_KiB=%.4f dispatches=%d kernel=%s\n"
-                        % (os.path.basename(a.out), name, fk, wk, n, kernel.replace(" ", "_")))
+                        % (os.path.basename(a.out), name, e["fetch_size_kb_per_launch"], e["write_size_kb_per_launch"],
+                           e["launches_averaged"], e["kernel"].replace(" ", "_")))
     print(json.dumps(res, indent=1))
 
 
