@@ -214,10 +214,13 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     indices = (k * torch.rand(n, device="cuda") ** 3).long()
     up = torch.randint(-1, 2, (B, d), device="cuda").half()
     grads = {}
-    for kind in (True, "uncoalesced"):
+    for kind in (True, "uncoalesced", "blocked"):
         weight.grad = None
         (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=kind) * up).sum().backward()
         grads[kind] = weight.grad
+    # "blocked": the coalesced gradient computed from the same sample-blocked order -- identical tensors
+    assert torch.equal(grads["blocked"]._indices(), grads[True]._indices())
+    assert torch.equal(grads["blocked"]._values(), grads[True]._values())
     ids = grads[True]._indices()[0]
     assert (ids[1:] > ids[:-1]).all()                                # coalesced: ascending, no duplicates
     assert not grads["uncoalesced"].is_coalesced()
