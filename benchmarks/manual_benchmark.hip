@@ -58,7 +58,9 @@ struct Flags {
        weighted_sum = false, fp16_math = false, compressed_grad = true, skip_grad_init = true,
        forward_only = false, enable_csv = false, enable_stderr = true, clear_caches = true,
        bounded_sort = false,      // extension: Transpose sorts ceil(log2(num_categories)) key bits only
-       fused_row_ids = false;     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
+       fused_row_ids = false,     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
+       coalesce_blocks = false;   // extension: with --sample_blocks, the REFERENCE's compressed gradient from the blocked
+                                  // order (ComputeCompressedGradIndicesBlocked + EmbeddingBackward(sample_blocks))
 };
 
 bool ParseBool(const std::string& v) { return v.empty() || v == "1" || v == "true" || v == "True" || v == "yes"; }
@@ -91,6 +93,7 @@ Flags ParseFlags(int argc, char** argv) {
   getb("enable_stderr", &f.enable_stderr); getb("clear_caches", &f.clear_caches);
   getb("bounded_sort", &f.bounded_sort);
   getb("fused_row_ids", &f.fused_row_ids);
+  getb("coalesce_blocks", &f.coalesce_blocks);
   geti("sample_blocks", &f.sample_blocks);
   for (auto& e : kv) {
     std::fprintf(stderr, "unknown flag --%s\n", e.first.c_str());
@@ -231,6 +234,8 @@ struct Workload {
       transpose_sample_ids, inverse_mapping;
   DeviceBuffer<OffsetT> offsets;
   DeviceBuffer<char> workspace;
+  DeviceBuffer<uint32_t> block_row_ids, num_unique_dev;   // --coalesce_blocks
+  int blocks = 1;                                          // sample blocks of the last transpose
   size_t lwork = 0;
 };
 
@@ -271,7 +276,12 @@ void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
   else
     cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, weights, nnz, w.transpose_indices.ptr,
                                       w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits, 0, blocks);
-  if (w.f.compressed_grad)
+  w.blocks = blocks;
+  if (w.f.compressed_grad && w.f.coalesce_blocks)
+    cuembed::ComputeCompressedGradIndicesBlocked<IndexT>(w.transpose_indices.ptr, nnz, blocks,
+                                                         w.transpose_remapped_indices.ptr, w.block_row_ids.ptr,
+                                                         w.num_unique_dev.ptr, w.workspace.ptr, &lwork);
+  else if (w.f.compressed_grad)
     cuembed::ComputeCompressedGradIndices<IndexT>(w.transpose_indices.ptr, nnz,
                                                   w.transpose_remapped_indices.ptr, w.workspace.ptr, &lwork);
 }
@@ -283,7 +293,8 @@ void RunBackward(Workload<ElemT, IndexT, OffsetT>& w, int num_unique) {
       static_cast<int>(w.nnz), w.transpose_indices.ptr, w.transpose_sample_ids.ptr,
       w.f.compressed_grad ? w.transpose_remapped_indices.ptr : nullptr,
       w.f.weighted_sum ? w.transpose_weights.ptr : nullptr, w.f.skip_grad_init, w.grad_embedding.ptr,
-      w.f.compressed_grad ? w.inverse_mapping.ptr : nullptr);
+      w.f.compressed_grad ? w.inverse_mapping.ptr : nullptr, 0,
+      (w.f.compressed_grad && w.f.coalesce_blocks) ? w.blocks : 1, w.block_row_ids.ptr);
 }
 
 struct Timer {
@@ -418,6 +429,16 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
   cuembed::ComputeCompressedGradIndices<IndexT>(w.transpose_indices.ptr, static_cast<int>(w.nnz),
                                                 w.transpose_remapped_indices.ptr, nullptr, &lw_c);
   w.lwork = lw_t > lw_c ? lw_t : lw_c;
+  if (f.coalesce_blocks && f.compressed_grad) {
+    int blocks = f.sample_blocks > 0 ? f.sample_blocks
+                                     : cuembed::RecommendedSampleBlocks<ElemT>(f.embed_width, f.batch_size, w.nnz);
+    size_t lw_b = 0;
+    cuembed::ComputeCompressedGradIndicesBlocked<IndexT>(w.transpose_indices.ptr, static_cast<int>(w.nnz), blocks,
+                                                         w.transpose_remapped_indices.ptr, nullptr, nullptr, nullptr, &lw_b);
+    w.lwork = w.lwork > lw_b ? w.lwork : lw_b;
+    w.block_row_ids.Resize(w.nnz);
+    w.num_unique_dev.Resize(1);
+  }
   w.workspace.Resize(w.lwork);
   ms = timer.Run(f.iterations, [&] { RunTranspose<ElemT, IndexT, OffsetT>(w); });
   double tb = nnz * sizeof(IndexT) + (f.csr_input ? nnz * sizeof(OffsetT) : 0) + (f.weighted_sum ? nnz * es : 0) +
@@ -458,7 +479,11 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
 
   // ---- backward ----
   int num_unique = 0;
-  if (f.compressed_grad) {
+  if (f.compressed_grad && f.coalesce_blocks) {   // (a blocked order's last id is not the largest)
+    uint32_t nu = 0;
+    HIP_OK(hipMemcpy(&nu, w.num_unique_dev.ptr, sizeof nu, hipMemcpyDeviceToHost));
+    num_unique = static_cast<int>(nu);
+  } else if (f.compressed_grad) {
     IndexT last = 0;
     HIP_OK(hipMemcpy(&last, w.transpose_remapped_indices.ptr + (w.nnz - 1), sizeof(IndexT), hipMemcpyDeviceToHost));
     num_unique = static_cast<int>(last) + 1;
@@ -476,6 +501,7 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
   HIP_OK(hipMemcpy(h_t.data(), w.transpose_indices.ptr, w.nnz * sizeof(IndexT), hipMemcpyDeviceToHost));
   int64_t uniq = w.nnz > 0 ? 1 : 0;
   for (int64_t i = 1; i < w.nnz; ++i) uniq += h_t[i] != h_t[i - 1];
+  if (f.compressed_grad && f.coalesce_blocks) uniq = num_unique;   // (one gradient row per table row, not per run)
   double dram = es * W * uniq + 2.0 * sizeof(IndexT) * nnz + (f.weighted_sum ? es * nnz : 0) + es * W * B;
   double l2 = dram + es * W * nnz;
   std::fprintf(stderr, "Backward. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "

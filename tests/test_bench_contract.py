@@ -65,11 +65,13 @@ def test_roofline_entries_are_fractions():
 
 
 def test_traffic_files_follow_from_the_committed_counter_rows():
-    """profiles/r03_traffic_rows.txt holds the per-pass averages (KiB per dispatch) of the last refresh, written in
+    """profiles/rNN_traffic_rows.txt (the newest) holds the per-pass averages (KiB per dispatch) of the last refresh, written in
     the same run as the JSON files bench.py reads and committed next to the rocprofv3 pass summaries: every
     hbm_bytes_per_launch must be (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 of its row, within 0.5 %."""
+    import glob
     rows = {}
-    with open(os.path.join(ROOT, "profiles", "r03_traffic_rows.txt")) as f:
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_rows.txt")))[-1]     # the last refresh's
+    with open(latest) as f:
         for ln in f:
             parts = ln.split()
             if parts and parts[0] == "traffic_row":
@@ -87,7 +89,7 @@ def test_traffic_files_follow_from_the_committed_counter_rows():
             seen += 1
     assert seen >= 6      # forward c2 / alpha 0 / calibration, backward c4, transpose c4, forward c3
     # the same numbers are in the committed pass summaries (kernel-level averages over ALL dispatches of a pass)
-    summary = open(os.path.join(ROOT, "profiles", "r03_pmc_passes_forward_pipeline_c3.txt")).read()
+    summary = open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_passes_forward_pipeline_c3.txt")))[-1]).read()
     for tag in ("#### pmc_fwd_fetch", "#### pmc_pipe_write", "#### pmc_c3_fetch", "SegmentedScatterAddKernel", "FETCH_SIZE"):
         assert tag in summary
 

@@ -11,7 +11,7 @@ python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2> "$O/bench.err
 C2="--num_categories 10000000 --embed_width 256 --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true"
 C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 --hotness 128 --csr_input=true --weighted_sum=true"
 {
-  for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--bounded_sort --fused_row_ids --sample_blocks 0" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
+  for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--bounded_sort --fused_row_ids --sample_blocks 0" "--bounded_sort --fused_row_ids --sample_blocks 0 --coalesce_blocks" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
     echo "== C2/C4 $ex"; benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
   for ex in "" "--bounded_sort" "--bounded_sort --sample_blocks 0"; do
@@ -20,15 +20,19 @@ C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 
 } > "$O/manual_benchmark_c2_c3.txt"
 python tools/secondary_kernels.py > "$O/secondary_kernels.txt" 2>&1
 python benchmarks/train_step_benchmark.py --exchange none > "$O/train_step_none.json" 2> "$O/train_step.err"
-python benchmarks/train_step_benchmark.py --exchange none --sample_blocks 1 >> "$O/train_step_none.json" 2>> "$O/train_step.err"
+python benchmarks/train_step_benchmark.py --exchange none --order reference >> "$O/train_step_none.json" 2>> "$O/train_step.err"
+python benchmarks/train_step_benchmark.py --exchange none --order blocked >> "$O/train_step_none.json" 2>> "$O/train_step.err"
 python benchmarks/train_step_benchmark.py --exchange none --reference_api >> "$O/train_step_none.json" 2>> "$O/train_step.err"
 python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_native_binding.jsonl" 2> "$O/torch_probe.err"
+python tools/torch_sparse_orders_probe.py > "$O/torch_sparse_orders_probe.json" 2>> "$O/torch_probe.err"
+python tools/bwd_blocked_coalesced_probe.py 2 3 4 > "$O/bwd_blocked_coalesced_probe.json" 2>> "$O/torch_probe.err"
+python tools/c3_balance_probe.py > "$O/c3_balance_probe.json" 2>> "$O/torch_probe.err"
 CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_python_ctypes_ops.jsonl" 2>> "$O/torch_probe.err"
 python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
 python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
 # profiler passes last (they clock lower); the program goes directly after `--`
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-cpu-baseline > "$O/prof_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-c5 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pipeline" -- "$R/benchmarks/manual_benchmark" $C2 --iterations 10 --clear_caches=false > "$O/prof_pipeline.log" 2>&1
 cd "$R"
 python tools/rocprof_summary.py "$O/prof_bench" > "$O/bench_c2_kernel_trace_stats.txt" 2>/dev/null
@@ -51,10 +55,15 @@ PB="$PP --bounded_sort --fused_row_ids --sample_blocks 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_blocks_fetch" -- $PB >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_blocks_write" -- $PB >> "$O/pmc_pipe.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_blocks_tcc" -- $PB >> "$O/pmc_pipe.log" 2>&1
+# ... and with the reference's compressed gradient computed from that order (one scatter launch per block)
+PC2="$PB --coalesce_blocks"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_coal_fetch" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_coal_write" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_coal_tcc" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
 cd "$R"
 # C3 (fp32 weighted CSR forward): bench.py itself is the profiled program -- every GatherReduceKernel dispatch is a C3 launch
 cd /tmp
-PC="python3 $R/bench.py --workload c3 --steps 10 --warmup 0 --preroll-ms 0 --no-extras --no-cpu-baseline"
+PC="python3 $R/bench.py --workload c3 --steps 10 --warmup 0 --no-extras --no-c5 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_c3_fetch" -- $PC > "$O/pmc_c3.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_c3_write" -- $PC >> "$O/pmc_c3.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_c3_tcc" -- $PC >> "$O/pmc_c3.log" 2>&1
@@ -64,16 +73,17 @@ python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" -
   --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
   --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" \
   --blocks-fetch "$O/pmc_blocks_fetch" --blocks-write "$O/pmc_blocks_write" --blocks-tcc "$O/pmc_blocks_tcc" \
+  --coalesced-fetch "$O/pmc_coal_fetch" --coalesced-write "$O/pmc_coal_write" --coalesced-tcc "$O/pmc_coal_tcc" \
   --out "$O/traffic_c2.json" --rows-out "$O/traffic_rows.txt" > /dev/null
 python tools/traffic_from_pmc.py --c3-fetch "$O/pmc_c3_fetch" --c3-write "$O/pmc_c3_write" --c3-tcc "$O/pmc_c3_tcc" \
   --workload "c3 (fp32 weighted sum, CSR bags U[0,128], 10Mx128, batch 65536)" \
   --out "$O/traffic_c3.json" --rows-out "$O/traffic_rows.txt" > /dev/null
 {
-  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc pmc_blocks_fetch pmc_blocks_write pmc_blocks_tcc pmc_c3_fetch pmc_c3_write pmc_c3_tcc; do
+  for d in pmc_fwd_fetch pmc_fwd_write pmc_fwd_tcc pmc_pipe_fetch pmc_pipe_write pmc_pipe_tcc pmc_blocks_fetch pmc_blocks_write pmc_blocks_tcc pmc_coal_fetch pmc_coal_write pmc_coal_tcc pmc_c3_fetch pmc_c3_write pmc_c3_tcc; do
     echo "#### $d"; python tools/rocprof_summary.py "$O/$d" 2>/dev/null
   done
 } > "$O/pmc_passes.txt"
-rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_blocks_* "$O"/pmc_c3_fetch "$O"/pmc_c3_write "$O"/pmc_c3_tcc
+rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_blocks_* "$O"/pmc_coal_* "$O"/pmc_c3_fetch "$O"/pmc_c3_write "$O"/pmc_c3_tcc
 # SQ issue / wait counters of the same pipeline (two passes of 8 counters)
 bash tools/pmc_sq_pass.sh > /dev/null 2>&1 && cp "$R/gpurun_out/pmc_sq.txt" "$O/pmc_sq_pipeline.txt"
 # the bench line again, now with roofline.traffic from the traffic file measured above

@@ -75,8 +75,10 @@ def entry(fetch_kb, write_kb, launches, kernel):
 def main():
     p = argparse.ArgumentParser()
     for k in ("forward-fetch", "forward-write", "forward-tcc", "pipeline-fetch", "pipeline-write",
-              "pipeline-tcc", "pipeline-trace", "c3-fetch", "c3-write", "c3-tcc", "blocks-fetch", "blocks-write", "blocks-tcc"):
+              "pipeline-tcc", "pipeline-trace", "c3-fetch", "c3-write", "c3-tcc", "blocks-fetch", "blocks-write", "blocks-tcc",
+              "coalesced-fetch", "coalesced-write", "coalesced-tcc"):
         p.add_argument("--" + k)
+    p.add_argument("--coalesced-launches-per-call", type=int, default=2)
     p.add_argument("--iters", type=int, default=0, help="launches per pattern in the forward passes")
     p.add_argument("--expected-unique-read-bytes", type=int, default=65536 * 64 * 512)
     p.add_argument("--workload", default="c2 (fp16 sum, 10Mx256, batch 65536, hotness 64, alpha 1.15) + its C4 backward")
@@ -153,6 +155,20 @@ def main():
             tb = read_counters(a.blocks_tcc)
             h, m = avg(pick(tb, "SegmentedScatterAddKernel", "TCC_HIT_sum")), avg(pick(tb, "SegmentedScatterAddKernel", "TCC_MISS_sum"))
             K["backward_c4_sample_blocks"]["l2"] = {"TCC_HIT_sum": h, "TCC_MISS_sum": m, "hit_rate": round(h / (h + m), 4)}
+    if a.coalesced_fetch and a.coalesced_write:
+        # the blocked order with the REFERENCE's compressed gradient (--coalesce_blocks): one scatter launch per sample
+        # block; the bytes of one EmbeddingBackward call are those of its launches together
+        cf = pick(read_counters(a.coalesced_fetch), "SegmentedScatterAddKernel", "FETCH_SIZE")
+        cw = pick(read_counters(a.coalesced_write), "SegmentedScatterAddKernel", "WRITE_SIZE")
+        per_call = a.coalesced_launches_per_call
+        calls = max(len(cf) // per_call, 1)
+        K["backward_c4_blocked_coalesced"] = entry(sum(cf) / calls, sum(cw) / calls, calls,
+                                                   "SegmentedScatterAddKernel x %d (one per sample block)" % per_call)
+        if a.coalesced_tcc:
+            tb = read_counters(a.coalesced_tcc)
+            h, m = sum(pick(tb, "SegmentedScatterAddKernel", "TCC_HIT_sum")), sum(pick(tb, "SegmentedScatterAddKernel", "TCC_MISS_sum"))
+            K["backward_c4_blocked_coalesced"]["l2"] = {"TCC_HIT_sum": h / calls, "TCC_MISS_sum": m / calls,
+                                                        "hit_rate": round(h / (h + m), 4)}
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
         f.write("\n")
