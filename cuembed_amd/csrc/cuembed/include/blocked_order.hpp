@@ -4,17 +4,19 @@
 // Transpose(..., sample_blocks = P) cuts the sample-major input into consecutive blocks of
 // SampleBlockLength() lookups and sorts every block on its own.  While EmbeddingBackward scatters a
 // block, each L2 gathers from 1 / P of grad_y only (C4: 8.4 MB -> 4.2 MB per 4 MiB L2, the cliff of
-// DESIGN.md 3.3).  A table row that is looked up from several blocks has one run per block.  Two
+// docs/EXPERIMENTS.md).  A table row that is looked up from several blocks has one run per block.  Two
 // ways to turn that into a compressed gradient:
 //   * uncoalesced (round 3): ComputeCompressedGradIndices over the blocked array -> one gradient row
 //     per (block, table row);
-//   * coalesced (this file's constants): ComputeCompressedGradIndicesBlocked gives every lookup the
-//     id the REFERENCE's fully sorted order would give it (the rank of its table row among all
-//     distinct rows of the batch), plus kSharedRowBit when the same table row already occurred in
-//     an EARLIER block.  EmbeddingBackward(..., sample_blocks = P) then scatters block after block
-//     (stream-ordered launches): a run without the bit ends in a plain store as always, a run with
-//     it is ADDED (hardware float atomic, no return value) to what the earlier blocks stored.  The
-//     result has the reference's layout: num_unique ascending rows, the same inverse_mapping.
+//   * coalesced (this file's constants): ComputeCompressedGradIndicesBlocked numbers the (block, table
+//     row) pairs -- that is the remapped array -- and gives every pair, in a table of its own, the id the
+//     REFERENCE's fully sorted order would give its table row (the rank of the row among all distinct rows
+//     of the batch), plus kSharedRowBit when the same table row already occurred in an EARLIER block.
+//     EmbeddingBackward(..., sample_blocks = P, block_row_ids) then scatters block after block
+//     (stream-ordered launches; the staging translates pair -> row): a run without the bit ends in a plain
+//     store as always, a run with it is ADDED to what the earlier blocks stored (read-modify-write inside a
+//     workgroup, float atomics across workgroups).  The result has the reference's layout: num_unique
+//     ascending rows, the same inverse_mapping.
 #ifndef CUEMBED_INCLUDE_BLOCKED_ORDER_HPP_
 #define CUEMBED_INCLUDE_BLOCKED_ORDER_HPP_
 

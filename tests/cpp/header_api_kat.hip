@@ -66,6 +66,15 @@ void Expect(const char* what, const std::vector<T>& got, std::initializer_list<f
     std::fprintf(stderr, "MISMATCH %s\n", what);
   }
 }
+template <typename T, typename U>
+void ExpectAll(const char* what, const std::vector<T>& got, const std::vector<U>& want) {
+  bool ok = got.size() == want.size();
+  for (size_t i = 0; ok && i < got.size(); ++i) ok = static_cast<double>(got[i]) == static_cast<double>(want[i]);
+  if (!ok) {
+    ++g_failures;
+    std::fprintf(stderr, "MISMATCH %s\n", what);
+  }
+}
 template <typename T>
 void ExpectInt(const char* what, const std::vector<T>& got, std::initializer_list<long long> want) {
   bool ok = got.size() == want.size();
@@ -245,6 +254,37 @@ void ExtensionTransposeKat(hipStream_t stream) {
       std::fprintf(stderr, "FAIL: transpose in sample blocks\n");
       ++g_failures;
     }
+    // ... and the REFERENCE's compressed gradient from that blocked order: every key 0..999 occurs 200 times (100 per
+    // block), grad_y is all ones -> 1000 ascending rows of 200s, inverse_mapping = 0..999
+    const int width = 4, samples = n / 4;
+    DeviceArray<float> gy(std::vector<float>(static_cast<size_t>(samples) * width, 1.0f));
+    DeviceArray<IndexT> pairs(n), inv(1000);
+    DeviceArray<uint32_t> pair_rows(n), num_unique(1);
+    DeviceArray<float> grad(1000 * width);
+    size_t lb = 0;
+    cuembed::ComputeCompressedGradIndicesBlocked<IndexT>(o_keys.ptr, n, blocks, pairs.ptr, pair_rows.ptr, num_unique.ptr,
+                                                         nullptr, &lb, stream);
+    DeviceArray<char> work4(lb);
+    cuembed::ComputeCompressedGradIndicesBlocked<IndexT>(o_keys.ptr, n, blocks, pairs.ptr, pair_rows.ptr, num_unique.ptr,
+                                                         work4.ptr, &lb, stream);
+    const float* no_weights = nullptr;
+    cuembed::EmbeddingBackward<float, IndexT>(gy.ptr, width, 1000, n, o_keys.ptr, o_rows.ptr, pairs.ptr, no_weights,
+                                              /*skip_grad_init=*/false, grad.ptr, inv.ptr, stream, blocks, pair_rows.ptr);
+    HIP_OK(hipStreamSynchronize(stream));
+    ExpectInt("blocked remap: num_unique", num_unique.host(), {1000});
+    std::vector<long long> ids(1000);
+    for (int i = 0; i < 1000; ++i) ids[i] = i;
+    ExpectAll("blocked backward: inverse mapping", inv.host(), ids);
+    ExpectAll("blocked backward: gradient rows", grad.host(), std::vector<float>(1000 * width, 200.0f));
+    // per-call forward options (no process-wide state): streaming row loads give the same bits
+    DeviceArray<float> table(std::vector<float>(1000 * width, 0.5f)), pooled(static_cast<size_t>(samples) * width);
+    cuembed::ForwardOptions options;
+    options.row_loads = cuembed::RowLoadPolicy::kStreaming;
+    const int* no_offsets = nullptr;
+    cuembed::EmbeddingForward<float, float, IndexT, int>(table.ptr, width, b_cols.ptr, no_offsets, no_weights, samples, 4,
+                                                          cuembed::CombineMode::kSum, pooled.ptr, stream, options);
+    HIP_OK(hipStreamSynchronize(stream));
+    ExpectAll("forward with ForwardOptions{kStreaming}", pooled.host(), std::vector<float>(static_cast<size_t>(samples) * width, 2.0f));
   }
   // row-cache index translation: rows 3 and 0 are cached in slots 0 and 1, cache 1000 rows above the table
   DeviceArray<int32_t> slot_of_row(std::vector<int32_t>{1, -1, -1, 0, -1});
