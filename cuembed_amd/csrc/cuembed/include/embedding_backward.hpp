@@ -132,7 +132,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
   const int launches = static_cast<int>((nnz + launch_len - 1) / launch_len);
   const uint32_t* pair_rows = blocked ? block_row_ids : nullptr;
   if (zero_shared) {
-    const int64_t tail_blocks = zero_rows > 0 ? (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock : 0;
+    const int64_t tail_blocks = ZeroTailBlocks(zero_rows);
     const int64_t per_launch = s.NzBlocks(launch_len);
     ZeroSharedAndTailRowsKernel<GradT, IndexT>
         <<<static_cast<unsigned>(per_launch * launches + tail_blocks), 256, 0, stream>>>(

@@ -4,7 +4,9 @@ random table shapes, batch sizes, hotness, index distributions and types, fixed 
 weights -- forward (bit-exact), row-id extraction, Transpose (bit-exact, stable; with and without the
 key / row bounds; the fused fixed-hotness variant; signed keys and arbitrary payloads), compressed-index
 remap, EmbeddingBackward dense and compressed (exact on small-integer gradients), the compressed backward with
-num_unique left on the device, and Transpose in sample blocks + the uncoalesced compressed gradient it leads to.
+num_unique left on the device, Transpose in sample blocks + the uncoalesced compressed gradient it leads to, and the
+reference's compressed gradient computed from that blocked order (ComputeCompressedGradIndicesBlocked +
+EmbeddingBackward(sample_blocks)).
 
     python tools/fuzz_parity.py [--seconds 300] [--seed 0]
 
@@ -139,6 +141,24 @@ def one_case(rng, ce, O, np, torch, verbose=False):
                 bc, binv = ce.embedding_backward(dev(gy), nub, b_ti, b_ts, b_remap, b_tw if use_w else None)
                 dense = torch.zeros((ncat, W), dtype=torch.float32, device="cuda").index_add_(0, binv.long(), bc.float())
                 assert np.array_equal(dense.cpu().numpy(), want_d), ("backward over sample blocks", P, desc)
+            # the REFERENCE's compressed gradient from the blocked order (at most 8 blocks): pair numbers + pair -> row
+            # table compose to the fully sorted order's ids; rows, their order and the inverse mapping are the oracle's
+            if -(-nnz // L) <= 8:
+                pairs, table, nud = ce.compute_compressed_grad_indices_blocked(b_ti, P)
+                assert int(nud.item()) == nu, ("blocked remap: num_unique", P, desc)
+                full = table[pairs.long()].cpu().numpy().astype(np.int64)
+                keys = b_ti.cpu().numpy()
+                uniq, rank = np.unique(keys, return_inverse=True)
+                assert np.array_equal(full & (ce.SHARED_ROW_BIT - 1), rank), ("blocked remap: ranks", P, desc)
+                seen = np.zeros(uniq.shape[0], dtype=bool)
+                for lo in range(0, nnz, L):
+                    blk = rank[lo:lo + L]
+                    assert np.array_equal((full[lo:lo + L] & ce.SHARED_ROW_BIT) != 0, seen[blk]), ("blocked remap: flags", P, desc)
+                    seen[blk] = True
+                cc, cinv = ce.embedding_backward(dev(gy), nu, b_ti, b_ts, pairs, b_tw if use_w else None, sample_blocks=P,
+                                                 block_row_ids=table)
+                assert np.array_equal(cc.float().cpu().numpy(), want_c), ("blocked coalesced backward", P, desc)
+                assert np.array_equal(cinv.cpu().numpy(), want_inv), ("blocked coalesced inverse mapping", P, desc)
     return desc
 
 
