@@ -32,7 +32,7 @@ constexpr int kRankSelfScanTiles = 4096;                  // tile counts a finis
 //! Workspace of ComputeCompressedGradIndicesBlocked for n lookups in `blocks` blocks (byte offsets).
 template <typename IndexT>
 struct BlockedRemapPlan {
-  size_t tile_sum, unique_keys, block_start, lower_bounds, masks, word_prefix, tile_count, num_unique, total;
+  size_t tile_sum, unique_keys, fence_keys, block_start, lower_bounds, masks, word_prefix, tile_count, num_unique, total;
   size_t cap;       //!< entries the per-entry arrays hold (>= the number of distinct (block, key) pairs)
   int rank_tiles;   //!< grid of the two rank kernels (most workgroups leave at once: M is only known on the device)
   BlockedRemapPlan(const size_t n, const int blocks) {
@@ -43,6 +43,8 @@ struct BlockedRemapPlan {
     off += RunHeadScanWorkBytes(n);
     unique_keys = off;
     off += SortAlign((cap + 64) * sizeof(IndexT));
+    fence_keys = off;
+    off += SortAlign((cap / kFenceStride + 2) * sizeof(IndexT));
     block_start = off;
     off += SortAlign((kMaxCoalescedBlocks + 1) * sizeof(unsigned));
     lower_bounds = off;
@@ -64,14 +66,22 @@ struct BlockedRemapPlan {
 //! b = the last block with block_start[b] <= e.  For every other block b' it finds lb = the number of keys of b'
 //! below its own (kRankItems independent binary searches per thread in flight; the lists are L2-resident) and stores
 //! it at lower_bounds[(b' < b ? b' : b' - 1) * cap + e].
+//! The search is two-level: every kFenceStride-th key of the other block's list (`fence_keys`, written by the
+//! compaction) is loaded into LDS once per workgroup and searched there; only the last log2(kFenceStride) = 8 steps
+//! read the full list (19 dependent L2 reads per entry before: 17.7 -> see docs/EXPERIMENTS.md).  Lists with more
+//! than kMaxLdsFences fences (> 1 M distinct keys per block) skip the LDS level.
+constexpr int kMaxLdsFences = 4096;
+
 template <typename IndexT>
 __global__ void __launch_bounds__(kRankThreads)
-BlockedRankSearchKernel(const IndexT* __restrict__ unique_keys, const unsigned* __restrict__ block_start,
+BlockedRankSearchKernel(const IndexT* __restrict__ unique_keys, const IndexT* __restrict__ fence_keys,
+                        const unsigned* __restrict__ block_start,
                         const int blocks, const size_t cap, unsigned* __restrict__ lower_bounds,
                         unsigned long long* __restrict__ masks, unsigned* __restrict__ word_prefix,
                         unsigned* __restrict__ tile_count) {
   __shared__ unsigned s_start[kMaxCoalescedBlocks + 1];
   __shared__ unsigned s_word[kRankWords];
+  __shared__ IndexT s_fence[kMaxLdsFences];
   if (static_cast<int>(threadIdx.x) <= blocks) s_start[threadIdx.x] = block_start[threadIdx.x];
   __syncthreads();
   const unsigned total = s_start[blocks];                       // M: distinct (block, key) pairs
@@ -103,7 +113,53 @@ BlockedRankSearchKernel(const IndexT* __restrict__ unique_keys, const unsigned* 
       lo[r] = 0;
       hi[r] = (valid[r] && mine[r] != other) ? len : 0u;
     }
-    const int steps = len == 0 ? 0 : 32 - __clz(static_cast<int>(len));   // lower bound among len keys
+    // ---- level 1: the fences of this list that are whole multiples of kFenceStride inside it, in LDS.
+    // Fence f holds the key at entry f * kFenceStride of the concatenated lists: f_first .. f_last lie in this list.
+    const unsigned f_first = (base + kFenceStride - 1) / kFenceStride;
+    const unsigned f_end = len == 0 ? f_first : (base + len - 1) / kFenceStride + 1;   // one past the last fence
+    const unsigned fences = f_end > f_first ? f_end - f_first : 0u;
+    const bool two_level = fences > 0 && fences <= static_cast<unsigned>(kMaxLdsFences);
+    __syncthreads();                                    // (the previous list's fences are no longer read)
+    if (two_level) {
+      for (unsigned f = threadIdx.x; f < fences; f += kRankThreads) s_fence[f] = fence_keys[f_first + f];
+      __syncthreads();
+      // number of fences whose key is below mine (the kRankItems searches of a thread in lockstep: their LDS reads
+      // overlap); the lower bound then lies in the stride that ends at that fence
+      unsigned fa[kRankItems], fb[kRankItems];
+#pragma unroll
+      for (int r = 0; r < kRankItems; ++r) {
+        fa[r] = 0;
+        fb[r] = lo[r] < hi[r] ? fences : 0u;
+      }
+      const int fence_steps = 32 - __clz(static_cast<int>(fences));
+      for (int q = 0; q < fence_steps; ++q) {
+        unsigned fm[kRankItems];
+        IndexT fv[kRankItems];
+#pragma unroll
+        for (int r = 0; r < kRankItems; ++r) {
+          fm[r] = (fa[r] + fb[r]) >> 1;
+          fv[r] = s_fence[fa[r] < fb[r] ? fm[r] : 0u];
+        }
+#pragma unroll
+        for (int r = 0; r < kRankItems; ++r) {
+          if (fa[r] < fb[r]) {
+            if (fv[r] < key[r]) fa[r] = fm[r] + 1;
+            else fb[r] = fm[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRankItems; ++r) {
+        if (lo[r] < hi[r]) {
+          // fences [0, a) are below the key, fence a (if any) is not: entry positions relative to `base`
+          const unsigned a = fa[r];
+          lo[r] = a == 0 ? 0u : (f_first + a - 1) * kFenceStride - base + 1;   // all entries up to fence a-1 are below
+          hi[r] = a == fences ? len : (f_first + a) * kFenceStride - base;      // fence a itself is >= key
+        }
+      }
+    }
+    // lower bound among `len` keys, or -- after level 1 -- inside one stride of at most kFenceStride keys
+    const int steps = len == 0 ? 0 : 32 - __clz(static_cast<int>(two_level && len > kFenceStride ? kFenceStride : len));
     for (int s = 0; s < steps; ++s) {
       unsigned mid[kRankItems];
       IndexT v[kRankItems];
@@ -120,11 +176,14 @@ BlockedRankSearchKernel(const IndexT* __restrict__ unique_keys, const unsigned* 
         }
       }
     }
+    IndexT at[kRankItems];   // the key at the lower bound (all four requested together)
+#pragma unroll
+    for (int r = 0; r < kRankItems; ++r) at[r] = list[(valid[r] && other < mine[r] && lo[r] < len) ? lo[r] : 0u];
 #pragma unroll
     for (int r = 0; r < kRankItems; ++r) {
       if (valid[r] && mine[r] != other) {
         lower_bounds[static_cast<size_t>(other < mine[r] ? other : other - 1) * cap + e[r]] = lo[r];
-        if (other < mine[r] && lo[r] < len && list[lo[r]] == key[r]) first[r] = false;
+        if (other < mine[r] && lo[r] < len && at[r] == key[r]) first[r] = false;
       }
     }
   }
@@ -216,22 +275,37 @@ BlockedRankFinishKernel(const unsigned* __restrict__ block_start, const int bloc
   __syncthreads();
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
+  // the kRankItems entries of a thread side by side: their loads (lower bound, then prefix word and mask) overlap
+  unsigned e[kRankItems], rank[kRankItems];
+  int mine[kRankItems];
 #pragma unroll
   for (int r = 0; r < kRankItems; ++r) {
-    const unsigned e = tile_base + static_cast<unsigned>((r * kSortWaves + wave) * 64 + lane);
-    if (e >= total) continue;
-    int mine = 0;
+    e[r] = tile_base + static_cast<unsigned>((r * kSortWaves + wave) * 64 + lane);
+    rank[r] = 0;
+    mine[r] = 0;
     for (int q = 1; q < blocks; ++q)
-      if (e >= s_start[q]) mine = q;
-    unsigned rank = 0;
-    for (int other = 0; other < blocks; ++other) {
-      const unsigned rel = other == mine
-                               ? e - s_start[mine]
-                               : lower_bounds[static_cast<size_t>(other < mine ? other : other - 1) * cap + e];
-      rank += below(s_start[other] + rel) - s_below_start[other];
+      if (e[r] >= s_start[q]) mine[r] = q;
+  }
+  for (int other = 0; other < blocks; ++other) {
+    unsigned rel[kRankItems];
+#pragma unroll
+    for (int r = 0; r < kRankItems; ++r) {
+      rel[r] = 0;
+      if (e[r] < total)
+        rel[r] = other == mine[r] ? e[r] - s_start[other]
+                                  : lower_bounds[static_cast<size_t>(other < mine[r] ? other : other - 1) * cap + e[r]];
     }
-    const bool first = ((masks[e >> 6] >> (e & 63)) & 1ull) != 0;
-    table[e] = rank | (first ? 0u : kSharedRowBit);
+    unsigned upto[kRankItems];
+#pragma unroll
+    for (int r = 0; r < kRankItems; ++r) upto[r] = e[r] < total ? below(s_start[other] + rel[r]) : 0u;
+#pragma unroll
+    for (int r = 0; r < kRankItems; ++r) rank[r] += upto[r] - s_below_start[other];
+  }
+#pragma unroll
+  for (int r = 0; r < kRankItems; ++r) {
+    if (e[r] >= total) continue;
+    const bool first = ((masks[e[r] >> 6] >> (e[r] & 63)) & 1ull) != 0;
+    table[e[r]] = rank[r] | (first ? 0u : kSharedRowBit);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *num_unique = all_first;
@@ -260,10 +334,11 @@ inline void BlockedRunHeadRemap(const IndexT* indices, const size_t n, const int
   unsigned* tile_count = reinterpret_cast<unsigned*>(work + plan.tile_count);
   unsigned* num_unique = reinterpret_cast<unsigned*>(work + plan.num_unique);
   const int block_tiles = static_cast<int>(block_len / kSortTile);
+  IndexT* fence_keys = reinterpret_cast<IndexT*>(work + plan.fence_keys);
   RunHeadScanLaunch<IndexT, RunHeadOutput::kCompact>(indices, n, remapped, tile_sum, block_tiles, unique_keys,
-                                                     block_start, stream);
+                                                     block_start, fence_keys, stream);
   BlockedRankSearchKernel<IndexT><<<plan.rank_tiles, kRankThreads, 0, stream>>>(
-      unique_keys, block_start, blocks, plan.cap, lower_bounds, masks, word_prefix, tile_count);
+      unique_keys, fence_keys, block_start, blocks, plan.cap, lower_bounds, masks, word_prefix, tile_count);
   const bool prefix = plan.rank_tiles > kRankSelfScanTiles;
   if (prefix)
     BlockedRankTilePrefixKernel<<<1, kSortThreads, 0, stream>>>(tile_count, block_start, blocks, plan.rank_tiles);

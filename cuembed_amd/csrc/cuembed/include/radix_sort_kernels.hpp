@@ -896,6 +896,9 @@ RunHeadTilePrefixKernel(unsigned* __restrict__ tile_count, const int num_tiles) 
 //!   kCompact   the same, and unique_keys[u[i]] = indices[i] at every run head (and i = 0); block_start[b] =
 //!              u[first element of block b], block_start[number of blocks] = u[n - 1] + 1.
 enum class RunHeadOutput { kIds, kCompact };
+//! kCompact also writes every kFenceStride-th distinct key to a compact array: the coarse index that
+//! BlockedRankSearchKernel searches in LDS before it touches the full lists.
+constexpr unsigned kFenceStride = 256;
 
 template <typename IndexT, RunHeadOutput kOut>
 __global__ void __launch_bounds__(kSortThreads)
@@ -904,7 +907,8 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
                   const bool tile_count_is_prefix,
                   IndexT* __restrict__ remapped,
                   const int block_tiles,
-                  IndexT* __restrict__ unique_keys, unsigned* __restrict__ block_start) {
+                  IndexT* __restrict__ unique_keys, unsigned* __restrict__ block_start,
+                  IndexT* __restrict__ fence_keys) {
   __shared__ unsigned wave_sum[kSortWaves];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -948,7 +952,11 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
     if (i < n) {
       remapped[i] = static_cast<IndexT>(u);
       if constexpr (kOut == RunHeadOutput::kCompact) {
-        if (((heads[r] >> lane) & 1ull) != 0 || i == 0) unique_keys[u] = indices[i];
+        if (((heads[r] >> lane) & 1ull) != 0 || i == 0) {
+          const IndexT key = indices[i];
+          unique_keys[u] = key;
+          if ((u & (kFenceStride - 1)) == 0) fence_keys[u / kFenceStride] = key;   // every kFenceStride-th distinct key
+        }
         if (r == 0 && threadIdx.x == 0 && (starts_block || i == 0))
           block_start[block_tiles > 0 ? static_cast<int>(blockIdx.x) / block_tiles : 0] = u;
         if (i == n - 1)
@@ -968,12 +976,12 @@ inline size_t RunHeadScanWorkBytes(const size_t n) {
 template <typename IndexT, RunHeadOutput kOut>
 inline void RunHeadScanLaunch(const IndexT* indices, const size_t n, IndexT* remapped, unsigned* tile_sum,
                               const int block_tiles, IndexT* unique_keys, unsigned* block_start,
-                              hipStream_t stream) {
+                              IndexT* fence_keys, hipStream_t stream) {
   if (n == 0) return;
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
   if (tiles == 1) {  // one launch instead of two
     RunHeadScanKernel<IndexT, kOut><<<1, kSortThreads, 0, stream>>>(
-        indices, static_cast<int64_t>(n), nullptr, false, remapped, block_tiles, unique_keys, block_start);
+        indices, static_cast<int64_t>(n), nullptr, false, remapped, block_tiles, unique_keys, block_start, fence_keys);
     return;
   }
   // every workgroup of the scan adds up the counts of the earlier tiles itself: tiles^2 / 2 words
@@ -984,14 +992,14 @@ inline void RunHeadScanLaunch(const IndexT* indices, const size_t n, IndexT* rem
                                                                   block_tiles);
   if (prefix) RunHeadTilePrefixKernel<<<1, kSortThreads, 0, stream>>>(tile_sum, tiles);
   RunHeadScanKernel<IndexT, kOut><<<tiles, kSortThreads, 0, stream>>>(
-      indices, static_cast<int64_t>(n), tile_sum, prefix, remapped, block_tiles, unique_keys, block_start);
+      indices, static_cast<int64_t>(n), tile_sum, prefix, remapped, block_tiles, unique_keys, block_start, fence_keys);
 }
 
 template <typename IndexT>
 inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped, char* work,
                         hipStream_t stream) {
   RunHeadScanLaunch<IndexT, RunHeadOutput::kIds>(indices, n, remapped, reinterpret_cast<unsigned*>(work),
-                                                 /*block_tiles=*/0, nullptr, nullptr, stream);
+                                                 /*block_tiles=*/0, nullptr, nullptr, nullptr, stream);
 }
 
 }  // namespace detail
