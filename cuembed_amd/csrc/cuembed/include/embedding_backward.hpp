@@ -146,17 +146,21 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
     const int64_t count = first + launch_len < nnz ? launch_len : nnz - first;
     const dim3 grid(static_cast<unsigned>(s.GridBlocks(s.NzBlocks(count))), 1, 1);
     const IndexT* run_ids_p = run_ids != nullptr ? run_ids + first : nullptr;
-#define CUEMBED_LAUNCH_SCATTER(W, BLK)                                                                            \
-  SegmentedScatterAddKernel<GradT, IndexT, N, W, BLK><<<grid, block, s.lds, stream>>>(                              \
+#define CUEMBED_LAUNCH_SCATTER(W, BLK, WIN)                                                                       \
+  SegmentedScatterAddKernel<GradT, IndexT, N, W, BLK, WIN><<<grid, block, s.lds, stream>>>(                         \
       grad_y, width, rows + first, sample_ids + first, (W) ? weights + first : weights, count, s.segment_len,        \
       seg_shift, grad_out, s.slices, s.xcds, run_ids_p, inverse_mapping, pair_rows)
     const bool adds_to_rows = blocked && p > 0;   // (the first block finds nothing stored yet: plain kernel)
+    // window depth: column-sliced launches gather mostly from L2 (short window, more wavefronts); unsliced ones miss
+    const bool short_window = s.slices > 1 || adds_to_rows;
     if (weights != nullptr) {
-      if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(true, true);
-      else CUEMBED_LAUNCH_SCATTER(true, false);
+      if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(true, true, kBackwardWindowHits);
+      else if (short_window) CUEMBED_LAUNCH_SCATTER(true, false, kBackwardWindowHits);
+      else CUEMBED_LAUNCH_SCATTER(true, false, kBackwardWindowMisses);
     } else {
-      if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(false, true);
-      else CUEMBED_LAUNCH_SCATTER(false, false);
+      if (adds_to_rows) CUEMBED_LAUNCH_SCATTER(false, true, kBackwardWindowHits);
+      else if (short_window) CUEMBED_LAUNCH_SCATTER(false, false, kBackwardWindowHits);
+      else CUEMBED_LAUNCH_SCATTER(false, false, kBackwardWindowMisses);
     }
 #undef CUEMBED_LAUNCH_SCATTER
   }

@@ -4,7 +4,7 @@
 // equal row ids are contiguous.  The work is cut into fixed-length nz-segments so
 // that it is balanced no matter how skewed the run lengths are (at the north-star
 // shape one row owns a run of 65,528 lookups); `lanes_per_row` lanes walk one
-// segment in nz order, gathering grad_y[sample_id] row slices with kBackwardUnroll
+// segment in nz order, gathering grad_y[sample_id] row slices with kWindow
 // loads in flight (a rolling window) and keeping the running sum in fp32 registers.  When a run ends:
 //   * the run lies entirely inside this segment  -> one plain vector store;
 //   * the run continues from / into a neighbour segment -> the partial is combined with its
@@ -28,7 +28,12 @@
 namespace cuembed {
 namespace detail {
 
-constexpr int kBackwardUnroll = 4;
+//! Depth of the rolling window of gathers (lookups in flight per lane group): 4 where grad_y is mostly L2-resident
+//! (column-sliced launches: 64 instead of 86 VGPRs = 7-8 instead of 5 wavefronts per SIMD; the blocked orders gain
+//! 5 %), 8 where the gathers miss (unsliced launches -- narrow rows or few lookups: uniform indices at W = 32,
+//! B = 131,072 measured 0.265 ms with 8 and 0.318 ms with 4).  Segment lengths are multiples of 8 either way.
+constexpr int kBackwardWindowHits = 4;
+constexpr int kBackwardWindowMisses = 8;
 
 template <int N>
 __device__ __forceinline__ void FlushAtomic(float* dst, const float (&acc)[N]) {
@@ -121,7 +126,7 @@ enum : int { kPartHead = 1, kPartTail = 2, kPartWhole = 4 };
 //!    reads ids from LDS and only the grad_y row gathers stay on the global-memory path.
 //!    Where runs end is decided here, once per lookup (kRunEndBit of the staged sample id).
 //! 2. Each segment is walked in nz order by `lanes_per_row` lanes: a uniform loop over a rolling
-//!    window of kBackwardUnroll gathers (lookup i + K is requested into the registers of lookup
+//!    window of kWindow gathers (lookup i + K is requested into the registers of lookup
 //!    i as soon as those are converted), fp32 partial sums in register pairs.  A run that lies
 //!    inside the segment ends in a plain vector store.  The partial sums of the segment's FIRST
 //!    run (when it continues from the previous segment) and LAST run (when it continues into
@@ -147,7 +152,7 @@ enum : int { kPartHead = 1, kPartTail = 2, kPartWhole = 4 };
 //!    touches the row during this launch), the usual float atomics when it crosses workgroups.  The rows to be read
 //!    are requested once while staging (they were written by another launch and come from HBM; that brings their
 //!    lines into this XCD's L2) and again with the gather of the run's last lookup (see `old` below).
-template <typename GradT, typename IndexT, int N, bool kWeighted, bool kBlocked = false>
+template <typename GradT, typename IndexT, int N, bool kWeighted, bool kBlocked = false, int kWindow = kBackwardWindowHits>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int width,
@@ -329,7 +334,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     const uint32_t* my_pk = st_pk + seg * pk_stride;
     const GradT* my_w = st_w + seg * w_stride;
     typedef uint32_t __attribute__((ext_vector_type(4))) word4_t;
-    constexpr int K = kBackwardUnroll;
+    constexpr int K = kWindow;
     static_assert(K % 4 == 0, "packed ids are fetched four at a time");
 
     // A run is "shared" when it also has lookups in a neighbouring segment (the -1 sentinels and
@@ -378,7 +383,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
     };
     // Sample-blocked order: a run whose row an earlier block (an earlier launch) already stored is ADDED to it -- a
     // read-modify-write, not an atomic (13.7 M dword atomics at C4 cost 0.1 ms; the 55 MB they touch are 10 us of
-    // traffic).  The old row is requested TOGETHER with the gather of the run's last lookup, kBackwardUnroll
+    // traffic).  The old row is requested TOGETHER with the gather of the run's last lookup, kWindow
     // lookups ahead of its use, into a register tuple of its own per window slot: loads return in order, so it is
     // there when that lookup is consumed and the window never drains for it (a read issued at the run's end and
     // awaited at the next one made the compiler wait for vmcnt(1): 0.177 instead of 0.119 ms per block).
@@ -391,7 +396,7 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
       }
     };
 
-    // kBackwardUnroll gathers stay in flight for the whole walk: the row of lookup i + K is
+    // kWindow gathers stay in flight for the whole walk: the row of lookup i + K is
     // requested as soon as the registers of lookup i have been converted (a rolling window, not
     // load-8 / wait / add-8: the wave's own arithmetic overlaps its own memory latency).
     raw_t g[K];
