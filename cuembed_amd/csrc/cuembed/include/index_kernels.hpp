@@ -17,17 +17,48 @@ constexpr int kSequenceItemsPerThread = 4;
 //! workgroup's slice of row_ids (~samples x hotness entries) amortises the staging.
 constexpr int kCsrSamplesPerBlock = 128;
 
-//! out[t] = t / divisor.  Grid-free of tails: each workgroup covers
-//! blockDim.x * kSequenceItemsPerThread consecutive items, lane-interleaved so
-//! every store instruction of a wave is one contiguous 256/512-byte segment.
+//! magic / shift with (uint64(i) * magic) >> shift == i / d for every 0 <= i < 2^31, d >= 1
+//! (s = ceil(log2 d), magic = ceil(2^(31+s) / d) < 2^32): a 64-bit integer division per element costs more than the
+//! store it feeds (FillQuotientKernel at C4: 7.0 -> see docs/EXPERIMENTS.md).
+struct QuotientMagic {
+  unsigned magic;
+  int shift;
+  explicit QuotientMagic(const int d) {
+    int s = 0;
+    while ((int64_t{1} << s) < d) ++s;
+    const unsigned __int128 one = static_cast<unsigned __int128>(1) << (31 + s);
+    magic = static_cast<unsigned>((one + d - 1) / d);
+    shift = 31 + s;
+  }
+};
+
+//! out[t] = t / divisor.  Every thread writes kSequenceItemsPerThread CONSECUTIVE items (one 16-byte store for
+//! 32-bit ids); positions below 2^31 divide by multiply-shift, larger ones (never reached through the int-sized
+//! API) by a real division.
 template <typename OutT>
-__global__ void FillQuotientKernel(const int64_t count, const int divisor, OutT* __restrict__ out) {
-  const int64_t base =
-      static_cast<int64_t>(blockIdx.x) * blockDim.x * kSequenceItemsPerThread + threadIdx.x;
+__global__ void FillQuotientKernel(const int64_t count, const int divisor, const unsigned magic, const int shift,
+                                   OutT* __restrict__ out) {
+  const int64_t t0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * kSequenceItemsPerThread;
+  if (t0 >= count) return;
+  OutT v[kSequenceItemsPerThread];
 #pragma unroll
   for (int k = 0; k < kSequenceItemsPerThread; ++k) {
-    const int64_t t = base + static_cast<int64_t>(k) * blockDim.x;
-    if (t < count) out[t] = static_cast<OutT>(divisor == 1 ? t : t / divisor);
+    const int64_t t = t0 + k;
+    v[k] = static_cast<OutT>(divisor == 1 ? t
+                             : (t < (int64_t{1} << 31)
+                                    ? static_cast<int64_t>((static_cast<unsigned long long>(static_cast<unsigned>(t)) * magic) >> shift)
+                                    : t / divisor));
+  }
+  if (t0 + kSequenceItemsPerThread <= count) {
+    typedef OutT __attribute__((ext_vector_type(kSequenceItemsPerThread))) vec_t;
+    vec_t w;
+#pragma unroll
+    for (int k = 0; k < kSequenceItemsPerThread; ++k) w[k] = v[k];
+    *reinterpret_cast<vec_t*>(out + t0) = w;      // (t0 is a multiple of 4 items: 16- / 32-byte aligned)
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSequenceItemsPerThread; ++k)
+      if (t0 + k < count) out[t0 + k] = v[k];
   }
 }
 

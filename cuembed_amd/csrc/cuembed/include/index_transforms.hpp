@@ -47,9 +47,10 @@ void ExtractRowIdsFromFixed(const int batch_size,
   if (nnz <= 0) return;
   const int threads = detail::kIndexBlockThreads;
   const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
+  const detail::QuotientMagic q(num_hots);
   detail::FillQuotientKernel<IndexT>
       <<<static_cast<unsigned>((nnz + per_block - 1) / per_block), threads, 0, stream>>>(
-          nnz, num_hots, row_ids);
+          nnz, num_hots, q.magic, q.shift, row_ids);
 }
 
 /*!
@@ -79,7 +80,7 @@ void ExtractRowIdsForConcat(const int nnz, IndexT* row_ids, const hipStream_t st
   const int64_t per_block = static_cast<int64_t>(threads) * detail::kSequenceItemsPerThread;
   detail::FillQuotientKernel<IndexT>
       <<<static_cast<unsigned>((nnz + per_block - 1) / per_block), threads, 0, stream>>>(
-          nnz, 1, row_ids);
+          nnz, 1, 0u, 0, row_ids);
 }
 
 /**

@@ -310,17 +310,26 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   // every run of equal digits inside the wavefront adds, and it adds the run's length (the
   // distance to the next run head in the ballot of heads).  Random digits: every lane is a head.
   const int lane = tid & 63;
+  if (pass == 0) {
+    // the lowest digit of unsorted keys: equal neighbours are rare, one LDS atomic per key is the cheaper way
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const bool in_range = base + static_cast<int64_t>(r) * kSortThreads < n;
-    const unsigned digit = in_range ? (static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip) : 0xffffffffu;
-    const unsigned before = __shfl_up(digit, 1);
-    const bool head = lane == 0 || before != digit;
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
-    const unsigned run = above != 0 ? static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
-                                    : static_cast<unsigned>(64 - lane);
-    if (head && in_range) atomicAdd(&count[wave][digit], run);
+    for (int r = 0; r < kSortItems; ++r) {
+      if (base + static_cast<int64_t>(r) * kSortThreads < n)
+        atomicAdd(&count[wave][static_cast<unsigned>(key[r] & 0xff) ^ flip], 1u);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+      const bool in_range = base + static_cast<int64_t>(r) * kSortThreads < n;
+      const unsigned digit = in_range ? (static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip) : 0xffffffffu;
+      const unsigned before = __shfl_up(digit, 1);
+      const bool head = lane == 0 || before != digit;
+      const unsigned long long heads = __ballot(head);
+      const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+      const unsigned run = above != 0 ? static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
+                                      : static_cast<unsigned>(64 - lane);
+      if (head && in_range) atomicAdd(&count[wave][digit], run);
+    }
   }
   __syncthreads();
   unsigned total = 0;
@@ -422,12 +431,24 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
   const int last = first + segment_tiles < num_tiles ? first + segment_tiles : num_tiles;
   unsigned* row = tile_hist + static_cast<size_t>(bin) * num_tiles;
   unsigned carry = 0;
-  for (int base = first; base < last; base += kSortThreads) {
-    const int t = base + threadIdx.x;
-    const unsigned v = t < last ? row[t] : 0u;
+  // four consecutive tiles per thread and round: 1024 tiles (4.19 M keys) are ONE round -- one load, one block scan,
+  // one store per thread instead of four dependent rounds (this kernel is all latency: 4.7 -> see EXPERIMENTS)
+  constexpr int kPerThread = 4;
+  for (int base = first; base < last; base += kSortThreads * kPerThread) {
+    const int t0 = base + static_cast<int>(threadIdx.x) * kPerThread;
+    unsigned v[kPerThread];
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) v[q] = t0 + q < last ? row[t0 + q] : 0u;
+    unsigned mine = 0;
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) mine += v[q];
     unsigned total;
-    const unsigned excl = BlockExclusiveScan(v, &total);
-    if (t < last) row[t] = carry + excl;
+    unsigned excl = carry + BlockExclusiveScan(mine, &total);
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+      if (t0 + q < last) row[t0 + q] = excl;
+      excl += v[q];
+    }
     carry += total;
   }
   if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;   // [segment][bin]
@@ -840,10 +861,30 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
 // For a sample-blocked array (blocked_order.hpp) `block_tiles` > 0 makes the first element of every block a
 // run head whatever its neighbour holds (blocks are whole tiles, so only a tile's first element can be one).
 // ---------------------------------------------------------------------------
+//! Run-head ballots of the kSortItems x 64 consecutive elements a wavefront owns (element r * 64 + lane of the wave's
+//! range is lane `lane` of round r): every element is loaded ONCE (all rounds in flight together); a lane's
+//! predecessor is its neighbour's element (cross-lane read), lane 0's is the last element of the previous round, and
+//! only the wave's very first element reads one word more.  `cur` returns the elements (the compaction needs them).
 template <typename IndexT>
-__device__ __forceinline__ unsigned RunHead(const IndexT* __restrict__ indices, const int64_t i,
-                                            const int64_t n) {
-  return (i > 0 && i < n && indices[i] != indices[i - 1]) ? 1u : 0u;
+__device__ __forceinline__ void WaveRunHeads(const IndexT* __restrict__ indices, const int64_t wave_base, const int64_t n,
+                                             const bool forced_first, IndexT (&cur)[kSortItems],
+                                             unsigned long long (&heads)[kSortItems]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = wave_base + r * 64 + lane;
+    cur[r] = i < n ? indices[i] : IndexT(0);
+  }
+  IndexT edge = IndexT(0);   // the element before the wave's first one
+  if (lane == 0 && wave_base > 0 && wave_base <= n) edge = indices[wave_base - 1];
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = wave_base + r * 64 + lane;
+    IndexT prev = __shfl_up(cur[r], 1);
+    const IndexT last_of_previous_round = r > 0 ? __shfl(cur[r > 0 ? r - 1 : 0], 63) : edge;
+    if (lane == 0) prev = last_of_previous_round;
+    heads[r] = __ballot((i > 0 && i < n && cur[r] != prev) || (forced_first && r == 0));
+  }
 }
 
 //! The tile of this workgroup starts a block of a sample-blocked array.
@@ -861,11 +902,12 @@ RunHeadCountKernel(const IndexT* __restrict__ indices, const int64_t n, unsigned
   const int lane = threadIdx.x & 63;
   const int64_t wave_base = static_cast<int64_t>(blockIdx.x) * kSortTile + wave * (64 * kSortItems);
   const bool forced = TileStartsBlock(block_tiles) && threadIdx.x == 0;   // (the tile's first element is in range)
+  IndexT cur[kSortItems];
+  unsigned long long heads[kSortItems];
+  WaveRunHeads<IndexT>(indices, wave_base, n, forced, cur, heads);
   unsigned c = 0;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r)
-    c += static_cast<unsigned>(
-        __popcll(__ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0 || (forced && r == 0))));
+  for (int r = 0; r < kSortItems; ++r) c += static_cast<unsigned>(__popcll(heads[r]));
   if (lane == 0) wave_sum[wave] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -916,12 +958,11 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
   const bool starts_block = TileStartsBlock(block_tiles);
   const bool forced = starts_block && threadIdx.x == 0;
   unsigned long long heads[kSortItems];
+  IndexT cur[kSortItems];
+  WaveRunHeads<IndexT>(indices, wave_base, n, forced, cur, heads);
   unsigned c = 0;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    heads[r] = __ballot(RunHead(indices, wave_base + r * 64 + lane, n) != 0 || (forced && r == 0));
-    c += static_cast<unsigned>(__popcll(heads[r]));
-  }
+  for (int r = 0; r < kSortItems; ++r) c += static_cast<unsigned>(__popcll(heads[r]));
   // run heads in all earlier tiles: every workgroup adds up the raw per-tile counts itself (at
   // most a few thousand words from L2) -- cheaper than a separate single-workgroup scan launch
   __shared__ unsigned wave_before[kSortWaves];
@@ -953,7 +994,7 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
       remapped[i] = static_cast<IndexT>(u);
       if constexpr (kOut == RunHeadOutput::kCompact) {
         if (((heads[r] >> lane) & 1ull) != 0 || i == 0) {
-          const IndexT key = indices[i];
+          const IndexT key = cur[r];
           unique_keys[u] = key;
           if ((u & (kFenceStride - 1)) == 0) fence_keys[u / kFenceStride] = key;   // every kFenceStride-th distinct key
         }
