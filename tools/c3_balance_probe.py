@@ -73,6 +73,20 @@ def main():
             ce.embedding_forward(table, b["idx_sorted"], b["off_sorted"], b["w_sorted"], batch_size=B, num_hots=0, out=res)
 
         e["bags_sorted_by_length_ms"] = timed(run_sorted)
+        # (d) the two bags of a wavefront alike, wavefronts in random order: the sorted samples, PAIRS of them shuffled.
+        #     Separates "the two halves of a wavefront wait for each other" from "neighbouring wavefronts differ".
+        rng = np.random.default_rng(7)
+        for b in batches:
+            o = b["off"].cpu().numpy().astype(np.int64)
+            lens = np.diff(o)
+            order = np.argsort(lens, kind="stable").reshape(-1, 2)
+            order = order[rng.permutation(order.shape[0])].reshape(-1)
+            new_off = np.concatenate([[0], np.cumsum(lens[order])])
+            gather = np.concatenate([np.arange(o[s], o[s + 1]) for s in order])
+            b["idx_sorted"] = b["idx"][torch.from_numpy(gather).to(dev)]
+            b["w_sorted"] = b["w"][torch.from_numpy(gather).to(dev)]
+            b["off_sorted"] = torch.from_numpy(new_off.astype(np.int32)).to(dev)
+        e["equal_pairs_random_order_ms"] = timed(run_sorted)
         out["alpha_%g" % alpha] = e
         del table
     print(json.dumps(out))
