@@ -41,6 +41,20 @@ def test_every_declared_symbol_is_exported(lib_path):
     assert not missing, missing
 
 
+def test_cmake_project_builds_the_same_translation_units():
+    """CMakeLists.txt (the C++ user's way in) and cuembed_amd/build.py (the Python package's) must not drift apart:
+    the shared library is made of the same units, with the same float-atomics flag."""
+    from cuembed_amd import build
+    with open(os.path.join(ROOT, "CMakeLists.txt")) as f:
+        cm = f.read()
+    listed = set(re.findall(r"\$\{CUEMBED_AMD_CSRC\}/(c_api_[a-z_]+\.hip)", cm))
+    assert listed == set(build.UNITS)
+    assert "-munsafe-fp-atomics" in cm and "-munsafe-fp-atomics" in build.HIPCC_FLAGS
+    assert "gfx950" in cm and build.ARCH == "gfx950"
+    for src in ("tests/cpp/header_api_kat.hip", "benchmarks/manual_benchmark.hip"):
+        assert src in cm and os.path.exists(os.path.join(ROOT, src))
+
+
 def test_launch_shapes_of_baseline_configs():
     import torch
     import cuembed_amd as ce
