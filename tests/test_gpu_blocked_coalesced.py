@@ -66,6 +66,26 @@ def test_blocked_remap_is_the_rank_among_all_distinct_rows(ce, idx, nnz, blocks,
     assert ce._lib.lib().cuembed_peek_last_error() == 0
 
 
+@pytest.mark.parametrize("nnz,blocks,ncat,power", [
+    (6_000_000, 3, 40_000_000, 1),      # > 4096 rank tiles (tile counts scanned by their own launch); ~1.9 M distinct
+                                        # keys per block: more fences than the LDS level holds
+    (9_000_001, 2, 5_000_000, 3),       # skewed, ragged last tile
+    (5_500_000, 8, 2_000_000, 2),
+], ids=["6M_uniform", "9M_skewed", "5.5M_8_blocks"])
+def test_blocked_remap_beyond_the_benchmark_size(ce, nnz, blocks, ncat, power):
+    """More (block, row) pairs than a finishing workgroup scans itself (4096 tiles of 1024 pairs = what C4 just
+    fits) and more distinct keys per block than the two-level search keeps fences for."""
+    rng = np.random.default_rng(nnz % 977)
+    keys = (ncat * rng.random(nnz) ** power).astype(np.int32)
+    L = ce.transpose_sample_block_length(nnz, blocks)
+    blocked = np.concatenate([np.sort(keys[lo:lo + L]) for lo in range(0, nnz, L)])
+    pair, table, nu = ce.compute_compressed_grad_indices_blocked(dev(blocked), blocks)
+    want, uniq = _expected_blocked_remap(blocked, L, ce.SHARED_ROW_BIT)
+    assert int(nu.item()) == uniq
+    _check_pairs(host(pair), blocked, L)
+    assert np.array_equal(host(table)[host(pair)].astype(np.int64), want)
+
+
 def test_blocked_remap_extremes(ce):
     """every block holds the same single key; every key distinct; blocks with disjoint key ranges in both orders"""
     n = 4096 * 48
