@@ -26,6 +26,9 @@ def _declare(L):
     L.cuembed_embedding_forward_with_options.restype = None
     L.cuembed_embedding_forward_with_options.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I,
                                                          _VP]
+    L.cuembed_embedding_forward_ordered.restype = None
+    L.cuembed_embedding_forward_ordered.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I, _VP,
+                                                    _VP]
     L.cuembed_set_forward_row_load_policy.restype = None
     L.cuembed_set_forward_row_load_policy.argtypes = [_I]
     L.cuembed_get_forward_row_load_policy.restype = _I

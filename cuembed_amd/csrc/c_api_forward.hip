@@ -12,9 +12,11 @@ namespace {
 template <typename ElemT, typename IndexT, typename OffsetT>
 void Forward(const void* params, int embed_width, const IndexT* indices, const OffsetT* offsets,
              const void* weights, int batch_size, int num_hots, int mode, int fp16_math,
-             void* ret, cuembed_stream_t stream, int reduction_order = -1, int row_load_policy = -1) {
+             void* ret, cuembed_stream_t stream, int reduction_order = -1, int row_load_policy = -1,
+             const int32_t* sample_order = nullptr) {
   // per-call options (cuembed_embedding_forward_with_options); < 0 = the process-wide default
   cuembed::ForwardOptions options = cuembed::DefaultForwardOptions();
+  options.sample_order = sample_order;
   CUEMBED_ASSERT(reduction_order <= 1 && row_load_policy <= 1);
   if (reduction_order >= 0) options.reduction_order = static_cast<cuembed::ReductionOrder>(reduction_order);
   if (row_load_policy >= 0) options.row_loads = static_cast<cuembed::RowLoadPolicy>(row_load_policy);
@@ -73,10 +75,21 @@ void cuembed_embedding_forward_with_options(const void* params, int elem_type, i
                                             int num_hots, int mode, int fp16_math, void* ret,
                                             int reduction_order, int row_load_policy,
                                             cuembed_stream_t stream) {
+  cuembed_embedding_forward_ordered(params, elem_type, embed_width, indices, index_type, offsets, offset_type, weights,
+                                    batch_size, num_hots, mode, fp16_math, ret, reduction_order, row_load_policy,
+                                    nullptr, stream);
+}
+
+void cuembed_embedding_forward_ordered(const void* params, int elem_type, int embed_width,
+                                       const void* indices, int index_type, const void* offsets,
+                                       int offset_type, const void* weights, int batch_size,
+                                       int num_hots, int mode, int fp16_math, void* ret,
+                                       int reduction_order, int row_load_policy,
+                                       const int32_t* sample_order, cuembed_stream_t stream) {
 #define FWD(E, I, O)                                                                          \
   Forward<E, I, O>(params, embed_width, static_cast<const I*>(indices),                       \
                    static_cast<const O*>(offsets), weights, batch_size, num_hots, mode,       \
-                   fp16_math, ret, stream, reduction_order, row_load_policy)
+                   fp16_math, ret, stream, reduction_order, row_load_policy, sample_order)
   const int key = (elem_type << 2) | (index_type << 1) | (offsets ? offset_type : 0);
   switch (key) {
     case 0: FWD(float, int32_t, int32_t); break;

@@ -339,14 +339,15 @@ GatherReduceKernel(const ElemT* __restrict__ table,
                    const bool is_mean,
                    ElemT* __restrict__ out,
                    const int column_slices,    // 1, 2, 4 or 8 (see ColumnSlice)
-                   const bool stream_rows) {   // RowLoadPolicy::kStreaming: table rows are not kept in L2
+                   const bool stream_rows,     // RowLoadPolicy::kStreaming: table rows are not kept in L2
+                   const int32_t* __restrict__ sample_order = nullptr) {   // ForwardOptions::sample_order (CSR only)
   using A = Arith<AccT>;
   const int lane_x = threadIdx.x;
   const int slot = threadIdx.y;
   const int samples_per_block = blockDim.y;
   const ColumnSlice cs = ColumnSlice::Of(blockIdx.x, column_slices);
   const int64_t block_id = cs.block;
-  const int64_t sample = block_id * samples_per_block + slot;
+  int64_t sample = block_id * samples_per_block + slot;
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * blockDim.x + lane_x) * N;
   const ElemT* lane_base = table + column0;
   RowPool<ElemT, AccT, N, kWeighted> pool;
@@ -379,6 +380,10 @@ GatherReduceKernel(const ElemT* __restrict__ table,
     else pool.template Gather<kUnroll, kPipelined, false>(lane_base, width, hot, idx_at, w_at);
   } else {
     if (sample >= batch) return;
+    // scheduling hint: position p of the grid pools sample sample_order[p] (a permutation of the batch; e.g. bags by
+    // descending length, so that the bags of a wavefront and of neighbouring wavefronts are alike).  Only WHICH lanes
+    // pool a sample changes: its sum and its output row do not.
+    if (sample_order != nullptr) sample = sample_order[sample];
     int64_t begin;
     if (offsets != nullptr) {
       begin = static_cast<int64_t>(offsets[sample]);

@@ -114,14 +114,16 @@ def backward_launch_shape(elem_dtype, index_dtype, embed_width, nnz, is_weighted
 
 
 def embedding_forward(params, indices, offsets=None, weights=None, batch_size=None, num_hots=0,
-                      mode="sum", fp16_math=False, out=None, reduction_order=None, row_loads=None):
+                      mode="sum", fp16_math=False, out=None, reduction_order=None, row_loads=None, sample_order=None):
     """out[s] = combine_j weights[s,j] * params[indices[s,j]].
 
     Fixed hotness: offsets=None, num_hots>0 (indices holds batch_size*num_hots ids).
     CSR: offsets[batch_size+1], num_hots=0.  mode: "sum" | "mean" | "concat".
     Returns [batch, width] (sum/mean) or [batch, num_hots, width] (concat).
     Per-call options (extension; None = the process-wide default): reduction_order "sequential" | "split"
-    (set_forward_reduction_order), row_loads "default" | "streaming" (set_forward_row_load_policy)."""
+    (set_forward_reduction_order), row_loads "default" | "streaming" (set_forward_row_load_policy);
+    sample_order (CSR only): an int32 permutation of range(batch_size) on the device, the order in which the samples
+    are handed to the wavefronts -- a scheduling hint that never changes a result (bag_order_by_length())."""
     if mode not in _MODES:
         raise ValueError("mode must be 'sum', 'mean' or 'concat'")
     if reduction_order not in _ORDERS or row_loads not in _ROW_LOADS:
@@ -166,6 +168,12 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
             raise TypeError("weights must have the table's dtype")
         if weights.numel() < indices.numel():
             raise ValueError("weights must have one entry per index")
+    if sample_order is not None:
+        _check_dev("sample_order", sample_order, dev)
+        if offsets is None:
+            raise ValueError("sample_order is a hint for CSR batches (bags of different lengths)")
+        if sample_order.dtype != torch.int32 or sample_order.numel() != batch_size or not sample_order.is_contiguous():
+            raise ValueError("sample_order must be a contiguous int32 permutation of range(batch_size)")
     shape = (batch_size, num_hots, width) if m == CONCAT else (batch_size, width)
     if out is None:
         out = torch.empty(shape, dtype=params.dtype, device=dev)
@@ -175,11 +183,33 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
             raise ValueError("out has the wrong dtype or size")
     if batch_size > 0:
         with torch.cuda.device(params.device):   # the launch must happen on the tensors' device
-            _lib.lib().cuembed_embedding_forward_with_options(
+            _lib.lib().cuembed_embedding_forward_ordered(
                 _ptr(params), et, width, _ptr(indices), it, _ptr(offsets), ot, _ptr(weights),
                 batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _ORDERS[reduction_order],
-                _ROW_LOADS[row_loads], _stream(params))
+                _ROW_LOADS[row_loads], _ptr(sample_order), _stream(params))
     return out
+
+
+def bag_order_by_length(offsets, batch_size=None, max_length=None):
+    """int32 permutation of range(batch_size): the samples of a CSR batch by DESCENDING bag length (ties in input
+    order) -- what embedding_forward(..., sample_order=) wants for ragged bags: the two bags of a wavefront are alike,
+    neighbouring wavefronts are alike, and the longest bags start first.  Computed on the device with the library's
+    own stable sort (Transpose over the lengths); max_length, when the caller knows a bound on the bag length, keeps
+    the sort to the key bits that exist (one radix pass for bags of up to 255 lookups).  Typically prepared once per
+    batch next to the offsets (it only depends on them)."""
+    _check_dev("offsets", offsets)
+    if batch_size is None:
+        batch_size = offsets.numel() - 1
+    if offsets.numel() < batch_size + 1:
+        raise ValueError("offsets must hold batch_size + 1 entries")
+    lengths = (offsets[1:batch_size + 1] - offsets[:batch_size]).to(torch.int32)
+    if max_length is None:
+        keys, bound = (2 ** 31 - 1) - lengths, None          # descending: the complement ascends
+    else:
+        keys, bound = int(max_length) - lengths, int(max_length) + 1
+    samples = extract_row_ids_for_concat(batch_size, torch.int32, offsets.device)
+    _, order, _ = transpose(samples, keys, num_categories=bound)
+    return order
 
 
 def embedding_weight_grad(params, indices, grad_y, offsets=None, batch_size=None, num_hots=0):

@@ -285,6 +285,23 @@ void ExtensionTransposeKat(hipStream_t stream) {
                                                           cuembed::CombineMode::kSum, pooled.ptr, stream, options);
     HIP_OK(hipStreamSynchronize(stream));
     ExpectAll("forward with ForwardOptions{kStreaming}", pooled.host(), std::vector<float>(static_cast<size_t>(samples) * width, 2.0f));
+    // ... and a sample order (CSR: bags of 0, 1, 2, 3, 0, 1, ... lookups, handed out back to front) moves no result
+    std::vector<int> offsets(samples + 1, 0);
+    std::vector<int32_t> back_to_front(samples);
+    std::vector<float> want(static_cast<size_t>(samples) * width);
+    for (int s = 0; s < samples; ++s) {
+      offsets[s + 1] = offsets[s] + s % 4;
+      back_to_front[s] = samples - 1 - s;
+      for (int c = 0; c < width; ++c) want[static_cast<size_t>(s) * width + c] = 0.5f * (s % 4);
+    }
+    DeviceArray<int> d_offsets(offsets);
+    DeviceArray<int32_t> d_order(back_to_front);
+    cuembed::ForwardOptions ordered;
+    ordered.sample_order = d_order.ptr;
+    cuembed::EmbeddingForward<float, float, IndexT, int>(table.ptr, width, b_cols.ptr, d_offsets.ptr, no_weights, samples, 0,
+                                                          cuembed::CombineMode::kSum, pooled.ptr, stream, ordered);
+    HIP_OK(hipStreamSynchronize(stream));
+    ExpectAll("forward with ForwardOptions{sample_order}", pooled.host(), want);
   }
   // row-cache index translation: rows 3 and 0 are cached in slots 0 and 1, cache 1000 rows above the table
   DeviceArray<int32_t> slot_of_row(std::vector<int32_t>{1, -1, -1, 0, -1});

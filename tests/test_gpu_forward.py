@@ -295,3 +295,40 @@ def test_weight_gradient_all_types_and_layouts(ce, tdtype, idx):
                                            offsets=dev(offsets), num_hots=0 if layout == "csr" else H)
             assert got.dtype == tdtype and got.numel() == indices.size
             assert np.array_equal(got.float().cpu().numpy().astype(np.float64), want), (W, layout, H)
+
+
+@pytest.mark.parametrize("dtype,index_dtype,weighted,mode", [
+    (torch.float32, torch.int32, True, "sum"), (torch.float16, torch.int64, False, "mean"),
+    (torch.float16, torch.int32, True, "sum"), (torch.float32, torch.int64, False, "sum")])
+def test_forward_sample_order_is_a_scheduling_hint_only(dtype, index_dtype, weighted, mode):
+    """ForwardOptions::sample_order (extension): whatever permutation the samples are handed to the wavefronts in,
+    every output row holds the same bits; bag_order_by_length() is the permutation by descending bag length."""
+    import cuembed_amd as ce
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, rows, W = 3001, 5000, 128 if dtype == torch.float32 else 256
+    lens = torch.randint(0, 129, (B,), device=dev, generator=g)
+    lens[7] = 0
+    lens[B - 1] = 700                     # one bag far longer than the rest
+    off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(lens, 0)
+    nnz = int(off[-1])
+    off = off.to(index_dtype)
+    idx = torch.randint(0, rows, (nnz,), device=dev, generator=g).to(index_dtype)
+    table = torch.randn((rows, W), device=dev, generator=g).to(dtype)
+    w = torch.rand((nnz,), device=dev, generator=g).to(dtype) if weighted else None
+    want = ce.embedding_forward(table, idx, off, w, num_hots=0, mode=mode)
+    by_length = ce.bag_order_by_length(off, max_length=700)
+    assert by_length.dtype == torch.int32 and torch.equal(torch.sort(by_length).values,
+                                                            torch.arange(B, device=dev, dtype=torch.int32))
+    sorted_lens = lens[by_length.long()]
+    assert bool((sorted_lens[1:] <= sorted_lens[:-1]).all()) and int(by_length[0]) == B - 1
+    assert torch.equal(ce.bag_order_by_length(off), by_length)           # without the bound: all key bits, same result
+    for order in (by_length, torch.randperm(B, device=dev, generator=g).int(),
+                  torch.arange(B - 1, -1, -1, device=dev, dtype=torch.int32)):
+        got = ce.embedding_forward(table, idx, off, w, num_hots=0, mode=mode, sample_order=order)
+        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+    with pytest.raises(ValueError):       # a hint for ragged bags only
+        ce.embedding_forward(table, idx[:B * 2], num_hots=2, batch_size=B, sample_order=by_length)
+    with pytest.raises(ValueError):
+        ce.embedding_forward(table, idx, off, w, num_hots=0, sample_order=by_length.long())

@@ -54,6 +54,18 @@ def main():
             ce.embedding_forward(table, b["idx"], b[key], b["w"], batch_size=B, num_hots=0, out=res)
 
         e["ragged_ms"] = timed(lambda: run("off"))
+        # the same batches, untouched, with the scheduling hint: samples handed out by descending bag length
+        for b in batches:
+            b["order"] = ce.bag_order_by_length(b["off"], max_length=H)
+
+        def run_ordered():
+            b = batches[state["t"] % 2]
+            state["t"] += 1
+            ce.embedding_forward(table, b["idx"], b["off"], b["w"], batch_size=B, num_hots=0, out=res,
+                                 sample_order=b["order"])
+
+        e["ragged_with_sample_order_ms"] = timed(run_ordered)
+        e["bag_order_by_length_ms"] = timed(lambda: ce.bag_order_by_length(batches[0]["off"], max_length=H))
         for b in batches:      # constant bags over the same lookups: offsets = round(i * nnz / B)
             b["const"] = torch.from_numpy(np.round(np.arange(B + 1) * (b["nnz"] / B)).astype(np.int32)).to(dev)
         e["constant_bags_ms"] = timed(lambda: run("const"))
