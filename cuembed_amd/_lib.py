@@ -29,6 +29,8 @@ def _declare(L):
     L.cuembed_embedding_forward_ordered.restype = None
     L.cuembed_embedding_forward_ordered.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I, _VP,
                                                     _VP]
+    L.cuembed_bag_order_by_length.restype = None
+    L.cuembed_bag_order_by_length.argtypes = [_VP, _I, _I, _I, _VP, _VP, ctypes.POINTER(ctypes.c_size_t), _VP]
     L.cuembed_set_forward_row_load_policy.restype = None
     L.cuembed_set_forward_row_load_policy.argtypes = [_I]
     L.cuembed_get_forward_row_load_policy.restype = _I

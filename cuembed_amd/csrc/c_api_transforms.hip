@@ -245,4 +245,16 @@ void cuembed_transpose_fixed_hotness_sample_blocks(const void* indices, const vo
 #undef TFB
 }
 
+void cuembed_bag_order_by_length(const void* offsets, int offset_type, int batch_size, int max_length,
+                                 int32_t* sample_order, char* work, size_t* lwork, cuembed_stream_t stream) {
+  if (offset_type == CUEMBED_I32)
+    cuembed::BagOrderByLength<int32_t>(static_cast<const int32_t*>(offsets), batch_size, max_length, sample_order, work,
+                                       lwork, Stream(stream));
+  else if (offset_type == CUEMBED_I64)
+    cuembed::BagOrderByLength<int64_t>(static_cast<const int64_t*>(offsets), batch_size, max_length, sample_order, work,
+                                       lwork, Stream(stream));
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
 }  // extern "C"

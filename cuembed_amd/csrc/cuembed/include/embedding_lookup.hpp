@@ -56,8 +56,8 @@ struct ForwardOptions {
   //! CSR only (extension): a permutation of [0, batch_size) on the device -- the order in which the samples are
   //! handed to the wavefronts.  Results do not depend on it (every sample is still pooled in lookup order into its own
   //! output row); time does when bag lengths vary: the two bags of a wavefront run in lockstep and wavefronts with
-  //! unequal bags end at different times.  With the bags in descending order of length (BagOrderByLength in
-  //! ops.py; a data loader can prepare it with the batch) C3 takes 0.15 instead of 0.17 ms.
+  //! unequal bags end at different times.  With the bags in descending order of length (BagOrderByLength,
+  //! index_transforms.hpp; it only depends on the offsets) C3 takes 0.156 instead of 0.169 ms.
   const int32_t* sample_order = nullptr;
 };
 

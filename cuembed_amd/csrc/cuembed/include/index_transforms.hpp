@@ -10,6 +10,7 @@
 //   Transpose                    <-> index_transforms.cuh:224-250
 //   ComputeCompressedGradIndices <-> index_transforms.cuh:278-323
 //   ComputeCompressedGradIndicesBlocked: extension (the same ids for a sample-blocked order, blocked_order.hpp)
+//   BagOrderByLength: extension (ForwardOptions::sample_order for ragged CSR batches)
 // Every result is integer (or a permutation of the inputs) and bit-exact.
 #ifndef CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_
 #define CUEMBED_INCLUDE_INDEX_TRANSFORMS_HPP_
@@ -260,6 +261,60 @@ void TransposeFixedHotness(const IndexT* indices,
   detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, nullptr, transpose_sample_ids, weights,
                                                 transpose_weights, n, key_bits, work, stream,
                                                 /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks);
+}
+
+namespace detail {
+//! keys[s] = bound - min(bag length of sample s, bound): ascending keys = descending lengths
+template <typename OffsetT>
+__global__ void __launch_bounds__(kIndexBlockThreads)
+BagLengthKeysKernel(const OffsetT* __restrict__ offsets, const int batch_size, const int bound,
+                    int32_t* __restrict__ keys) {
+  const int s = blockIdx.x * kIndexBlockThreads + threadIdx.x;
+  if (s >= batch_size) return;
+  int64_t len = static_cast<int64_t>(offsets[s + 1]) - static_cast<int64_t>(offsets[s]);
+  len = len < 0 ? 0 : (len > bound ? bound : len);
+  keys[s] = bound - static_cast<int32_t>(len);
+}
+}  // namespace detail
+
+/**
+ * @brief sample_order for ForwardOptions (extension): the samples of a CSR batch by DESCENDING bag length, ties in
+ * input order -- a permutation of [0, batch_size).  A key kernel and the library's own stable sort over the keys
+ * (TransposeFixedHotness with hotness 1: the payload is the position); `max_length` > 0, a bound on the bag length,
+ * keeps the sort to the key bits that exist (one radix pass up to 255 lookups per bag; longer bags are ranked as
+ * max_length: that costs balance, never correctness); 0 = unknown.  It only depends on the offsets: prepare it
+ * where they are made.  Two-phase workspace query as for Transpose().
+ */
+template <typename OffsetT>
+void BagOrderByLength(const OffsetT* offsets,
+                      const int batch_size,
+                      const int max_length,
+                      int32_t* sample_order,
+                      char* work,
+                      size_t* lwork,
+                      const hipStream_t stream = 0) {
+  const int bound = max_length > 0 ? max_length : INT32_MAX;
+  int bits = 0;
+  while (bits < 31 && (int64_t{1} << bits) <= bound) ++bits;   // keys lie in [0, bound]
+  const int batch = batch_size > 0 ? batch_size : 0;
+  const size_t keys_bytes = detail::AlignUp(static_cast<size_t>(batch) * sizeof(int32_t), 256);
+  size_t sort_bytes = 0;
+  TransposeFixedHotness<int32_t, float>(nullptr, nullptr, batch, 1, nullptr, nullptr, nullptr, nullptr, &sort_bytes,
+                                        stream, bits);
+  const size_t need = 2 * keys_bytes + sort_bytes;
+  if (work == nullptr) {
+    *lwork = need;
+    return;
+  }
+  assert(*lwork >= need);
+  if (batch == 0) return;
+  int32_t* keys = reinterpret_cast<int32_t*>(work);
+  int32_t* sorted_keys = reinterpret_cast<int32_t*>(work + keys_bytes);
+  detail::BagLengthKeysKernel<OffsetT>
+      <<<(batch + detail::kIndexBlockThreads - 1) / detail::kIndexBlockThreads, detail::kIndexBlockThreads, 0, stream>>>(
+          offsets, batch, bound, keys);
+  TransposeFixedHotness<int32_t, float>(keys, nullptr, batch, 1, sorted_keys, sample_order, nullptr,
+                                        work + 2 * keys_bytes, &sort_bytes, stream, bits);
 }
 
 /**

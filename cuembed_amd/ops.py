@@ -190,25 +190,34 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
     return out
 
 
-def bag_order_by_length(offsets, batch_size=None, max_length=None):
+def bag_order_by_length(offsets, batch_size=None, max_length=None, workspace=None):
     """int32 permutation of range(batch_size): the samples of a CSR batch by DESCENDING bag length (ties in input
     order) -- what embedding_forward(..., sample_order=) wants for ragged bags: the two bags of a wavefront are alike,
-    neighbouring wavefronts are alike, and the longest bags start first.  Computed on the device with the library's
-    own stable sort (Transpose over the lengths); max_length, when the caller knows a bound on the bag length, keeps
-    the sort to the key bits that exist (one radix pass for bags of up to 255 lookups).  Typically prepared once per
-    batch next to the offsets (it only depends on them)."""
+    neighbouring wavefronts are alike, and the longest bags start first (cuembed::BagOrderByLength: a key kernel +
+    the library's own stable sort).  max_length, when the caller knows a bound on the bag length, keeps the sort to
+    the key bits that exist (one radix pass for bags of up to 255 lookups; longer bags rank as max_length).  It
+    only depends on the offsets: prepare it once per batch where they are made."""
     _check_dev("offsets", offsets)
+    ot = _index_code("offsets", offsets)
     if batch_size is None:
         batch_size = offsets.numel() - 1
-    if offsets.numel() < batch_size + 1:
+    if batch_size < 0 or offsets.numel() < batch_size + 1:
         raise ValueError("offsets must hold batch_size + 1 entries")
-    lengths = (offsets[1:batch_size + 1] - offsets[:batch_size]).to(torch.int32)
-    if max_length is None:
-        keys, bound = (2 ** 31 - 1) - lengths, None          # descending: the complement ascends
-    else:
-        keys, bound = int(max_length) - lengths, int(max_length) + 1
-    samples = extract_row_ids_for_concat(batch_size, torch.int32, offsets.device)
-    _, order, _ = transpose(samples, keys, num_categories=bound)
+    bound = 0 if max_length is None else int(max_length)
+    if bound < 0:
+        raise ValueError("max_length must be positive (or None)")
+    order = torch.empty((batch_size,), dtype=torch.int32, device=offsets.device)
+    need = ctypes.c_size_t(0)
+    _lib.lib().cuembed_bag_order_by_length(None, ot, batch_size, bound, None, None, ctypes.byref(need), None)
+    if workspace is None:
+        workspace = torch.empty((max(need.value, 1),), dtype=torch.uint8, device=offsets.device)
+    elif workspace.numel() * workspace.element_size() < need.value:
+        raise ValueError("workspace too small: need %d bytes" % need.value)
+    lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
+    if batch_size > 0:
+        with torch.cuda.device(offsets.device):
+            _lib.lib().cuembed_bag_order_by_length(_ptr(offsets), ot, batch_size, bound, _ptr(order), _ptr(workspace),
+                                                   ctypes.byref(lwork), _stream(offsets))
     return order
 
 

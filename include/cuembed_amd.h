@@ -340,6 +340,12 @@ void cuembed_embedding_forward_ordered(const void* params, int elem_type, int em
                                        int num_hots, int mode, int fp16_math, void* ret,
                                        int reduction_order, int row_load_policy,
                                        const int32_t* sample_order, cuembed_stream_t stream);
+/* cuembed::BagOrderByLength (extension): sample_order[batch_size] = the samples of a CSR batch by descending bag
+ * length, ties in input order (a key kernel + the library's stable sort).  max_length > 0: a bound on the bag
+ * length (fewer radix passes; longer bags rank as max_length), 0 = unknown.  Two-phase workspace query: work == NULL
+ * writes the bytes needed to *lwork. */
+void cuembed_bag_order_by_length(const void* offsets, int offset_type, int batch_size, int max_length,
+                                 int32_t* sample_order, char* work, size_t* lwork, cuembed_stream_t stream);
 /* cuembed::SetBackwardTuning / GetBackwardTuning (tuning and tests; 0 = built-in heuristic):
  * lookups per nz-segment (rounded down to a multiple of 8), XCD column slices of the gather
  * (1, 2, 4, 8).  Process-wide; initial values from CUEMBED_BWD_SEGMENT_LEN / CUEMBED_BWD_SLICES,

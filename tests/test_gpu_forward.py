@@ -324,6 +324,10 @@ def test_forward_sample_order_is_a_scheduling_hint_only(dtype, index_dtype, weig
     sorted_lens = lens[by_length.long()]
     assert bool((sorted_lens[1:] <= sorted_lens[:-1]).all()) and int(by_length[0]) == B - 1
     assert torch.equal(ce.bag_order_by_length(off), by_length)           # without the bound: all key bits, same result
+    too_small = ce.bag_order_by_length(off, max_length=64)                # a bound that is too small costs balance only
+    assert torch.equal(torch.sort(too_small).values, torch.arange(B, device=dev, dtype=torch.int32))
+    clamped = torch.clamp(lens, max=64)[too_small.long()]
+    assert bool((clamped[1:] <= clamped[:-1]).all())
     for order in (by_length, torch.randperm(B, device=dev, generator=g).int(),
                   torch.arange(B - 1, -1, -1, device=dev, dtype=torch.int32)):
         got = ce.embedding_forward(table, idx, off, w, num_hots=0, mode=mode, sample_order=order)
