@@ -59,8 +59,10 @@ struct Flags {
        forward_only = false, enable_csv = false, enable_stderr = true, clear_caches = true,
        bounded_sort = false,      // extension: Transpose sorts ceil(log2(num_categories)) key bits only
        fused_row_ids = false,     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
-       coalesce_blocks = false;   // extension: with --sample_blocks, the REFERENCE's compressed gradient from the blocked
+       coalesce_blocks = false,   // extension: with --sample_blocks, the REFERENCE's compressed gradient from the blocked
                                   // order (ComputeCompressedGradIndicesBlocked + EmbeddingBackward(sample_blocks))
+       bag_order = false;         // extension (CSR): forward with ForwardOptions::sample_order = bags by descending
+                                  // length (BagOrderByLength, computed once outside the timed loop)
 };
 
 bool ParseBool(const std::string& v) { return v.empty() || v == "1" || v == "true" || v == "True" || v == "yes"; }
@@ -94,6 +96,7 @@ Flags ParseFlags(int argc, char** argv) {
   getb("bounded_sort", &f.bounded_sort);
   getb("fused_row_ids", &f.fused_row_ids);
   getb("coalesce_blocks", &f.coalesce_blocks);
+  getb("bag_order", &f.bag_order);
   geti("sample_blocks", &f.sample_blocks);
   for (auto& e : kv) {
     std::fprintf(stderr, "unknown flag --%s\n", e.first.c_str());
@@ -235,6 +238,7 @@ struct Workload {
   DeviceBuffer<OffsetT> offsets;
   DeviceBuffer<char> workspace;
   DeviceBuffer<uint32_t> block_row_ids, num_unique_dev;   // --coalesce_blocks
+  DeviceBuffer<int32_t> sample_order;                      // --bag_order (CSR only)
   int blocks = 1;                                          // sample blocks of the last transpose
   size_t lwork = 0;
 };
@@ -244,6 +248,14 @@ void RunForward(Workload<ElemT, IndexT, OffsetT>& w) {
   const OffsetT* offsets = w.f.csr_input ? w.offsets.ptr : nullptr;
   const int hotness = w.f.csr_input ? 0 : w.f.hotness;
   const ElemT* weights = w.f.weighted_sum ? w.weights.ptr : nullptr;
+  if (w.f.bag_order && w.f.csr_input) {
+    cuembed::ForwardOptions options = cuembed::DefaultForwardOptions();
+    options.sample_order = w.sample_order.ptr;
+    cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, fp16_math>(
+        w.table.ptr, w.f.embed_width, w.indices.ptr, offsets, weights, w.f.batch_size, hotness,
+        cuembed::CombineMode::kSum, w.result.ptr, 0, options);
+    return;
+  }
   cuembed::EmbeddingForward<ElemT, ElemT, IndexT, OffsetT, fp16_math>(
       w.table.ptr, w.f.embed_width, w.indices.ptr, offsets, weights, w.f.batch_size, hotness,
       cuembed::CombineMode::kSum, w.result.ptr);
@@ -393,6 +405,15 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
   const double it = f.iterations;
 
   // ---- forward ----
+  if (f.bag_order && f.csr_input) {   // the scheduling hint is prepared once, with the batch
+    w.sample_order.Resize(f.batch_size);
+    size_t lw_o = 0;
+    cuembed::BagOrderByLength<OffsetT>(w.offsets.ptr, f.batch_size, f.hotness, w.sample_order.ptr, nullptr, &lw_o);
+    DeviceBuffer<char> order_work;
+    order_work.Resize(lw_o);
+    cuembed::BagOrderByLength<OffsetT>(w.offsets.ptr, f.batch_size, f.hotness, w.sample_order.ptr, order_work.ptr, &lw_o);
+    HIP_OK(hipDeviceSynchronize());
+  }
   float ms = timer.Run(f.iterations, [&] { RunForward<ElemT, IndexT, OffsetT, fp16_math>(w); });
   double bytes = f.csr_input ? es * (nnz - 1 + B) * W : es * B * (H + 1) * W;
   double bw = bytes * it / 1e6 / ms;

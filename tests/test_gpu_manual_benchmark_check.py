@@ -23,6 +23,8 @@ CASES = {
                               "--alpha", "1.15"],
     "fp16_csr_weighted": ["--num_categories", "5000", "--embed_width", "128", "--batch_size", "1000", "--hotness", "12",
                           "--alpha", "1.05", "--half_embedding_type=true", "--csr_input=true", "--weighted_sum=true"],
+    "fp32_csr_weighted_bag_order": ["--num_categories", "8000", "--embed_width", "128", "--batch_size", "3001", "--hotness", "40",
+                                    "--alpha", "1.15", "--csr_input=true", "--weighted_sum=true", "--bag_order=true"],
     "fp32_i64_dense_grad": ["--num_categories", "3000", "--embed_width", "32", "--batch_size", "4099", "--hotness", "7",
                             "--use_int64_indices=true", "--compressed_grad=false", "--skip_grad_init=false"],
     "fp16_math_fused_bounded": ["--num_categories", "100000", "--embed_width", "256", "--batch_size", "4096", "--hotness", "8",

@@ -14,7 +14,7 @@ C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 
   for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--bounded_sort --fused_row_ids --sample_blocks 0" "--bounded_sort --fused_row_ids --sample_blocks 0 --coalesce_blocks" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
     echo "== C2/C4 $ex"; benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
-  for ex in "" "--bounded_sort" "--bounded_sort --sample_blocks 0"; do
+  for ex in "" "--bag_order --forward_only" "--bounded_sort" "--bounded_sort --sample_blocks 0"; do
     echo "== C3 $ex"; benchmarks/manual_benchmark $C3 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
 } > "$O/manual_benchmark_c2_c3.txt"
