@@ -34,3 +34,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _same_random_data_every_run(request):
+    """Tests that draw data from torch's global generators get the same data in every run (seeded from the test's
+    id): a test that only fails for one draw in twenty is found here, not by the driver.  Open-ended random testing
+    is tools/fuzz_parity.py's job."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import zlib
+        import torch
+        torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff)   # CPU and every CUDA generator
+    yield

@@ -202,6 +202,7 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     import cuembed_amd as ce
     k, d, B, H = 50000, 256, 40000, 64
     assert ce.recommended_sample_blocks(torch.float16, d, B, B * H) == 2
+    torch.manual_seed(20240 + int(ragged))
     weight = torch.randint(-2, 3, (k, d), device="cuda").half().requires_grad_()
     if ragged:   # CSR bags of 32..96 lookups with weights 0.5 / 0.25: the blocks are cut by position, mid-bag if need be
         lens = torch.randint(32, 97, (B,), device="cuda")
@@ -211,7 +212,11 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     else:
         offsets = torch.arange(0, B * H + 1, H, device="cuda")
         n, w = B * H, None
-    indices = (k * torch.rand(n, device="cuda") ** 3).long()
+    # Skew: the hottest row gets ~11 k lookups (several workgroups, both blocks).  Not more in the weighted case: its
+    # partial sums are multiples of 0.25 and only exact in fp16 below 512 -- with rand ** 3 (69 k lookups, partial sums
+    # of +-85 standard deviation per element) one run in twenty met a partial sum beyond that in SOME order of the
+    # float atomics, and "bit for bit" then no longer holds between two correct summation orders.
+    indices = (k * torch.rand(n, device="cuda") ** (2 if ragged else 3)).long()
     up = torch.randint(-1, 2, (B, d), device="cuda").half()
     grads = {}
     for kind in (True, "uncoalesced", "blocked"):
