@@ -64,6 +64,7 @@ def test_gpus_1_line_has_the_contract_fields():
         assert o["frac"] == o["algorithmic_frac"] and o["frac"] <= o["traffic_frac"] + 1e-9
     c3 = [o for o in rl["other_kernels"] if "C3" in o["kernel"]]
     assert not c3 or (c3[0]["compulsory_bytes_per_launch"] > 0 and c3[0]["hbm_bound_companion"]["row_loads_streaming"]["ms"] > 0)
+    assert not c3 or (c3[0]["with_sample_order"]["bit_identical_to_default"] is True and c3[0]["with_sample_order"]["ms"] > 0)
     comp = rl["hbm_bound_companion"]
     assert comp["row_loads"] == "default" and comp["row_loads_streaming"]["ms"] > 0
     assert line["cpu_baseline"]["gpu_matches_oracle_bit_exact"] is True and line["cpu_baseline"]["cpu_model"]
