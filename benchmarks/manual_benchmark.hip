@@ -59,6 +59,7 @@ struct Flags {
        forward_only = false, enable_csv = false, enable_stderr = true, clear_caches = true,
        bounded_sort = false,      // extension: Transpose sorts ceil(log2(num_categories)) key bits only
        fused_row_ids = false,     // extension: TransposeFixedHotness (no sample-id array; fixed hotness only)
+       fused_remap = false,       // extension: Transpose(..., transpose_remapped_indices): sort + remap in one call
        coalesce_blocks = false,   // extension: with --sample_blocks, the REFERENCE's compressed gradient from the blocked
                                   // order (ComputeCompressedGradIndicesBlocked + EmbeddingBackward(sample_blocks))
        bag_order = false;         // extension (CSR): forward with ForwardOptions::sample_order = bags by descending
@@ -95,6 +96,7 @@ Flags ParseFlags(int argc, char** argv) {
   getb("enable_stderr", &f.enable_stderr); getb("clear_caches", &f.clear_caches);
   getb("bounded_sort", &f.bounded_sort);
   getb("fused_row_ids", &f.fused_row_ids);
+  getb("fused_remap", &f.fused_remap);
   getb("coalesce_blocks", &f.coalesce_blocks);
   getb("bag_order", &f.bag_order);
   geti("sample_blocks", &f.sample_blocks);
@@ -281,14 +283,19 @@ void RunTranspose(Workload<ElemT, IndexT, OffsetT>& w) {
   if (w.f.compressed_grad)   // never with a dense gradient: a table row would be produced once per block
     blocks = w.f.sample_blocks > 0 ? w.f.sample_blocks
                                    : cuembed::RecommendedSampleBlocks<ElemT>(w.f.embed_width, w.f.batch_size, w.nnz);
+  // --fused_remap: the remapped ids come out of the transpose call itself (plain remap only: not the blocked one)
+  const bool remap_in_sort = w.f.fused_remap && w.f.compressed_grad && !w.f.coalesce_blocks;
+  IndexT* remap_out = remap_in_sort ? w.transpose_remapped_indices.ptr : nullptr;
   if (fused)
     cuembed::TransposeFixedHotness<IndexT, ElemT>(w.indices.ptr, weights, w.f.batch_size, w.f.hotness,
                                                   w.transpose_indices.ptr, w.transpose_sample_ids.ptr, t_weights,
-                                                  w.workspace.ptr, &lwork, 0, bits, blocks);
+                                                  w.workspace.ptr, &lwork, 0, bits, blocks, remap_out);
   else
     cuembed::Transpose<IndexT, ElemT>(w.sample_ids.ptr, w.indices.ptr, weights, nnz, w.transpose_indices.ptr,
-                                      w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits, 0, blocks);
+                                      w.transpose_sample_ids.ptr, t_weights, w.workspace.ptr, &lwork, 0, bits, 0, blocks,
+                                      remap_out);
   w.blocks = blocks;
+  if (remap_in_sort) return;
   if (w.f.compressed_grad && w.f.coalesce_blocks)
     cuembed::ComputeCompressedGradIndicesBlocked<IndexT>(w.transpose_indices.ptr, nnz, blocks,
                                                          w.transpose_remapped_indices.ptr, w.block_row_ids.ptr,

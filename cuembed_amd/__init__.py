@@ -13,7 +13,7 @@ from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBack
                   compute_compressed_grad_indices, compute_compressed_grad_indices_blocked,
                   compressed_grad_blocked_workspace_bytes, SHARED_ROW_BIT, embedding_backward, embedding_forward,
                   get_backward_tuning, set_backward_tuning, recommended_sample_blocks, transpose_sample_block_length,
-                  embedding_weight_grad, bag_order_by_length,
+                  embedding_weight_grad, bag_order_by_length, capacity_overflowed,
                   extract_row_ids_for_concat, extract_row_ids_from_csr,
                   extract_row_ids_from_fixed, forward_launch_shape, backward_launch_shape, device_shape, get_forward_reduction_order,
                   set_forward_reduction_order, set_forward_row_load_policy, get_forward_row_load_policy, transpose, transpose_fixed_hotness,

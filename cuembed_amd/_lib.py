@@ -59,6 +59,12 @@ def _declare(L):
     L.cuembed_transpose_fixed_hotness_sample_blocks.restype = None
     L.cuembed_transpose_fixed_hotness_sample_blocks.argtypes = [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP,
                                                                 ctypes.POINTER(ctypes.c_size_t), _I, _I, _VP]
+    L.cuembed_transpose_remapped.restype = None
+    L.cuembed_transpose_remapped.argtypes = [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP,
+                                             ctypes.POINTER(ctypes.c_size_t), _I, _I, _I, _VP]
+    L.cuembed_transpose_fixed_hotness_remapped.restype = None
+    L.cuembed_transpose_fixed_hotness_remapped.argtypes = [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP,
+                                                           ctypes.POINTER(ctypes.c_size_t), _I, _I, _VP]
     L.cuembed_transpose_sample_block_length.restype = ctypes.c_int64
     L.cuembed_transpose_sample_block_length.argtypes = [ctypes.c_int64, _I]
     L.cuembed_recommended_sample_blocks.restype = _I
@@ -75,6 +81,9 @@ def _declare(L):
     L.cuembed_embedding_backward_blocked.restype = None
     L.cuembed_embedding_backward_blocked.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP,
                                                      _VP]
+    L.cuembed_embedding_backward_bounded.restype = None
+    L.cuembed_embedding_backward_bounded.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP,
+                                                     _I, _VP, _VP]
     L.cuembed_extract_row_ids_from_fixed.restype = None
     L.cuembed_extract_row_ids_from_fixed.argtypes = [_I, _I, _I, _VP, _VP]
     L.cuembed_extract_row_ids_from_csr.restype = None

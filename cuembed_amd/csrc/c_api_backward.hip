@@ -11,11 +11,11 @@ template <typename ElemT, typename IndexT>
 void Backward(const void* grad_y, int embed_width, int num_rows, int nnz, const IndexT* t_idx,
               const IndexT* t_sid, const IndexT* t_remap, const void* t_w, int skip_init,
               void* grad, IndexT* inverse_mapping, cuembed_stream_t stream, int sample_blocks = 1,
-              const uint32_t* block_row_ids = nullptr) {
+              const uint32_t* block_row_ids = nullptr, int capacity_rows = 0, uint32_t* capacity_overflow = nullptr) {
   cuembed::EmbeddingBackward<ElemT, IndexT>(
       static_cast<const ElemT*>(grad_y), embed_width, num_rows, nnz, t_idx, t_sid, t_remap,
       static_cast<const ElemT*>(t_w), skip_init != 0, static_cast<ElemT*>(grad), inverse_mapping,
-      Stream(stream), sample_blocks, block_row_ids);
+      Stream(stream), sample_blocks, block_row_ids, capacity_rows, capacity_overflow);
 }
 }  // namespace
 
@@ -81,13 +81,27 @@ void cuembed_embedding_backward_blocked(const void* grad_y, int elem_type, int e
                                         const void* transpose_weights, int skip_grad_init,
                                         void* grad_embedding, void* inverse_mapping, int sample_blocks,
                                         const uint32_t* block_row_ids, cuembed_stream_t stream) {
+  cuembed_embedding_backward_bounded(grad_y, elem_type, embed_width, num_grad_embedding_rows, nnz, transpose_indices,
+                                     transpose_sample_ids, transpose_remapped_indices, index_type, transpose_weights,
+                                     skip_grad_init, grad_embedding, inverse_mapping, sample_blocks, block_row_ids,
+                                     0, nullptr, stream);
+}
+
+void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int embed_width,
+                                        int num_grad_embedding_rows, int nnz,
+                                        const void* transpose_indices, const void* transpose_sample_ids,
+                                        const void* transpose_remapped_indices, int index_type,
+                                        const void* transpose_weights, int skip_grad_init,
+                                        void* grad_embedding, void* inverse_mapping, int sample_blocks,
+                                        const uint32_t* block_row_ids, int capacity_rows,
+                                        uint32_t* capacity_overflow, cuembed_stream_t stream) {
 #define BWD(E, I)                                                                             \
   Backward<E, I>(grad_y, embed_width, num_grad_embedding_rows, nnz,                           \
                  static_cast<const I*>(transpose_indices),                                    \
                  static_cast<const I*>(transpose_sample_ids),                                 \
                  static_cast<const I*>(transpose_remapped_indices), transpose_weights,        \
                  skip_grad_init, grad_embedding, static_cast<I*>(inverse_mapping), stream, sample_blocks, \
-                 block_row_ids)
+                 block_row_ids, capacity_rows, capacity_overflow)
   switch ((elem_type << 1) | index_type) {
     case 0: BWD(float, int32_t); break;
     case 1: BWD(float, int64_t); break;

@@ -206,11 +206,23 @@ void cuembed_transpose_sample_blocks(const void* rows, const void* cols, const v
                                      int index_type, int weight_type, void* transpose_rows,
                                      void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
                                      int index_bits, int row_bits, int sample_blocks, cuembed_stream_t stream) {
+  cuembed_transpose_remapped(rows, cols, weights, nnz, index_type, weight_type, transpose_rows, transpose_cols,
+                             transpose_weights, nullptr, work, lwork, index_bits, row_bits, sample_blocks, stream);
+}
+
+// Extension: ... and ComputeCompressedGradIndices' output from the same call (cuembed::Transpose,
+// transpose_remapped_indices): ONE launch for the whole index work of a batch of up to 16,384 lookups.
+void cuembed_transpose_remapped(const void* rows, const void* cols, const void* weights, int nnz,
+                                int index_type, int weight_type, void* transpose_rows,
+                                void* transpose_cols, void* transpose_weights, void* transpose_remapped_indices,
+                                char* work, size_t* lwork, int index_bits, int row_bits, int sample_blocks,
+                                cuembed_stream_t stream) {
 #define TRB(I, W)                                                                                      \
   cuembed::Transpose<I, W>(static_cast<const I*>(rows), static_cast<const I*>(cols),                   \
                            static_cast<const W*>(weights), nnz, static_cast<I*>(transpose_rows),       \
                            static_cast<I*>(transpose_cols), static_cast<W*>(transpose_weights), work,  \
-                           lwork, Stream(stream), index_bits, row_bits, sample_blocks)
+                           lwork, Stream(stream), index_bits, row_bits, sample_blocks,                 \
+                           static_cast<I*>(transpose_remapped_indices))
   switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {   // 16-bit weights move as bit patterns
     case 0: TRB(int32_t, float); break;
     case 1: TRB(int32_t, __half); break;
@@ -230,11 +242,23 @@ void cuembed_transpose_fixed_hotness_sample_blocks(const void* indices, const vo
                                                    void* transpose_indices, void* transpose_sample_ids,
                                                    void* transpose_weights, char* work, size_t* lwork,
                                                    int index_bits, int sample_blocks, cuembed_stream_t stream) {
+  cuembed_transpose_fixed_hotness_remapped(indices, weights, batch_size, num_hots, index_type, weight_type,
+                                           transpose_indices, transpose_sample_ids, transpose_weights, nullptr, work,
+                                           lwork, index_bits, sample_blocks, stream);
+}
+
+void cuembed_transpose_fixed_hotness_remapped(const void* indices, const void* weights, int batch_size,
+                                              int num_hots, int index_type, int weight_type,
+                                              void* transpose_indices, void* transpose_sample_ids,
+                                              void* transpose_weights, void* transpose_remapped_indices, char* work,
+                                              size_t* lwork, int index_bits, int sample_blocks,
+                                              cuembed_stream_t stream) {
 #define TFB(I, W)                                                                                               \
   cuembed::TransposeFixedHotness<I, W>(static_cast<const I*>(indices), static_cast<const W*>(weights), batch_size, \
                                        num_hots, static_cast<I*>(transpose_indices),                             \
                                        static_cast<I*>(transpose_sample_ids), static_cast<W*>(transpose_weights), \
-                                       work, lwork, Stream(stream), index_bits, sample_blocks)
+                                       work, lwork, Stream(stream), index_bits, sample_blocks,                   \
+                                       static_cast<I*>(transpose_remapped_indices))
   switch ((index_type << 1) | (weight_type != CUEMBED_F32 ? 1 : 0)) {   // 16-bit weights move as bit patterns
     case 0: TFB(int32_t, float); break;
     case 1: TFB(int32_t, __half); break;

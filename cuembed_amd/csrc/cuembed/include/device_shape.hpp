@@ -2,8 +2,8 @@
 //
 // The reference asks the runtime at every EmbeddingBackward call (cudaGetDevice + two attribute queries,
 // embedding_lookup.cuh:355-363).  Here the attributes are read ONCE per device id (a small table indexed by the
-// id, filled on first use: no lock, the values are the same whoever writes them) and every call only pays
-// hipGetDevice.  A full MI355X reports 256 compute units in 8 XCDs with 4 MiB of L2 each; a CPX / DPX / QPX
+// id; the first caller claims the slot with a compare-and-swap, writes it and publishes it, a caller that races with
+// it answers from its own query instead of reading a half-written slot) and every call only pays hipGetDevice.  A full MI355X reports 256 compute units in 8 XCDs with 4 MiB of L2 each; a CPX / DPX / QPX
 // partition reports its own share, and every XCD-aware mapping (column slices of the backward gather, tile maps of
 // the radix sort) follows what is reported instead of assuming the whole chip.
 #ifndef CUEMBED_INCLUDE_DEVICE_SHAPE_HPP_
@@ -52,11 +52,16 @@ inline DeviceShape CurrentDeviceShape() {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return Mi355xShape();
   Slot& slot = slots[device];
-  if (slot.ready.load(std::memory_order_acquire) == 0) {
-    slot.shape = QueryDeviceShape(device);   // (racing first callers write the same values)
-    slot.ready.store(1, std::memory_order_release);
+  // 0 = empty, 1 = one thread is writing `shape`, 2 = published.  Only the thread that moved 0 -> 1 writes the
+  // (non-atomic) struct; nobody reads it before the release store of 2.
+  if (slot.ready.load(std::memory_order_acquire) == 2) return slot.shape;
+  const DeviceShape mine = QueryDeviceShape(device);
+  int expected = 0;
+  if (slot.ready.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) {
+    slot.shape = mine;
+    slot.ready.store(2, std::memory_order_release);
   }
-  return slot.shape;
+  return mine;   // (the writer and every racing first caller: the same values, from their own query)
 }
 
 }  // namespace detail

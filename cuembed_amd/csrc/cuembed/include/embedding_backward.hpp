@@ -123,8 +123,10 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const bool zero_shared /* compressed gradient: zero only what needs it, see below */,
                              const int64_t zero_rows /* ... and the rows from the last id up to here (<= 0: none) */,
                              const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */,
-                             const int64_t sample_block_len = 0, const uint32_t* block_row_ids = nullptr) {
-  const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr, CurrentDeviceShape());
+                             const int64_t sample_block_len = 0, const uint32_t* block_row_ids = nullptr,
+                             const int64_t capacity_rows = 0, uint32_t* capacity_overflow = nullptr) {
+  const DeviceShape dev = CurrentDeviceShape();
+  const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr, dev);
   const dim3 block(s.lanes, s.segments_per_block, 1);
   const int block_len = s.segments_per_block * s.segment_len;
   const bool blocked = sample_block_len > 0 && sample_block_len < nnz;
@@ -132,11 +134,12 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
   const int launches = static_cast<int>((nnz + launch_len - 1) / launch_len);
   const uint32_t* pair_rows = blocked ? block_row_ids : nullptr;
   if (zero_shared) {
-    const int64_t tail_blocks = ZeroTailBlocks(zero_rows);
+    const int64_t tail_blocks = ZeroTailBlocks(zero_rows, dev);
     const int64_t per_launch = s.NzBlocks(launch_len);
     ZeroSharedAndTailRowsKernel<GradT, IndexT>
         <<<static_cast<unsigned>(per_launch * launches + tail_blocks), 256, 0, stream>>>(
-            rows, nnz, block_len, per_launch, launch_len, launches, width, zero_rows, grad_out, pair_rows);
+            rows, nnz, block_len, per_launch, launch_len, launches, width, zero_rows, grad_out, pair_rows,
+            capacity_rows);
   }
   int seg_shift = -1;
   if ((s.segment_len & (s.segment_len - 1)) == 0)
@@ -149,7 +152,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
 #define CUEMBED_LAUNCH_SCATTER(W, BLK, WIN)                                                                       \
   SegmentedScatterAddKernel<GradT, IndexT, N, W, BLK, WIN><<<grid, block, s.lds, stream>>>(                         \
       grad_y, width, rows + first, sample_ids + first, (W) ? weights + first : weights, count, s.segment_len,        \
-      seg_shift, grad_out, s.slices, s.xcds, run_ids_p, inverse_mapping, pair_rows)
+      seg_shift, grad_out, s.slices, s.xcds, run_ids_p, inverse_mapping, pair_rows, capacity_rows, capacity_overflow)
     const bool adds_to_rows = blocked && p > 0;   // (the first block finds nothing stored yet: plain kernel)
     // window depth: column-sliced launches gather mostly from L2 (short window, more wavefronts); unsliced ones miss
     const bool short_window = s.slices > 1 || adds_to_rows;
@@ -212,7 +215,11 @@ inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, 
  * and `inverse_mapping` must then hold at least that many rows (nnz always suffices); rows past
  * the last id are left untouched.  This takes the host read-back of num_unique out of a training
  * step (the reference's benchmark reads it back between Transpose and EmbeddingBackward,
- * manual_benchmark.cu:392-394).
+ * manual_benchmark.cu:392-394).  `capacity_rows` > 0 (compressed gradient only) states how many rows `grad_embedding`
+ * and `inverse_mapping` really hold: if the device-side row count exceeds it, NOTHING is written (per launch: a
+ * sample-blocked call may have written its earlier blocks) and `*capacity_overflow` (a device word the caller
+ * zeroed once; may be null) is OR-ed with 1 -- a flag to read back whenever convenient instead of a silent overrun.
+ * 0 = unchecked, the reference's contract.
  *
  * Extension: `sample_blocks` > 1 (compressed gradient only) says that the COO comes from
  * Transpose(..., sample_blocks) and transpose_remapped_indices + block_row_ids from
@@ -222,6 +229,7 @@ inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, 
  * ascending rows, the same inverse_mapping as the fully sorted order gives -- with the sum of a table row
  * taken block by block (fp32 partial sums per block, one GradT rounding per block: within the bound stated in
  * include/cuembed_amd.h; exact on exactly representable data).  C4: 0.257 -> 0.232 ms.
+ * Precondition of this order: nnz < 2^30 and sample ids < 2^30 (bit 30 of a staged sample id carries a flag).
  */
 template <typename GradT, typename IndexT>
 void EmbeddingBackward(const GradT* grad_y,
@@ -237,7 +245,9 @@ void EmbeddingBackward(const GradT* grad_y,
                        IndexT* inverse_mapping,
                        const hipStream_t stream = 0,
                        const int sample_blocks = 1,
-                       const uint32_t* block_row_ids = nullptr) {
+                       const uint32_t* block_row_ids = nullptr,
+                       const int capacity_rows = 0,
+                       uint32_t* capacity_overflow = nullptr) {
   static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value ||
                     std::is_same<GradT, __hip_bfloat16>::value,
                 "EmbeddingBackward: gradients must be float, __half or __hip_bfloat16");
@@ -248,6 +258,7 @@ void EmbeddingBackward(const GradT* grad_y,
 
   if (transpose_remapped_indices != nullptr && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
   if (transpose_remapped_indices == nullptr) CUEMBED_ASSERT(num_grad_embedding_rows >= 0);  // "unknown" is a compressed-only extension
+  if (capacity_rows > 0) CUEMBED_ASSERT(transpose_remapped_indices != nullptr);            // ... and so is its capacity
   // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
   // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
   // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
@@ -267,7 +278,10 @@ void EmbeddingBackward(const GradT* grad_y,
     CUEMBED_ASSERT(compressed);   // a dense gradient has nothing to gain and the ids carry no flags
     sample_block_len = static_cast<int64_t>(detail::SortSegmentLength(static_cast<size_t>(nnz), sample_blocks));
     CUEMBED_ASSERT((nnz + sample_block_len - 1) / sample_block_len <= detail::kMaxCoalescedBlocks);
-    if (sample_block_len < nnz) CUEMBED_ASSERT(block_row_ids != nullptr);
+    if (sample_block_len < nnz) {
+      CUEMBED_ASSERT(block_row_ids != nullptr);
+      CUEMBED_ASSERT(nnz < (1 << 30));   // bit 30 of a staged sample id is a flag in this order (sample ids < 2^30)
+    }
   }
 
   const IndexT* run_ids = compressed ? transpose_indices : nullptr;  // inverse mapping is written by the scatter
@@ -278,15 +292,17 @@ void EmbeddingBackward(const GradT* grad_y,
   if (split.elems_per_lane == kMaxN)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
                                                    stream, zero_shared, zero_rows, run_ids, inverse_mapping,
-                                                   sample_block_len, block_row_ids);
+                                                   sample_block_len, block_row_ids, capacity_rows, capacity_overflow);
   else if (split.elems_per_lane == kMaxN / 2)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
                                                        split, stream, zero_shared, zero_rows, run_ids, inverse_mapping,
-                                                       sample_block_len, block_row_ids);
+                                                       sample_block_len, block_row_ids, capacity_rows,
+                                                       capacity_overflow);
   else
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
                                                        split, stream, zero_shared, zero_rows, run_ids, inverse_mapping,
-                                                       sample_block_len, block_row_ids);
+                                                       sample_block_len, block_row_ids, capacity_rows,
+                                                       capacity_overflow);
 }
 
 }  // namespace cuembed

@@ -154,6 +154,10 @@ void TranslateIndicesForRowCache(const IndexT* indices,
  *    block in inverse_mapping -- and while a block is being scattered every L2 gathers from 1 / sample_blocks
  *    of grad_y only (C4: EmbeddingBackward 0.258 -> 0.191 ms with 2 blocks, 572 k -> 679 k gradient rows).
  *    RecommendedSampleBlocks() picks the count.  Never use it with a dense gradient.
+ *  - `transpose_remapped_indices` (default nullptr).  Not null: also receives ComputeCompressedGradIndices' output for
+ *    the sorted indices (nnz entries) -- the same values, one call.  Up to 16,384 lookups the whole thing is ONE launch
+ *    of one workgroup (block_sort_kernels.hpp: a dependent launch costs 3.5-5 us at these sizes, the reference's
+ *    sequence is ~10 of them); beyond, the run-head scan's launches follow the sort's on the stream, sharing `work`.
  */
 template <typename IndexT, typename WeightT>
 void Transpose(const IndexT* rows,
@@ -168,7 +172,8 @@ void Transpose(const IndexT* rows,
                const hipStream_t stream = 0,
                const int index_bits = static_cast<int>(sizeof(IndexT) * 8),
                const int row_bits = 0,
-               const int sample_blocks = 1) {
+               const int sample_blocks = 1,
+               IndexT* transpose_remapped_indices = nullptr) {
   using KeyT = typename std::make_unsigned<IndexT>::type;  // bit pattern; signed order via the top digit
   const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
                            ? index_bits
@@ -187,7 +192,7 @@ void Transpose(const IndexT* rows,
     assert(*lwork >= plan.total);
     detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
         keys_in, keys_out, rows, transpose_cols, nullptr, nullptr, n, key_bits, work, stream,
-        /*signed_keys=*/true, row_bits, /*v1_div=*/0, sample_blocks);
+        /*signed_keys=*/true, row_bits, /*v1_div=*/0, sample_blocks, transpose_remapped_indices);
     return;
   }
   // weighted: sample id AND weight move with the key as two payload arrays (the reference
@@ -201,7 +206,8 @@ void Transpose(const IndexT* rows,
   assert(*lwork >= plan.total);
   detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, rows, transpose_cols, weights,
                                                 transpose_weights, n, key_bits, work, stream,
-                                                /*signed_keys=*/true, row_bits, /*v1_div=*/0, sample_blocks);
+                                                /*signed_keys=*/true, row_bits, /*v1_div=*/0, sample_blocks,
+                                                transpose_remapped_indices);
 }
 
 //! Where Transpose(..., sample_blocks) cuts: lookups [k * L, (k + 1) * L) form block k, L = this value
@@ -231,7 +237,8 @@ void TransposeFixedHotness(const IndexT* indices,
                            size_t* lwork,
                            const hipStream_t stream = 0,
                            const int index_bits = static_cast<int>(sizeof(IndexT) * 8),
-                           const int sample_blocks = 1) {
+                           const int sample_blocks = 1,
+                           IndexT* transpose_remapped_indices = nullptr) {
   using KeyT = typename std::make_unsigned<IndexT>::type;
   const int key_bits = (index_bits > 0 && index_bits < static_cast<int>(sizeof(IndexT) * 8))
                            ? index_bits
@@ -249,7 +256,7 @@ void TransposeFixedHotness(const IndexT* indices,
     assert(*lwork >= plan.total && num_hots > 0 && nnz <= INT32_MAX);
     detail::RadixSortPairs<KeyT, IndexT, detail::NoPayload>(
         keys_in, keys_out, nullptr, transpose_sample_ids, nullptr, nullptr, n, key_bits, work, stream,
-        /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks);
+        /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks, transpose_remapped_indices);
     return;
   }
   const detail::RadixSortPlan<KeyT, IndexT, WeightT> plan(n, key_bits);
@@ -260,7 +267,8 @@ void TransposeFixedHotness(const IndexT* indices,
   assert(*lwork >= plan.total && num_hots > 0 && nnz <= INT32_MAX);
   detail::RadixSortPairs<KeyT, IndexT, WeightT>(keys_in, keys_out, nullptr, transpose_sample_ids, weights,
                                                 transpose_weights, n, key_bits, work, stream,
-                                                /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks);
+                                                /*signed_keys=*/true, /*v1_bits=*/31, /*v1_div=*/num_hots, sample_blocks,
+                                                transpose_remapped_indices);
 }
 
 namespace detail {

@@ -42,43 +42,16 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
+#include "cuembed/include/block_sort_kernels.hpp"
 #include "cuembed/include/blocked_order.hpp"
 #include "cuembed/include/device_shape.hpp"
+#include "cuembed/include/sort_common.hpp"
 
 namespace cuembed {
 namespace detail {
-
-constexpr int kSortThreads = 256;
-constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kSortItems = 16;                          // keys per lane (8 measured 10 % slower)
-static_assert(kSortTile == kSortThreads * kSortItems, "4096 keys per workgroup (blocked_order.hpp)");
-constexpr int kSortBins = 256;                          // 8-bit digits
-
-struct NoPayload {};
-
-//! Lanes of the wavefront (among `valid` ones) whose 8-bit digit equals this lane's.
-//! Per digit bit b: m = ballot(bit b set); a lane keeps the peers that agree with it on bit b,
-//! peers &= ~(m ^ sel) with sel = all-ones if its own bit is set.  That three-input function is
-//! ONE v_bitop3_b32 per mask half on gfx950 (truth table 0x90 = S0 & ~(S1 ^ S2)).
-__device__ __forceinline__ unsigned long long MatchDigit(const unsigned digit, const bool valid) {
-  const unsigned long long v = __ballot(valid);
-  unsigned lo = static_cast<unsigned>(v);
-  unsigned hi = static_cast<unsigned>(v >> 32);
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    const int sel = static_cast<int>(digit << (31 - b)) >> 31;  // bit b ? -1 : 0
-    const unsigned long long m = __ballot(sel != 0);
-    lo = __builtin_amdgcn_bitop3_b32(lo, static_cast<unsigned>(m), static_cast<unsigned>(sel), 0x90);
-    hi = __builtin_amdgcn_bitop3_b32(hi, static_cast<unsigned>(m >> 32), static_cast<unsigned>(sel), 0x90);
-  }
-  return (static_cast<unsigned long long>(hi) << 32) | lo;
-}
-
-__device__ __forceinline__ unsigned long long LanesBelow(const int lane) {
-  return (1ull << lane) - 1ull;
-}
 
 // Passes that cannot move anything are skipped ON THE DEVICE.  The first pass also reduces the
 // keys to `varying` = the bits in which any two keys differ (OR of all keys & ~AND of all keys);
@@ -112,40 +85,6 @@ enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
 enum : int { kStateVarying = 0, kStateAllBits = 1, kStatePayloadBits = 2, kStateWords = 3 };
 
-//! How one sort treats its arrays; the same for every pass and kernel of the sort.
-struct SortMode {
-  int narrow_keys;   //!< NarrowKeys: 64-bit keys stored as 32 bits in the scratch
-  int narrow_v1;     //!< NarrowKeys: 64-bit first payload stored as 32 bits (IfConstantHigh: if all values < 2^32)
-  int use_varying;   //!< passes whose digit is the same for every key are skipped on the device
-  int sign_pass;     //!< pass whose digit holds the sign bit of the keys, or -1
-  // Implicit first payload: v1_div > 0 means "the first payload of input element i is i / v1_div"
-  // (the sample id of lookup i of a fixed-hotness batch) -- pass 0 computes it instead of loading an
-  // array that somebody would have had to write first.  i / d = (i * magic) >> shift for i < 2^31.
-  int v1_div;
-  unsigned v1_magic;
-  int v1_shift;
-};
-
-//! magic / shift with (uint64(i) * magic) >> shift == i / d for every 0 <= i < 2^31, d >= 1:
-//! s = ceil(log2 d), magic = ceil(2^(31+s) / d) < 2^32; the error term i * e / (d * 2^(31+s)) with
-//! e < d <= 2^s stays below 1 / d.
-inline void ImplicitPayloadDivisor(const int d, SortMode* mode) {
-  int s = 0;
-  while ((int64_t{1} << s) < d) ++s;
-  const unsigned __int128 one = static_cast<unsigned __int128>(1) << (31 + s);
-  mode->v1_div = d;
-  mode->v1_magic = static_cast<unsigned>((one + d - 1) / d);
-  mode->v1_shift = 31 + s;
-}
-
-__device__ __forceinline__ unsigned ImplicitPayload(const SortMode& mode, const int64_t i) {
-  return static_cast<unsigned>((static_cast<unsigned long long>(static_cast<unsigned>(i)) * mode.v1_magic) >> mode.v1_shift);
-}
-
-__device__ __forceinline__ unsigned SignFlip(const SortMode& mode, const int pass) {
-  return pass == mode.sign_pass ? 0x80u : 0u;
-}
-
 //! What the device knows about the arrays after pass 0: state[kStateVarying] = bits in which keys
 //! differ, state[kStateAllBits] = AND of all keys, state[kStatePayloadBits] = OR of all 64-bit first
 //! payloads.  state == nullptr: nothing is decided on the device (fixed route, all passes run).
@@ -153,15 +92,18 @@ struct PassPlan {
   bool active;        //!< this pass moves data
   bool first;         //!< reads the caller's input
   int later;          //!< working passes after this one
+  int next;           //!< the next working pass after this one, or -1
   bool narrow_keys;   //!< 64-bit keys are stored as 32 bits in the scratch buffers
   bool narrow_v1;     //!< a 64-bit first payload is stored as 32 bits in the scratch buffers
   unsigned long long key_high;  //!< constant high half to put back (narrow_keys only)
 };
 
-__device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restrict__ state, const int pass,
-                                             const int passes, const SortMode& mode) {
-  const bool know_keys = state != nullptr && mode.use_varying;
-  const unsigned long long varying = know_keys ? state[kStateVarying] : ~0ull;
+//! ... from the three words themselves (`have_state` false: nothing is decided on the device).
+__device__ __forceinline__ PassPlan PlanPassFrom(const bool have_state, const unsigned long long state_varying,
+                                                 const unsigned long long state_all, const unsigned long long state_payload,
+                                                 const int pass, const int passes, const SortMode& mode) {
+  const bool know_keys = have_state && mode.use_varying;
+  const unsigned long long varying = know_keys ? state_varying : ~0ull;
   unsigned active = 1u;  // pass 0 always runs
   for (int q = 1; q < passes; ++q)
     if ((varying >> (8 * q)) & 0xffull) active |= 1u << q;
@@ -169,14 +111,20 @@ __device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restric
   plan.active = (active >> pass) & 1u;
   plan.first = pass == 0;
   plan.later = __popc(active >> (pass + 1));
+  plan.next = (active >> (pass + 1)) != 0 ? pass + static_cast<int>(__ffs(static_cast<int>(active >> (pass + 1)))) : -1;
   plan.narrow_keys = mode.narrow_keys == kNarrowAlways ||
                      (mode.narrow_keys == kNarrowIfConstantHigh && know_keys && (varying >> 32) == 0);
   plan.key_high = (mode.narrow_keys == kNarrowIfConstantHigh && plan.narrow_keys)
-                      ? (state[kStateAllBits] & 0xffffffff00000000ull) : 0ull;
+                      ? (state_all & 0xffffffff00000000ull) : 0ull;
   plan.narrow_v1 = mode.narrow_v1 == kNarrowAlways ||
-                   (mode.narrow_v1 == kNarrowIfConstantHigh && state != nullptr &&
-                    (state[kStatePayloadBits] >> 32) == 0);
+                   (mode.narrow_v1 == kNarrowIfConstantHigh && have_state && (state_payload >> 32) == 0);
   return plan;
+}
+
+__device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restrict__ state, const int pass,
+                                             const int passes, const SortMode& mode) {
+  if (state == nullptr) return PlanPassFrom(false, 0ull, 0ull, 0ull, pass, passes, mode);
+  return PlanPassFrom(true, state[kStateVarying], state[kStateAllBits], state[kStatePayloadBits], pass, passes, mode);
 }
 
 //! Buffers of one array.  Wide: out / scratch alternate backwards from the last working pass.
@@ -205,17 +153,17 @@ struct SortArray {
   T* tmp;
 };
 
-//! Reads kSortItems elements per lane (positions pos0 + r * stride, r = 0..) from wherever the
+//! Reads ITEMS elements per lane (positions pos0 + r * stride, r = 0..) from wherever the
 //! route says.  `high` is OR-ed onto narrow elements.
-template <typename T>
+template <typename T, int ITEMS>
 __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int where, const bool narrow,
                                            const int64_t n, const int64_t pos0, const int stride, const T high,
-                                           T (&item)[kSortItems]) {
+                                           T (&item)[ITEMS]) {
   if constexpr (sizeof(T) == 8) {
     if (narrow && where >= kBufTmp0) {
       const unsigned* p = reinterpret_cast<const unsigned*>(a.tmp) + (where == kBufTmp1 ? n : 0);
 #pragma unroll
-      for (int r = 0; r < kSortItems; ++r) {
+      for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = pos0 + static_cast<int64_t>(r) * stride;
         item[r] = i < n ? static_cast<T>(static_cast<T>(p[i]) | high) : T(0);
       }
@@ -224,7 +172,7 @@ __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int wher
   }
   const T* p = where == kBufIn ? a.in : (where == kBufOut ? a.out : a.tmp);
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int64_t i = pos0 + static_cast<int64_t>(r) * stride;
     if constexpr (std::is_empty<T>::value) {
       (void)i;
@@ -247,11 +195,13 @@ __device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_til
   return (b % xcds) * per_xcd + (b / xcds);
 }
 
-//! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin`.
+//! tile_hist[bin * num_tiles + tile] = number of keys of the tile whose digit is `bin` (kChained: [tile][bin], and
+//! the same array of every LATER pass is zeroed -- the scatter passes fill those themselves, see RadixScatterKernel).
+//! A tile is kSortThreads * ITEMS keys.
 //! Plain LDS atomics: order does not matter for counting.  In pass 0 the tile's OR and AND of
 //! its keys, and the OR of its 64-bit first payloads (`payload64`, or nullptr), go to
 //! tile_bits[kStateWords * tile + ...].
-template <typename KeyT>
+template <typename KeyT, int ITEMS = kSortItems, bool kChained = false>
 __global__ void __launch_bounds__(kSortThreads)
 RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int pass, const int passes,
                          const SortMode mode, unsigned* __restrict__ tile_hist, const int num_tiles,
@@ -275,8 +225,8 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
     where = RouteArray(plan, narrow).src;
   }
   const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles, xcds);
-  const int64_t base = static_cast<int64_t>(tile) * kSortTile + tid;
-  KeyT key[kSortItems];
+  const int64_t base = static_cast<int64_t>(tile) * (kSortThreads * ITEMS) + tid;
+  KeyT key[ITEMS];
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) count[w][tid] = 0;
@@ -285,7 +235,7 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   if (reduce_bits) {
     unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
       const int64_t i = base + static_cast<int64_t>(r) * kSortThreads;
       if (i < n) {
         any |= static_cast<unsigned long long>(key[r]);
@@ -313,13 +263,13 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   if (pass == 0) {
     // the lowest digit of unsorted keys: equal neighbours are rare, one LDS atomic per key is the cheaper way
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
       if (base + static_cast<int64_t>(r) * kSortThreads < n)
         atomicAdd(&count[wave][static_cast<unsigned>(key[r] & 0xff) ^ flip], 1u);
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
       const bool in_range = base + static_cast<int64_t>(r) * kSortThreads < n;
       const unsigned digit = in_range ? (static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip) : 0xffffffffu;
       const unsigned before = __shfl_up(digit, 1);
@@ -335,7 +285,12 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   unsigned total = 0;
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) total += count[w][tid];
-  tile_hist[static_cast<size_t>(tid) * num_tiles + tile] = total;
+  if constexpr (kChained) {
+    tile_hist[static_cast<size_t>(tile) * kSortBins + tid] = total;
+    for (int q = 1; q < passes; ++q) tile_hist[(static_cast<size_t>(q) * num_tiles + tile) * kSortBins + tid] = 0u;
+  } else {
+    tile_hist[static_cast<size_t>(tid) * num_tiles + tile] = total;
+  }
   if (reduce_bits && tid == 0) {
     unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
 #pragma unroll
@@ -455,29 +410,28 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
 }
 
 //! Stable rank of the tile's keys by the digit at `shift`.  Lane l of wave w holds the keys at
-//! TILE-LOCAL positions first_pos + r * 64 (r = 0..kSortItems-1; first_pos = wave * 1024 + lane;
+//! TILE-LOCAL positions first_pos + r * 64 (r = 0..ITEMS-1; first_pos = wave * 64 * ITEMS + lane;
 //! 32-bit on purpose: 64-bit position compares cost the int64 scatter kernel 17 VGPRs); slot[r]
 //! receives the key's tile-local position in digit order (0xffffffff for positions >= n, the
 //! number of keys in the tile).
 //! `wave_count` ([kSortWaves][kSortBins], zeroed by the caller, barrier before the call) ends as
 //! the exclusive prefix over waves, `tile_start[d]` as the tile-local position of the first key
 //! with digit d.  Contains barriers: every thread of the workgroup must call it.
-template <typename KeyT>
-__device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const int shift, const unsigned flip,
+template <typename KeyT, int ITEMS>
+__device__ __forceinline__ void RankTile(const KeyT (&key)[ITEMS], const int shift, const unsigned flip,
                                          const int first_pos, const int n,
                                          unsigned (*wave_count)[kSortBins], unsigned* tile_start,
-                                         unsigned (&slot)[kSortItems]) {
+                                         unsigned (&slot)[ITEMS]) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
-  const int lane = tid & 63;
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const bool valid = first_pos + r * 64 < n;
     const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip;
     const unsigned long long peers = MatchDigit(digit, valid);
     // every peer reads the wave's running count of its digit (one LDS broadcast per digit), then
     // the lowest peer bumps it; a wavefront's LDS operations execute in program order
-    const unsigned lower = static_cast<unsigned>(__popcll(peers & LanesBelow(lane)));
+    const unsigned lower = CountBelow(peers);
     unsigned start = 0;
     if (valid) start = wave_count[wave][digit];
     __builtin_amdgcn_wave_barrier();
@@ -499,7 +453,7 @@ __device__ __forceinline__ void RankTile(const KeyT (&key)[kSortItems], const in
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     if (slot[r] != 0xffffffffu) {
       const unsigned digit = static_cast<unsigned>((key[r] >> shift) & 0xff) ^ flip;
       slot[r] += tile_start[digit] + wave_count[wave][digit];
@@ -526,20 +480,20 @@ __device__ __forceinline__ void StoreRouted(const SortArray<T>& a, const int whe
   p[dest] = value;
 }
 
-template <typename T>
-__device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T (&item)[kSortItems],
-                                              const unsigned (&slot)[kSortItems],
-                                              const unsigned (&dest)[kSortItems], const int count,
+template <typename T, int ITEMS>
+__device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T (&item)[ITEMS],
+                                              const unsigned (&slot)[ITEMS],
+                                              const unsigned (&dest)[ITEMS], const int count,
                                               const SortArray<T>& a, const int where, const bool narrow,
                                               const int64_t n) {
   T* stage = reinterpret_cast<T*>(stage_raw);
   __syncthreads();  // previous user of the staging buffer is done
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r)
+  for (int r = 0; r < ITEMS; ++r)
     if (slot[r] != 0xffffffffu) stage[slot[r]] = item[r];
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int q = r * kSortThreads + threadIdx.x;
     if (q < count) StoreRouted<T>(a, where, narrow, n, dest[r], stage[q]);
   }
@@ -547,27 +501,29 @@ __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T 
 
 // (second launch bound = wavefronts per SIMD: 4 workgroups of 4 waves per CU, i.e. at most 128
 // VGPRs -- with 1024 tiles on 256 CUs a fifth of the tiles would otherwise wait for a second round)
-template <typename KeyT, typename V1, typename V2>
+//
+// kChained (inputs of up to kChainedSortMax keys, tiles of kSortThreads * ITEMS keys): ONE launch per pass.  At these
+// sizes a dependent launch costs 3.5-5 us whatever it does (profiles/r05_small_sort_baseline.txt), so the histogram
+// launch of every pass but the first is folded into the scatter launch before it: while a workgroup of pass p writes a
+// key to its new position it also counts it -- a global atomic, one per run of equal (destination tile, next digit)
+// among neighbouring keys, so a hot index costs a few atomics per wavefront, not one per lookup -- into the histogram
+// of the pass that runs NEXT ([pass][tile][bin] words in `tile_prefix`, zeroed by pass 0's histogram launch).  Every
+// workgroup adds up the per-tile counts it needs itself (no scan launch), and the OR / AND words of the keys are folded
+// by every workgroup of pass 0 (no extra workgroup): 12-16 launches become 1 + the number of passes.
+template <typename KeyT, typename V1, typename V2, int ITEMS = kSortItems, bool kChained = false>
 __global__ void __launch_bounds__(kSortThreads, 4)
 RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
                    const int64_t n, const int pass, const int passes, const SortMode mode,
                    const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
                    const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles,
-                   const int xcds) {
-  // which of (caller's input, caller's output, scratch) this pass reads and writes follows from
-  // the passes that run at all and from how each array is stored in the scratch
-  const PassPlan plan = PlanPass(state, pass, passes, mode);
-  if (!plan.active) return;
-  const int shift = 8 * pass;
-  const unsigned flip = SignFlip(mode, pass);
+                   const int xcds, unsigned* next_hist = nullptr /* kChained: the [pass][tile][bin] words, writable */,
+                   const unsigned long long* __restrict__ tile_bits = nullptr /* kChained, pass 0: the tiles' OR / AND words */,
+                   unsigned long long* __restrict__ state_out = nullptr /* kChained, pass 0: where their fold goes */) {
+  constexpr int kTile = kSortThreads * ITEMS;
   constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
   constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
-  const bool narrow_v1 = kHasV1 && sizeof(V1) == 8 && plan.narrow_v1;  // all values in [0, 2^32)
-  const ArrayRoute key_route = RouteArray(plan, plan.narrow_keys);
-  const ArrayRoute v1_route = RouteArray(plan, narrow_v1);
-  const ArrayRoute v2_route = RouteArray(plan, false);
   constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
-  __shared__ __attribute__((aligned(16))) unsigned char stage[kSortTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[kTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
   __shared__ unsigned digit_base[kSortBins];   // global position of the tile's first key with this digit
   __shared__ unsigned tile_start[kSortBins];   // tile-local position of the first key with this digit
   __shared__ unsigned wave_count[kSortWaves][kSortBins];  // becomes the exclusive prefix over waves
@@ -575,28 +531,174 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles, xcds);
-  const int64_t tile_base = static_cast<int64_t>(tile) * kSortTile;
-  const int count = static_cast<int>(n - tile_base < kSortTile ? n - tile_base : kSortTile);
+  const int64_t tile_base = static_cast<int64_t>(tile) * kTile;
+  const int count = static_cast<int>(n - tile_base < kTile ? n - tile_base : kTile);
+  const int64_t wave_base = tile_base + wave * (64 * ITEMS);
+  KeyT key[ITEMS];
+  // which of (caller's input, caller's output, scratch) this pass reads and writes follows from
+  // the passes that run at all and from how each array is stored in the scratch
+  PassPlan plan;
+  bool keys_requested = false, payload_requested = false;
+  constexpr int kEarlyItems = (kChained && kHasV1 && sizeof(V1) == 4) ? ITEMS : 1;
+  V1 early1_out[kEarlyItems], early1_tmp[kEarlyItems];   // (kChained: a 32-bit first payload from both possible sources)
+  // kChained: this pass's per-tile counts ([tile][bin]) are added up by every workgroup itself.  Lane q of every
+  // wavefront owns bins 4 q .. 4 q + 3 (one 16-byte load per tile row), wavefront w the tiles w, w + 4, ...; the first
+  // kFoldBatch rows per wavefront (64 tiles in all) are requested HERE, before anything is waited for -- the counts came
+  // through memory-side atomics and every dependent round trip to them costs ~2 us.
+  typedef unsigned __attribute__((ext_vector_type(4))) count4_t;
+  constexpr int kFoldBatch = kChained ? 16 : 1;
+  count4_t fold_rows[kFoldBatch];
+  if constexpr (kChained) {
+    const count4_t* rows = reinterpret_cast<const count4_t*>(tile_prefix + static_cast<size_t>(pass) * num_tiles * kSortBins) + lane;
+#pragma unroll
+    for (int j = 0; j < kFoldBatch; ++j) {
+      const int t = wave + kSortWaves * j;
+      fold_rows[j] = t < num_tiles ? rows[static_cast<size_t>(t) * (kSortBins / 4)] : count4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  if constexpr (kChained) {
+    if (pass == 0) {
+      // the first pass always reads the caller's input: request it, then find out what the later passes will do
+      LoadRouted<KeyT>(keys, kBufIn, false, n, wave_base + lane, 64, KeyT(0), key);
+      keys_requested = true;
+      if (tile_bits != nullptr) {
+        __shared__ unsigned long long fold[kSortWaves][kStateWords];
+        unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
+        for (int t = tid; t < num_tiles; t += kSortThreads) {
+          any |= tile_bits[kStateWords * t];
+          all &= tile_bits[kStateWords * t + 1];
+          pay |= tile_bits[kStateWords * t + 2];
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          any |= __shfl_xor(any, d);
+          all &= __shfl_xor(all, d);
+          pay |= __shfl_xor(pay, d);
+        }
+        if (lane == 0) {
+          fold[wave][0] = any;
+          fold[wave][1] = all;
+          fold[wave][2] = pay;
+        }
+        __syncthreads();
+        any = 0ull;
+        all = ~0ull;
+        pay = 0ull;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+          any |= fold[w][0];
+          all &= fold[w][1];
+          pay |= fold[w][2];
+        }
+        plan = PlanPassFrom(true, any & ~all, all, pay, 0, passes, mode);
+        if (blockIdx.x == 0 && tid == 0) {   // (every workgroup computes the same three words; one writes them)
+          state_out[kStateVarying] = any & ~all;
+          state_out[kStateAllBits] = all;
+          state_out[kStatePayloadBits] = pay;
+        }
+      } else {
+        plan = PlanPassFrom(false, 0ull, 0ull, 0ull, 0, passes, mode);
+      }
+    } else {
+      // A later pass reads the caller's output or the scratch, depending on how many passes run after it -- which the
+      // three state words say.  Waiting for them before requesting the keys costs a full memory round trip (~2 us: the
+      // words were written by another XCD) per pass; 32-bit arrays have only two possible sources, so BOTH are
+      // requested together with the state and the right one is kept.
+      if constexpr (sizeof(KeyT) == 4) {
+        if (state != nullptr) {
+          KeyT from_out[ITEMS], from_tmp[ITEMS];
+          LoadRouted<KeyT>(keys, kBufOut, false, n, wave_base + lane, 64, KeyT(0), from_out);
+          LoadRouted<KeyT>(keys, kBufTmp0, false, n, wave_base + lane, 64, KeyT(0), from_tmp);
+          if constexpr (kHasV1 && sizeof(V1) == 4) {
+            LoadRouted<V1>(v1, kBufOut, false, n, wave_base + lane, 64, V1(0), early1_out);
+            LoadRouted<V1>(v1, kBufTmp0, false, n, wave_base + lane, 64, V1(0), early1_tmp);
+          }
+          plan = PlanPass(state, pass, passes, mode);
+          const bool use_out = RouteArray(plan, false).src == kBufOut;
+#pragma unroll
+          for (int r = 0; r < ITEMS; ++r) key[r] = use_out ? from_out[r] : from_tmp[r];
+          keys_requested = true;
+          payload_requested = kHasV1 && sizeof(V1) == 4;
+        } else {
+          plan = PlanPass(state, pass, passes, mode);
+        }
+      } else {
+        plan = PlanPass(state, pass, passes, mode);
+      }
+    }
+  } else {
+    plan = PlanPass(state, pass, passes, mode);
+  }
+  if (!plan.active) return;
+  const int shift = 8 * pass;
+  const unsigned flip = SignFlip(mode, pass);
+  const bool narrow_v1 = kHasV1 && sizeof(V1) == 8 && plan.narrow_v1;  // all values in [0, 2^32)
+  const ArrayRoute key_route = RouteArray(plan, plan.narrow_keys);
+  const ArrayRoute v1_route = RouteArray(plan, narrow_v1);
+  const ArrayRoute v2_route = RouteArray(plan, false);
   // ---- load first (everything in flight at once): the digit bases below are computed under the loads' latency ----
-  const int64_t wave_base = tile_base + wave * (64 * kSortItems);
-  KeyT key[kSortItems];
-  LoadRouted<KeyT>(keys, key_route.src, plan.narrow_keys, n, wave_base + lane, 64,
-                   static_cast<KeyT>(plan.key_high), key);
+  if (!keys_requested)
+    LoadRouted<KeyT>(keys, key_route.src, plan.narrow_keys, n, wave_base + lane, 64,
+                     static_cast<KeyT>(plan.key_high), key);
   // A 32-bit first payload is requested now as well, so that its latency overlaps the ranking.
   // A 64-bit one would push the kernel past 128 VGPRs (3 instead of 4 resident workgroups per CU,
   // i.e. a second round for a quarter of the 1024 tiles); it is loaded after the keys have left.
   constexpr bool kEarlyV1 = kHasV1 && sizeof(V1) <= 4;
-  V1 item1[kSortItems];
+  V1 item1[ITEMS];
   const bool implicit_v1 = kHasV1 && plan.first && mode.v1_div > 0;
   if constexpr (kEarlyV1) {
-    if (!implicit_v1) LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
+    if (payload_requested) {
+      if constexpr (kChained && kHasV1 && sizeof(V1) == 4) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) item1[r] = v1_route.src == kBufOut ? early1_out[r] : early1_tmp[r];
+      }
+    } else if (!implicit_v1) {
+      LoadRouted<V1>(v1, v1_route.src, false, n, wave_base + lane, 64, V1(0), item1);
+    }
   }
   {
     unsigned before_me, bin_sum;
     unsigned segment_start = 0;   // the tile's segment is sorted on its own: positions start at its first element
-    if (bin_total != nullptr) {
+    if constexpr (kChained) {
+      __shared__ __attribute__((aligned(16))) unsigned fold_part[kSortWaves][2][kSortBins];
+      count4_t before4 = count4_t{0u, 0u, 0u, 0u}, total4 = count4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < kFoldBatch; ++j) {
+        const int t = wave + kSortWaves * j;
+        if (t < tile) before4 += fold_rows[j];
+        total4 += fold_rows[j];            // (rows past num_tiles were set to zero)
+      }
+      if (num_tiles > kSortWaves * kFoldBatch) {   // more than 64 tiles: further batches of 16 rows per wavefront
+        const count4_t* rows =
+            reinterpret_cast<const count4_t*>(tile_prefix + static_cast<size_t>(pass) * num_tiles * kSortBins) + lane;
+        for (int j0 = kFoldBatch; wave + kSortWaves * j0 < num_tiles; j0 += kFoldBatch) {
+          count4_t more[kFoldBatch];
+#pragma unroll
+          for (int j = 0; j < kFoldBatch; ++j) {
+            const int t = wave + kSortWaves * (j0 + j);
+            more[j] = t < num_tiles ? rows[static_cast<size_t>(t) * (kSortBins / 4)] : count4_t{0u, 0u, 0u, 0u};
+          }
+#pragma unroll
+          for (int j = 0; j < kFoldBatch; ++j) {
+            const int t = wave + kSortWaves * (j0 + j);
+            if (t < tile) before4 += more[j];
+            total4 += more[j];
+          }
+        }
+      }
+      *reinterpret_cast<count4_t*>(&fold_part[wave][0][4 * lane]) = before4;
+      *reinterpret_cast<count4_t*>(&fold_part[wave][1][4 * lane]) = total4;
+      __syncthreads();
+      before_me = 0;
+      bin_sum = 0;
+#pragma unroll
+      for (int w = 0; w < kSortWaves; ++w) {
+        before_me += fold_part[w][0][tid];
+        bin_sum += fold_part[w][1][tid];
+      }
+    } else if (bin_total != nullptr) {
       const int segment = tile / segment_tiles;
-      segment_start = static_cast<unsigned>(segment) * static_cast<unsigned>(segment_tiles) * kSortTile;
+      segment_start = static_cast<unsigned>(segment) * static_cast<unsigned>(segment_tiles) * kTile;
       before_me = tile_prefix[static_cast<size_t>(tid) * num_tiles + tile];
       bin_sum = bin_total[segment * kSortBins + tid];
     } else {
@@ -619,18 +721,18 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   __syncthreads();
 
   // ---- rank inside the wave ----
-  unsigned slot[kSortItems];  // tile-local position in digit order
-  RankTile<KeyT>(key, shift, flip, wave * (64 * kSortItems) + lane, count, wave_count, tile_start, slot);
+  unsigned slot[ITEMS];  // tile-local position in digit order
+  RankTile<KeyT>(key, shift, flip, wave * (64 * ITEMS) + lane, count, wave_count, tile_start, slot);
 
   // ---- keys: through LDS into digit order, then out in runs ----
   KeyT* stage_keys = reinterpret_cast<KeyT*>(stage);
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r)
+  for (int r = 0; r < ITEMS; ++r)
     if (slot[r] != 0xffffffffu) stage_keys[slot[r]] = key[r];
   __syncthreads();
-  unsigned dest[kSortItems];  // global position of the element at tile-local position q
+  unsigned dest[ITEMS];  // global position of the element at tile-local position q
 #pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int q = r * kSortThreads + tid;
     if (q < count) {
       const KeyT k = stage_keys[q];
@@ -639,12 +741,38 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
       StoreRouted<KeyT>(keys, key_route.dst, plan.narrow_keys, n, dest[r], k);
     }
   }
+  if constexpr (kChained) {
+    // ---- the histogram of the NEXT working pass: its tiles are cut from the positions this pass writes ----
+    if (plan.next >= 0) {
+      unsigned* counts = next_hist + static_cast<size_t>(plan.next) * num_tiles * kSortBins;
+      const int next_shift = 8 * plan.next;
+      const unsigned next_flip = SignFlip(mode, plan.next);
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        const int q = r * kSortThreads + tid;
+        unsigned word = 0xffffffffu;   // (destination tile, next digit) of the key at tile-local position q
+        if (q < count) {
+          const KeyT k = stage_keys[q];
+          word = (dest[r] / kTile) * kSortBins + (static_cast<unsigned>((k >> next_shift) & 0xff) ^ next_flip);
+        }
+        // neighbours in digit order go to neighbouring positions: only the first lane of a run of equal words adds,
+        // and it adds the run's length
+        const unsigned before = __shfl_up(word, 1);
+        const bool head = lane == 0 || before != word;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+        const unsigned run = above != 0 ? static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
+                                        : static_cast<unsigned>(64 - lane);
+        if (head && word != 0xffffffffu) atomicAdd(&counts[word], run);
+      }
+    }
+  }
   // ---- payloads take the same route ----
   if constexpr (kHasV1) {
     if (implicit_v1) {
       if constexpr (!std::is_same<V1, NoPayload>::value) {
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r)
+        for (int r = 0; r < ITEMS; ++r)
           item1[r] = static_cast<V1>(ImplicitPayload(mode, wave_base + lane + r * 64));
       }
     } else {
@@ -653,118 +781,45 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     StageAndStore<V1>(stage, item1, slot, dest, count, v1, v1_route.dst, narrow_v1, n);
   }
   if constexpr (kHasV2) {
-    V2 item[kSortItems];
+    V2 item[ITEMS];
     LoadRouted<V2>(v2, v2_route.src, false, n, wave_base + lane, 64, V2(), item);
     StageAndStore<V2>(stage, item, slot, dest, count, v2, v2_route.dst, false, n);
   }
 }
 
-//! Whole sort of at most kSortTile elements in ONE launch: keys and payloads stay in registers,
-//! every working pass ranks them (RankTile) and permutes them through LDS; digits that do not
-//! vary are skipped (the OR / AND reduction is block-local here).  Small problems are launch
-//! bound: this replaces 3 launches per pass.
-template <typename T>
-__device__ __forceinline__ void PermuteThroughLds(unsigned char* stage_raw, T (&item)[kSortItems],
-                                                  const unsigned (&slot)[kSortItems], const int first_pos,
-                                                  const int n) {
-  T* stage = reinterpret_cast<T*>(stage_raw);
-  __syncthreads();  // previous user of the staging buffer is done
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r)
-    if (slot[r] != 0xffffffffu) stage[slot[r]] = item[r];
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r)
-    if (first_pos + r * 64 < n) item[r] = stage[first_pos + r * 64];
+//! Largest input the one-workgroup sort takes (tuning: CUEMBED_BLOCK_SORT_MAX, read once; never above kBlockSortMax).
+inline int BlockSortLimit() {
+  static const int limit = [] {
+    const char* e = std::getenv("CUEMBED_BLOCK_SORT_MAX");
+    const int v = e != nullptr ? std::atoi(e) : kBlockSortMax;
+    return v < 1 ? 1 : (v > kBlockSortMax ? kBlockSortMax : v);
+  }();
+  return limit;
 }
 
-template <typename KeyT, typename V1, typename V2>
-__global__ void __launch_bounds__(kSortThreads)
-SingleTileSortKernel(const KeyT* __restrict__ keys_in, KeyT* __restrict__ keys_out,
-                     const V1* __restrict__ v1_in, V1* __restrict__ v1_out,
-                     const V2* __restrict__ v2_in, V2* __restrict__ v2_out, const int n, const int passes,
-                     const int sign_pass, const int v1_div) {
-  constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
-  constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
-  constexpr size_t kStageElem = sizeof(KeyT) > sizeof(V1) ? sizeof(KeyT) : sizeof(V1);
-  __shared__ __attribute__((aligned(16))) unsigned char stage[kSortTile * (kStageElem > sizeof(V2) ? kStageElem : sizeof(V2))];
-  __shared__ unsigned tile_start[kSortBins];
-  __shared__ unsigned wave_count[kSortWaves][kSortBins];
-  __shared__ unsigned long long wave_bits[kSortWaves][2];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6;
-  const int lane = tid & 63;
-  const int first_pos = wave * (64 * kSortItems) + lane;
-  KeyT key[kSortItems];
-  V1 item1[kSortItems];
-  V2 item2[kSortItems];
-  unsigned long long any = 0ull, all = ~0ull;
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const int i = first_pos + r * 64;
-    key[r] = KeyT(0);
-    if (i < n) {
-      key[r] = keys_in[i];
-      if constexpr (kHasV1) item1[r] = v1_div > 0 ? static_cast<V1>(i / v1_div) : v1_in[i];
-      if constexpr (kHasV2) item2[r] = v2_in[i];
-      any |= static_cast<unsigned long long>(key[r]);
-      all &= static_cast<unsigned long long>(key[r]);
-    }
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    any |= __shfl_xor(any, d);
-    all &= __shfl_xor(all, d);
-  }
-  if (lane == 0) {
-    wave_bits[wave][0] = any;
-    wave_bits[wave][1] = all;
-  }
-  __syncthreads();
-  any = 0ull;
-  all = ~0ull;
-#pragma unroll
-  for (int w = 0; w < kSortWaves; ++w) {
-    any |= wave_bits[w][0];
-    all &= wave_bits[w][1];
-  }
-  const unsigned long long varying = any & ~all;
-  for (int pass = 0; pass < passes; ++pass) {
-    const int shift = 8 * pass;
-    if (((varying >> shift) & 0xffull) == 0) continue;  // every key has the same digit here
-    __syncthreads();                                     // wave_count / tile_start of the previous pass are done
-#pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) wave_count[w][tid] = 0;
-    __syncthreads();
-    unsigned slot[kSortItems];
-    RankTile<KeyT>(key, shift, pass == sign_pass ? 0x80u : 0u, first_pos, n, wave_count, tile_start, slot);
-    PermuteThroughLds<KeyT>(stage, key, slot, first_pos, n);
-    if constexpr (kHasV1) PermuteThroughLds<V1>(stage, item1, slot, first_pos, n);
-    if constexpr (kHasV2) PermuteThroughLds<V2>(stage, item2, slot, first_pos, n);
-  }
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const int i = first_pos + r * 64;
-    if (i < n) {
-      keys_out[i] = key[r];
-      if constexpr (kHasV1) v1_out[i] = item1[r];
-      if constexpr (kHasV2) v2_out[i] = item2[r];
-    }
-  }
+//! Inputs of up to this many keys are sorted by the chained kernels (one launch per pass, RadixScatterKernel<...,
+//! kChained>), in tiles of kSortThreads * ChainedSortItems(n) keys: small tiles while that leaves at most 256 of them
+//! -- a workgroup then ranks 4 rounds of 64 keys per wavefront instead of 16, and 64-256 compute units work on a pass
+//! instead of 16-64.
+constexpr size_t kChainedSortMax = size_t{1} << 18;
+constexpr int kChainedSortItems = 4;
+inline int ChainedSortTiles(const size_t n) {
+  const size_t tile = static_cast<size_t>(kSortThreads) * kChainedSortItems;
+  return static_cast<int>((n + tile - 1) / tile);
 }
-
-inline size_t SortAlign(size_t v) { return (v + 255) / 256 * 256; }
 
 template <typename KeyT, typename V1, typename V2>
 struct RadixSortPlan {
   int passes;
   int num_tiles;
+  int chained_tiles;   //!< > 0: n <= kChainedSortMax, tiles of the chained kernels
   size_t keys_tmp, v1_tmp, v2_tmp, tile_hist, bin_total, tile_bits, varying, total;  // byte offsets
   RadixSortPlan(const size_t n, const int key_bits) {
     passes = (key_bits + 7) / 8;
     if (passes < 1) passes = 1;
     num_tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
     if (num_tiles < 1) num_tiles = 1;
+    chained_tiles = (n > 0 && n <= kChainedSortMax) ? ChainedSortTiles(n) : 0;
     size_t off = 0;
     keys_tmp = off;
     off += SortAlign(n * sizeof(KeyT));
@@ -772,17 +827,25 @@ struct RadixSortPlan {
     if (!std::is_same<V1, NoPayload>::value) off += SortAlign(n * sizeof(V1));
     v2_tmp = off;
     if (!std::is_same<V2, NoPayload>::value) off += SortAlign(n * sizeof(V2));
-    tile_hist = off;
-    off += SortAlign(static_cast<size_t>(kSortBins) * num_tiles * sizeof(unsigned));
+    tile_hist = off;   // [bin][tile] of the current pass; chained: [pass][tile][bin] of every pass
+    const size_t hist_words = chained_tiles > 0 ? static_cast<size_t>(passes) * chained_tiles * kSortBins
+                                                : static_cast<size_t>(kSortBins) * num_tiles;
+    off += SortAlign((hist_words > static_cast<size_t>(kSortBins) * num_tiles ? hist_words
+                                                                             : static_cast<size_t>(kSortBins) * num_tiles) *
+                     sizeof(unsigned));
     bin_total = off;
     off += SortAlign(static_cast<size_t>(kMaxSortSegments) * kSortBins * sizeof(unsigned));
     tile_bits = off;
-    off += SortAlign(static_cast<size_t>(kStateWords) * num_tiles * sizeof(unsigned long long));
+    off += SortAlign(static_cast<size_t>(kStateWords) * (chained_tiles > num_tiles ? chained_tiles : num_tiles) *
+                     sizeof(unsigned long long));
     varying = off;
     off += SortAlign(kStateWords * sizeof(unsigned long long));
     total = off;
   }
 };
+
+template <typename IndexT>
+inline void RunHeadScan(const IndexT* indices, const size_t n, IndexT* remapped, char* work, hipStream_t stream);
 
 //! Stable sort of n (key, v1[, v2]) by the low `key_bits` bits of the key.  Inputs are not
 //! modified; outputs and `work` (at least RadixSortPlan::total bytes) must not overlap the inputs.
@@ -798,17 +861,23 @@ struct RadixSortPlan {
 //!                ON ITS OWN: the output is the concatenation of the sorted blocks (same kernels, same launches;
 //!                only the tile scan and the digit bases are per block).  At most kMaxSortSegments; ignored for
 //!                inputs of up to kFoldScanTiles tiles.
+//!   remapped   : not null: also receives the run-head ids of the SORTED keys (RunHeadScan below: remapped[i] = number
+//!                of k in (0, i] with keys_out[k] != keys_out[k - 1]) -- inside the one launch of a small sort, by the
+//!                run-head scan's own launches after a large one (`work` is re-used: the sort is done with it by then).
 template <typename KeyT, typename V1, typename V2>
 inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in, V1* v1_out,
                            const V2* v2_in, V2* v2_out, const size_t n, const int key_bits,
                            char* work, hipStream_t stream, const bool signed_keys = false,
-                           const int v1_bits = 0, const int v1_div = 0, const int blocks = 1) {
+                           const int v1_bits = 0, const int v1_div = 0, const int blocks = 1,
+                           typename std::make_signed<KeyT>::type* remapped = nullptr) {
   if (n == 0) return;
   const RadixSortPlan<KeyT, V1, V2> plan(n, key_bits);
   const int sign_pass = (signed_keys && key_bits >= static_cast<int>(8 * sizeof(KeyT))) ? plan.passes - 1 : -1;
-  if (n <= static_cast<size_t>(kSortTile)) {
-    SingleTileSortKernel<KeyT, V1, V2><<<1, kSortThreads, 0, stream>>>(
-        keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes, sign_pass, v1_div);
+  if (n <= static_cast<size_t>(BlockSortLimit())) {   // one workgroup, one launch: block_sort_kernels.hpp
+    SortMode small{};
+    if (v1_div > 0) ImplicitPayloadDivisor(v1_div, &small);
+    BlockSortLaunch<KeyT, V1, V2>(keys_in, keys_out, v1_in, v1_out, v2_in, v2_out, static_cast<int>(n), plan.passes,
+                                  sign_pass, small, remapped, stream);
     return;
   }
   const SortArray<KeyT> keys{keys_in, keys_out, reinterpret_cast<KeyT*>(work + plan.keys_tmp)};
@@ -841,6 +910,20 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   const int segment_tiles = static_cast<int>(SortSegmentLength(n, blocks) / kSortTile);
   const int segments = (plan.num_tiles + segment_tiles - 1) / segment_tiles;
   const int xcds = CurrentDeviceShape().xcds;   // tile maps keep runs of tiles on one XCD
+  if (plan.chained_tiles > 0 && segments == 1) {
+    // one histogram launch, then ONE launch per pass (see RadixScatterKernel, kChained)
+    const int tiles = plan.chained_tiles;
+    RadixTileHistogramKernel<KeyT, kChainedSortItems, true><<<tiles, kSortThreads, 0, stream>>>(
+        keys, count, 0, plan.passes, mode, tile_hist, tiles, tile_bits, nullptr, payload64, xcds);
+    for (int p = 0; p < plan.passes; ++p)
+      RadixScatterKernel<KeyT, V1, V2, kChainedSortItems, true><<<tiles, kSortThreads, 0, stream>>>(
+          keys, v1, v2, count, p, plan.passes, mode, tile_hist, nullptr, tiles, state, tiles, xcds, tile_hist,
+          p == 0 ? tile_bits : nullptr, state);
+    if (remapped != nullptr)
+      RunHeadScan<typename std::make_signed<KeyT>::type>(
+          reinterpret_cast<const typename std::make_signed<KeyT>::type*>(keys_out), n, remapped, work, stream);
+    return;
+  }
   for (int p = 0; p < plan.passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64, xcds);
@@ -852,6 +935,9 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
         keys, v1, v2, count, p, plan.passes, mode, tile_hist, fold_scan ? nullptr : bin_total,
         plan.num_tiles, state, segment_tiles, xcds);
   }
+  if (remapped != nullptr)
+    RunHeadScan<typename std::make_signed<KeyT>::type>(reinterpret_cast<const typename std::make_signed<KeyT>::type*>(keys_out),
+                                                       n, remapped, work, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -933,6 +1019,55 @@ RunHeadTilePrefixKernel(unsigned* __restrict__ tile_count, const int num_tiles) 
   }
 }
 
+//! Up to this many tiles (16,384 elements) the run-head scan is ONE launch: every workgroup counts the run heads of
+//! the elements before its tile itself -- ONE batch of 16-byte loads per lane -- instead of waiting for a count launch
+//! (two dependent launches of ~4.5 us each).  Not beyond: the array was written by other XCDs and comes from memory,
+//! ~2 us per dependent batch (measured: 6.2 us at 4 tiles against 9.0 for two launches, but 7.8 at 8 and 12.2 at 16).
+constexpr int kSelfCountTiles = 4;
+
+//! Run heads among elements [1, upto) of `indices` (element i is one when it differs from element i - 1), counted by the
+//! whole workgroup; every thread returns its share (the caller adds them up).  16 bytes per lane and load when the array
+//! is 16-byte aligned, all loads of a batch requested before the first compare.
+template <typename IndexT, int kThreads = kSortThreads>
+__device__ __forceinline__ unsigned CountRunHeadsBefore(const IndexT* __restrict__ indices, const int64_t upto) {
+  constexpr int kVec = 16 / static_cast<int>(sizeof(IndexT));
+  typedef IndexT __attribute__((ext_vector_type(kVec))) vec_t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  unsigned heads = 0;
+  if ((reinterpret_cast<uintptr_t>(indices) & 15) != 0) {   // (a caller's oddly aligned view: element by element)
+    for (int64_t i = 1 + tid; i < upto; i += kThreads) heads += indices[i] != indices[i - 1] ? 1u : 0u;
+    return heads;
+  }
+  constexpr int kBatch = kThreads > kSortThreads ? 12 : 16;   // (1024-thread workgroups have 128 registers per lane)
+  const int64_t groups = upto / kVec;                        // whole vectors; the ragged end is handled below
+  for (int64_t g0 = 0; g0 < groups; g0 += static_cast<int64_t>(kBatch) * kThreads) {
+    vec_t v[kBatch];
+    IndexT edge[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const int64_t g = g0 + static_cast<int64_t>(b) * kThreads + tid;
+      v[b] = g < groups ? *reinterpret_cast<const vec_t*>(indices + g * kVec) : vec_t(0);
+      // the element before a wavefront's first vector comes from memory; the other lanes get it from their neighbour
+      edge[b] = (lane == 0 && g > 0 && g < groups) ? indices[g * kVec - 1] : IndexT(0);
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const int64_t g = g0 + static_cast<int64_t>(b) * kThreads + tid;
+      IndexT prev = __shfl_up(v[b][kVec - 1], 1);
+      if (lane == 0) prev = edge[b];
+      if (g < groups) {
+        if (g > 0) heads += v[b][0] != prev ? 1u : 0u;
+#pragma unroll
+        for (int e = 1; e < kVec; ++e) heads += v[b][e] != v[b][e - 1] ? 1u : 0u;
+      }
+    }
+  }
+  for (int64_t i = groups * kVec + tid; i < upto; i += kThreads)
+    if (i > 0) heads += indices[i] != indices[i - 1] ? 1u : 0u;
+  return heads;
+}
+
 //! What RunHeadScanKernel does with u[i] = the number of run heads in (0, i]:
 //!   kIds       remapped[i] = u[i]                       (ComputeCompressedGradIndices)
 //!   kCompact   the same, and unique_keys[u[i]] = indices[i] at every run head (and i = 0); block_start[b] =
@@ -945,7 +1080,7 @@ constexpr unsigned kFenceStride = 256;
 template <typename IndexT, RunHeadOutput kOut>
 __global__ void __launch_bounds__(kSortThreads)
 RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
-                  const unsigned* __restrict__ tile_count /* run heads per tile; null: one tile */,
+                  const unsigned* __restrict__ tile_count /* run heads per tile; null: no count launch ran (few tiles) */,
                   const bool tile_count_is_prefix,
                   IndexT* __restrict__ remapped,
                   const int block_tiles,
@@ -973,6 +1108,10 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
     } else {
       for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += kSortThreads) before += tile_count[t];
     }
+  } else if (blockIdx.x > 0) {
+    // no count launch (few tiles): the run heads of everything before this tile are counted here.  The tile's own
+    // first element is a head of THIS tile (WaveRunHeads); blocks (block_tiles > 0) never come this way.
+    before = CountRunHeadsBefore<IndexT>(indices, static_cast<int64_t>(blockIdx.x) * kSortTile);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
@@ -1008,6 +1147,68 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
   }
 }
 
+//! The run-head scan of 5 .. kWideSelfCountTiles tiles (up to 131,072 elements) in ONE launch: 1024-thread workgroups,
+//! one per 4096-element tile; every workgroup counts the run heads before its tile itself, four times as many lanes
+//! sharing that work as in RunHeadScanKernel (at most two batches of 16 loads per lane: ~4 us for the last tile,
+//! against ~9 us for the count launch + the scan launch).  kIds output only.
+constexpr int kWideSelfCountTiles = 32;
+constexpr int kWideScanThreads = 1024;
+
+template <typename IndexT>
+__global__ void __launch_bounds__(kWideScanThreads)
+RunHeadScanWideKernel(const IndexT* __restrict__ indices, const int64_t n, IndexT* __restrict__ remapped) {
+  constexpr int kWaves = kWideScanThreads / 64;
+  constexpr int kRounds = kSortTile / kWideScanThreads;      // 4 rounds of 64 consecutive elements per wavefront
+  __shared__ unsigned wave_sum[kWaves];
+  __shared__ unsigned wave_before[kWaves];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_base = static_cast<int64_t>(blockIdx.x) * kSortTile + wave * (64 * kRounds);
+  IndexT cur[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = wave_base + r * 64 + lane;
+    cur[r] = i < n ? indices[i] : IndexT(0);
+  }
+  IndexT edge = IndexT(0);   // the element before the wavefront's first one
+  if (lane == 0 && wave_base > 0 && wave_base <= n) edge = indices[wave_base - 1];
+  // the elements before this tile: requested now, counted below
+  unsigned before = blockIdx.x > 0
+                        ? CountRunHeadsBefore<IndexT, kWideScanThreads>(indices, static_cast<int64_t>(blockIdx.x) * kSortTile)
+                        : 0u;
+  unsigned long long heads[kRounds];
+  unsigned c = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = wave_base + r * 64 + lane;
+    IndexT prev = __shfl_up(cur[r], 1);
+    const IndexT last_of_previous_round = r > 0 ? __shfl(cur[r > 0 ? r - 1 : 0], 63) : edge;
+    if (lane == 0) prev = last_of_previous_round;
+    heads[r] = __ballot(i > 0 && i < n && cur[r] != prev);
+    c += static_cast<unsigned>(__popcll(heads[r]));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  if (lane == 0) {
+    wave_sum[wave] = c;
+    wave_before[wave] = before;
+  }
+  __syncthreads();
+  unsigned running = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    running += wave_before[w];
+    if (w < wave) running += wave_sum[w];
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = wave_base + r * 64 + lane;
+    const unsigned u = running + CountBelow(heads[r]) + static_cast<unsigned>((heads[r] >> lane) & 1ull);
+    if (i < n) remapped[i] = static_cast<IndexT>(u);
+    running += static_cast<unsigned>(__popcll(heads[r]));
+  }
+}
+
 inline size_t RunHeadScanWorkBytes(const size_t n) {
   const size_t tiles = (n + kSortTile - 1) / kSortTile;
   return SortAlign((tiles ? tiles : 1) * sizeof(unsigned));
@@ -1020,10 +1221,16 @@ inline void RunHeadScanLaunch(const IndexT* indices, const size_t n, IndexT* rem
                               IndexT* fence_keys, hipStream_t stream) {
   if (n == 0) return;
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
-  if (tiles == 1) {  // one launch instead of two
-    RunHeadScanKernel<IndexT, kOut><<<1, kSortThreads, 0, stream>>>(
+  if (tiles == 1 || (tiles <= kSelfCountTiles && block_tiles == 0)) {  // one launch instead of two
+    RunHeadScanKernel<IndexT, kOut><<<tiles, kSortThreads, 0, stream>>>(
         indices, static_cast<int64_t>(n), nullptr, false, remapped, block_tiles, unique_keys, block_start, fence_keys);
     return;
+  }
+  if constexpr (kOut == RunHeadOutput::kIds) {
+    if (tiles <= kWideSelfCountTiles && block_tiles == 0) {   // still one launch, on four times the lanes
+      RunHeadScanWideKernel<IndexT><<<tiles, kWideScanThreads, 0, stream>>>(indices, static_cast<int64_t>(n), remapped);
+      return;
+    }
   }
   // every workgroup of the scan adds up the counts of the earlier tiles itself: tiles^2 / 2 words
   // in total -- 2 MB at 1024 tiles, but 5e11 bytes at the API's limit of 2^31 lookups; beyond

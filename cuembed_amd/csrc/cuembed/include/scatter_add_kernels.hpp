@@ -22,6 +22,7 @@
 #define CUEMBED_INCLUDE_SCATTER_ADD_KERNELS_HPP_
 
 #include "cuembed/include/blocked_order.hpp"
+#include "cuembed/include/device_shape.hpp"
 #include "cuembed/include/embedding_types.hpp"
 #include "cuembed/include/gather_reduce_kernels.hpp"
 
@@ -167,7 +168,9 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
                           const int xcds,           // XCDs of the device (workgroup b runs on XCD b % xcds)
                           const IndexT* __restrict__ run_ids,        // compressed gradient: table row ids ...
                           IndexT* __restrict__ inverse_mapping,      // ... and where the id of every run goes
-                          const uint32_t* __restrict__ block_row_ids) {  // sample-blocked order: pair number -> row | bit
+                          const uint32_t* __restrict__ block_row_ids,   // sample-blocked order: pair number -> row | bit
+                          const int64_t capacity_rows,               // > 0: rows that grad_out / inverse_mapping hold
+                          uint32_t* __restrict__ capacity_overflow) {  // ... and the word that says "not enough"
   // (a template parameter, not a run-time flag: the registers of the read-modify-write would cost the
   // reference-order kernel a wavefront per SIMD)
   constexpr uint32_t shared_row_bit = kBlocked ? kSharedRowBit : 0u;
@@ -181,6 +184,19 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
   const ColumnSlice cs = ColumnSlice::Of(blockIdx.x, column_slices, xcds);
   const int64_t block_begin = cs.block * block_len;
   if (block_begin >= nnz) return;  // the grid is rounded up to whole rounds of `xcds` workgroups
+  if (capacity_rows > 0) {
+    // Compressed gradient whose row count only the device knows (num_grad_embedding_rows < 0): the ids ascend through
+    // the sorted COO of this launch, so its LAST lookup holds the largest gradient row.  If the caller's buffers are
+    // too small for it, nothing of this launch is written -- every workgroup takes the same decision from the same
+    // word -- and the caller's overflow word is raised instead of an overrun.
+    uint32_t last = static_cast<uint32_t>(rows[nnz - 1]);
+    if (block_row_ids != nullptr) last = block_row_ids[last] & ~kSharedRowBit;
+    if (static_cast<int64_t>(last) >= capacity_rows) {
+      if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0 && capacity_overflow != nullptr)
+        atomicOr(capacity_overflow, 1u);
+      return;
+    }
+  }
   const int64_t column0 = (static_cast<int64_t>(cs.slice) * lanes + lane_x) * N;
   const uint32_t id_mask = ~shared_row_bit;   // staged ids keep the bit (equal inside a run); addresses drop it
 
@@ -530,8 +546,8 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 //! lookup of every workgroup -- the only ones that can receive atomics -- and (b) rows beyond
 //! the last id, should the caller have over-allocated, must be zero beforehand.  That is a few
 //! MB instead of a memset of the whole buffer (293 MB, ~45 us, at the north-star shape).
-//!   grid = sample_blocks * blocks_per_sample_block + tail workgroups (ZeroTailBlocks: at most kZeroTailMaxBlocks,
-//!   each striding over kZeroTailRowsPerBlock-row pieces of the tail), block = 256
+//!   grid = sample_blocks * blocks_per_sample_block + tail workgroups (ZeroTailBlocks: at most kZeroTailBlocksPerCu per
+//!   compute unit, all striding over the tail with 16-byte stores), block = 256
 //! Sample-blocked order (sample_blocks > 1): the COO is `sample_blocks` arrays of `sample_block_len` lookups that
 //! are scattered one after the other, each cut into workgroup ranges from its own start; ONE call zeroes the edge
 //! rows of all of them up front (a row that block 0 stores and block 1 adds to must not be zeroed in between), and
@@ -540,12 +556,15 @@ SegmentedScatterAddKernel(const GradT* __restrict__ grad_y,
 constexpr int kZeroTailRowsPerBlock = 64;
 //! The tail (rows past the last id) is usually EMPTY -- the caller read num_unique back and allocated exactly -- but
 //! only the device knows: a bounded number of workgroups stride over it instead of one workgroup per 64 rows of the
-//! whole buffer (8,938 workgroups that found nothing to do cost 5 us of the 8 us this kernel took at C4).
-constexpr int kZeroTailMaxBlocks = 128;
-inline int64_t ZeroTailBlocks(const int64_t zero_rows) {
+//! whole buffer (8,938 workgroups that found nothing to do cost 5 us of the 8 us this kernel took at C4).  The bound
+//! follows the device (4 workgroups per compute unit: a caller that over-allocates by gigabytes -- min(nnz, table
+//! rows) rows with few distinct ones -- gets the whole chip storing 16 bytes per lane, not 128 workgroups of scalars).
+constexpr int kZeroTailBlocksPerCu = 4;
+inline int64_t ZeroTailBlocks(const int64_t zero_rows, const DeviceShape& dev) {
   if (zero_rows <= 0) return 0;
   const int64_t pieces = (zero_rows + kZeroTailRowsPerBlock - 1) / kZeroTailRowsPerBlock;
-  return pieces < kZeroTailMaxBlocks ? pieces : kZeroTailMaxBlocks;
+  const int64_t cap = static_cast<int64_t>(kZeroTailBlocksPerCu) * dev.compute_units;
+  return pieces < cap ? pieces : cap;
 }
 
 template <typename GradT, typename IndexT>
@@ -553,7 +572,8 @@ __global__ void __launch_bounds__(256)
 ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, const int block_len,
                             const int64_t blocks_per_sample_block, const int64_t sample_block_len,
                             const int sample_blocks, const int width, const int64_t num_rows,
-                            GradT* __restrict__ grad_out, const uint32_t* __restrict__ block_row_ids) {
+                            GradT* __restrict__ grad_out, const uint32_t* __restrict__ block_row_ids,
+                            const int64_t capacity_rows) {
   // sample-blocked order: `rows` holds pair numbers, block_row_ids[pair] the gradient row | kSharedRowBit
   auto row_of = [&](const int64_t g) -> int64_t {
     const uint32_t r = static_cast<uint32_t>(rows[g]);
@@ -570,6 +590,9 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
     const int64_t last = (first + block_len < end ? first + block_len : end) - 1;
     const int64_t r0 = row_of(first);
     const int64_t r1 = row_of(last);
+    // (capacity_rows > 0: a launch whose last id does not fit the buffer writes nothing at all -- the scatter takes the
+    // same decision from the same word and raises the caller's flag)
+    if (capacity_rows > 0 && row_of(end - 1) >= capacity_rows) return;
     for (int c = threadIdx.x; c < width; c += blockDim.x) {
       grad_out[r0 * width + c] = static_cast<GradT>(0);
       grad_out[r1 * width + c] = static_cast<GradT>(0);
@@ -582,12 +605,23 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
     const int64_t id = row_of(end - 1);
     last_id = id > last_id ? id : last_id;
   }
+  // the tail is ONE contiguous range of bytes: 16-byte stores between its aligned ends, all tail workgroups striding
+  // over it; the (at most 15-byte) ragged ends go out element by element from one thread
+  char* const p0 = reinterpret_cast<char*>(grad_out + (last_id + 1) * width);
+  char* const p1 = reinterpret_cast<char*>(grad_out + num_rows * width);
+  if (p0 >= p1) return;
+  char* a0 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p0) + 15) & ~uintptr_t{15});
+  char* a1 = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(p1) & ~uintptr_t{15});
+  if (a0 > p1) a0 = p1;
+  if (a1 < a0) a1 = a0;
   const int64_t tail_blocks = static_cast<int64_t>(gridDim.x) - num_blocks;
-  for (int64_t begin = last_id + 1 + (b - num_blocks) * kZeroTailRowsPerBlock; begin < num_rows;
-       begin += tail_blocks * kZeroTailRowsPerBlock) {
-    const int64_t end = begin + kZeroTailRowsPerBlock < num_rows ? begin + kZeroTailRowsPerBlock : num_rows;
-    for (int64_t i = begin * width + threadIdx.x; i < end * width; i += blockDim.x)
-      grad_out[i] = static_cast<GradT>(0);
+  const int64_t worker = (b - num_blocks) * blockDim.x + threadIdx.x;
+  const int64_t step = tail_blocks * blockDim.x * 16;
+  typedef unsigned __attribute__((ext_vector_type(4))) word4_t;
+  for (char* p = a0 + worker * 16; p < a1; p += step) *reinterpret_cast<word4_t*>(p) = word4_t{0u, 0u, 0u, 0u};
+  if (worker == 0) {
+    for (char* p = p0; p < a0; p += sizeof(GradT)) *reinterpret_cast<GradT*>(p) = static_cast<GradT>(0);
+    for (char* p = a1; p < p1; p += sizeof(GradT)) *reinterpret_cast<GradT*>(p) = static_cast<GradT>(0);
   }
 }
 

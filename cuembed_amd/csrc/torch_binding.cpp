@@ -18,6 +18,7 @@
 #include <ATen/ATen.h>
 #include <ATen/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
 #include <string>
@@ -77,9 +78,11 @@ int IndexBits(const int64_t num_categories) {
 // ---- the reference's four ops --------------------------------------------------------------
 
 // reference: cuembed_embedding.cu:10-52 (CSR layout, offsets has batch + 1 entries)
-at::Tensor cuembed_embedding_forward_op(const at::Tensor& params, const at::Tensor& indices,
-                                     const at::Tensor& offsets, const at::Tensor& weights,
-                                     const std::string& mode) {
+// `row_loads` -1 = the process-wide default, 0 / 1 = RowLoadPolicy; `sample_order` = ForwardOptions::sample_order
+// (a permutation of the samples; undefined = none): scheduling hints, never a different result.
+at::Tensor ForwardImpl(const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
+                       const at::Tensor& weights, const std::string& mode, const int row_loads,
+                       const at::Tensor& sample_order) {
   CheckGpu(params, "params");
   CheckGpu(indices, "indices");
   CheckGpu(offsets, "offsets");
@@ -99,10 +102,50 @@ at::Tensor cuembed_embedding_forward_op(const at::Tensor& params, const at::Tens
   const int64_t batch = o.numel() - 1;
   TORCH_CHECK(batch >= 0, "cuembed_pyt: offsets must hold batch_size + 1 entries");
   at::Tensor out = at::empty({batch, p.size(1)}, p.options());
+  if (sample_order.defined())
+    TORCH_CHECK(sample_order.is_cuda() && sample_order.scalar_type() == at::kInt && sample_order.numel() == batch &&
+                    sample_order.is_contiguous(),
+                "cuembed_pyt: sample_order must be a contiguous int32 permutation of the samples on the GPU");
   if (batch > 0)
-    ::cuembed_embedding_forward(Ptr(p), elem, static_cast<int>(p.size(1)), Ptr(i), idx, Ptr(o), off, Ptr(w),
-                                static_cast<int>(batch), 0, m, 0, MutPtr(out), CurrentStream(p));
+    ::cuembed_embedding_forward_ordered(Ptr(p), elem, static_cast<int>(p.size(1)), Ptr(i), idx, Ptr(o), off, Ptr(w),
+                                        static_cast<int>(batch), 0, m, 0, MutPtr(out), /*reduction_order=*/-1, row_loads,
+                                        static_cast<const int32_t*>(Ptr(sample_order)), CurrentStream(p));
   return out;
+}
+
+at::Tensor cuembed_embedding_forward_op(const at::Tensor& params, const at::Tensor& indices,
+                                     const at::Tensor& offsets, const at::Tensor& weights,
+                                     const std::string& mode) {
+  return ForwardImpl(params, indices, offsets, weights, mode, -1, at::Tensor());
+}
+
+// Extension: ... with the per-call scheduling hints of cuembed::ForwardOptions.
+at::Tensor cuembed_embedding_forward_hinted_op(const at::Tensor& params, const at::Tensor& indices,
+                                            const at::Tensor& offsets, const c10::optional<at::Tensor>& weights,
+                                            const std::string& mode, const int64_t row_loads,
+                                            const c10::optional<at::Tensor>& sample_order) {
+  return ForwardImpl(params, indices, offsets, weights.has_value() ? *weights : at::Tensor(), mode,
+                     static_cast<int>(row_loads), sample_order.has_value() ? *sample_order : at::Tensor());
+}
+
+// Extension (cuembed::BagOrderByLength): the samples of a CSR batch by descending bag length, for sample_order.
+at::Tensor cuembed_bag_order_by_length_op(const at::Tensor& offsets, const int64_t max_length) {
+  CheckGpu(offsets, "offsets");
+  const int off = IndexCode(offsets, "offsets");
+  const at::DeviceGuard guard(offsets.device());
+  const at::Tensor o = offsets.contiguous();
+  const int64_t batch = o.numel() - 1;
+  TORCH_CHECK(batch >= 0, "cuembed_pyt: offsets must hold batch_size + 1 entries");
+  at::Tensor order = at::empty({batch}, o.options().dtype(at::kInt));
+  if (batch == 0) return order;
+  size_t lwork = 0;
+  ::cuembed_bag_order_by_length(nullptr, off, static_cast<int>(batch), static_cast<int>(max_length), nullptr, nullptr,
+                                &lwork, nullptr);
+  at::Tensor work = at::empty({static_cast<int64_t>(lwork > 0 ? lwork : 1)}, o.options().dtype(at::kByte));
+  ::cuembed_bag_order_by_length(Ptr(o), off, static_cast<int>(batch), static_cast<int>(max_length),
+                                static_cast<int32_t*>(order.data_ptr()), static_cast<char*>(work.data_ptr()), &lwork,
+                                CurrentStream(o));
+  return order;
 }
 
 // reference: cuembed_embedding.cu:54-68.  The reference's Python passes offsets[:-1] and the
@@ -364,6 +407,162 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> cuembed_transpose_fix
   return {t_idx, t_sid, t_w, remap};
 }
 
+
+// ---- the whole training step of cuemb_embedding as ONE autograd node -------------------------------------------
+// examples/pytorch/cuembed_pyt.py:12-51 runs forward and backward as a Python autograd.Function over four ops; at small
+// batches that is host-bound (B = 1024, H = 64: 0.236 ms per step for ~0.09 ms of kernels, most of it the Python
+// dispatch of six ops and a read-back of num_unique in the MIDDLE of the backward).  Here forward and backward are one
+// C++ node each: the backward enqueues row ids -> transpose (+ remap in the same call) -> scatter-add without returning
+// to Python, and for a sparse gradient the row count is read back AFTER everything is enqueued (the scatter runs into
+// buffers of capacity min(nnz, rows) under cuembed_embedding_backward_bounded and the result is narrowed to
+// num_unique rows), so the host waits for the device once, at the end, instead of stalling the pipeline in the middle.
+// Above kCapacityBytes of worst-case gradient the count is read back first, as before (2.1 GB at the C4 shape).
+constexpr int64_t kCapacityBytes = int64_t{192} << 20;
+
+enum GradKind : int64_t { kGradDense = 0, kGradSparseAuto = 1, kGradSparseReference = 2, kGradSparseUncoalesced = 3 };
+
+struct NarrowedIndices {
+  at::Tensor idx, offsets;
+};
+// int64 indices of a table with < 2^31 rows: the index work of the backward runs on int32 copies (half the bytes through
+// every sorting pass) -- from 2^18 lookups up, where the two conversions cost less than they save (cuembed_pyt.py).
+NarrowedIndices NarrowForIndexWork(const at::Tensor& idx, const at::Tensor& offsets, const int64_t num_categories) {
+  if (idx.scalar_type() == at::kLong && num_categories < (int64_t{1} << 31) && idx.numel() >= (int64_t{1} << 18) &&
+      idx.numel() < (int64_t{1} << 31))
+    return {idx.to(at::kInt), offsets.to(at::kInt)};
+  return {idx, offsets};
+}
+
+struct TransposedLookups {
+  at::Tensor t_idx, t_sid, t_w, remap;
+};
+// Transpose (+ ComputeCompressedGradIndices from the same call) of (sample_ids, indices[, weights]).
+TransposedLookups TransposeWithRemap(const at::Tensor& sample_ids, const at::Tensor& indices, const at::Tensor& weights,
+                                     const int64_t num_categories, const int sample_blocks, const bool want_remap) {
+  const int idx = IndexCode(indices, "indices");
+  const int wt = weights.defined() ? ElemCode(weights, "weights") : CUEMBED_F32;
+  const int nnz = static_cast<int>(indices.numel());
+  TransposedLookups t;
+  t.t_idx = at::empty_like(indices);
+  t.t_sid = at::empty_like(sample_ids);
+  if (weights.defined()) t.t_w = at::empty_like(weights);
+  if (want_remap) t.remap = at::empty_like(indices);
+  size_t lwork = 0;
+  const void* query_weights = weights.defined() ? reinterpret_cast<const void*>(256) : nullptr;
+  const int bits = IndexBits(num_categories);
+  ::cuembed_transpose_remapped(nullptr, nullptr, query_weights, nnz, idx, wt, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               &lwork, bits, 31, sample_blocks, nullptr);
+  at::Tensor work = at::empty({static_cast<int64_t>(lwork > 0 ? lwork : 1)}, indices.options().dtype(at::kByte));
+  ::cuembed_transpose_remapped(Ptr(sample_ids), Ptr(indices), Ptr(weights), nnz, idx, wt, MutPtr(t.t_idx), MutPtr(t.t_sid),
+                               weights.defined() ? MutPtr(t.t_w) : nullptr, want_remap ? MutPtr(t.remap) : nullptr,
+                               static_cast<char*>(work.data_ptr()), &lwork, bits, 31, sample_blocks, CurrentStream(indices));
+  return t;
+}
+
+class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> {
+ public:
+  // (optional tensors travel as std::optional: autograd's argument scan cannot take an undefined at::Tensor)
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& params, const at::Tensor& indices,
+                            const at::Tensor& offsets, const c10::optional<at::Tensor>& optional_weights,
+                            const int64_t grad_kind, const int64_t row_loads,
+                            const c10::optional<at::Tensor>& optional_sample_order) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    const at::Tensor weights = optional_weights.has_value() ? *optional_weights : at::Tensor();
+    const at::Tensor sample_order = optional_sample_order.has_value() ? *optional_sample_order : at::Tensor();
+    ctx->saved_data["num_categories"] = params.size(0);
+    ctx->saved_data["grad_kind"] = grad_kind;
+    ctx->saved_data["weighted"] = weights.defined();
+    if (weights.defined()) ctx->save_for_backward({indices, offsets, weights});
+    else ctx->save_for_backward({indices, offsets});
+    return ForwardImpl(params, indices, offsets, weights, "sum", static_cast<int>(row_loads), sample_order);
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::variable_list grad_outputs) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    const auto saved = ctx->get_saved_variables();
+    const bool weighted = ctx->saved_data["weighted"].toBool();
+    const int64_t num_categories = ctx->saved_data["num_categories"].toInt();
+    const int64_t grad_kind = ctx->saved_data["grad_kind"].toInt();
+    at::Tensor out_grad = grad_outputs[0];
+    torch::autograd::variable_list grads(7);   // (params, indices, offsets, weights, grad_kind, row_loads, sample_order)
+    if (!ctx->needs_input_grad(0)) return grads;
+    CheckGpu(out_grad, "the incoming gradient");
+    const at::DeviceGuard guard(out_grad.device());
+    out_grad = out_grad.contiguous();
+    const int64_t width = out_grad.size(1);
+    const int64_t nnz = saved[0].numel();
+    const at::Tensor weights = weighted ? saved[2].contiguous() : at::Tensor();
+    if (nnz == 0) {
+      if (grad_kind == kGradDense) {
+        grads[0] = at::zeros({num_categories, width}, out_grad.options());
+      } else {
+        grads[0] = at::_sparse_coo_tensor_unsafe(at::empty({1, 0}, out_grad.options().dtype(at::kLong)),
+                                                 at::empty({0, width}, out_grad.options()), {num_categories, width},
+                                                 out_grad.options().layout(at::kSparse));
+      }
+      return grads;
+    }
+    const NarrowedIndices nw = NarrowForIndexWork(saved[0].contiguous(), saved[1].contiguous(), num_categories);
+    const at::Tensor sample_ids = cuembed_extract_row_ids_from_offsets_op(nw.offsets, nnz);
+    const int elem = ElemCode(out_grad, "the incoming gradient");
+    const int idx = IndexCode(nw.idx, "indices");
+    const cuembed_stream_t stream = CurrentStream(out_grad);
+    if (grad_kind == kGradDense) {   // the reference's gradient: a zero-filled table-sized tensor (cuembed_embedding.cu:122-167)
+      const TransposedLookups t = TransposeWithRemap(sample_ids, nw.idx, weights, num_categories, 1, false);
+      grads[0] = cuembed_embedding_backward_op(out_grad, num_categories, t.t_idx, t.t_sid, t.t_w);
+      return grads;
+    }
+    // ---- compressed gradient as a sparse COO tensor ----
+    int blocks = 1;
+    if (grad_kind != kGradSparseReference)   // while a block of samples is scattered every L2 gathers from 1 / blocks of out_grad
+      blocks = ::cuembed_recommended_sample_blocks(elem, static_cast<int>(width), static_cast<int>(out_grad.size(0)), nnz);
+    const TransposedLookups t = TransposeWithRemap(sample_ids, nw.idx, weights, num_categories, blocks, true);
+    const bool one_block = ::cuembed_transpose_sample_block_length(nnz, blocks) >= nnz;
+    const int64_t row_bound = one_block ? num_categories : static_cast<int64_t>(blocks) * num_categories;
+    const int64_t capacity = nnz < row_bound ? nnz : row_bound;
+    const int64_t row_bytes = width * static_cast<int64_t>(out_grad.element_size());
+    at::Tensor rows, inv;
+    int64_t num_unique = -1;
+    if (capacity * row_bytes <= kCapacityBytes) {
+      // everything is enqueued before the host looks at the device: rows for the worst case, narrowed afterwards
+      rows = at::empty({capacity, width}, out_grad.options());
+      inv = at::empty({capacity}, nw.idx.options());
+      ::cuembed_embedding_backward_bounded(Ptr(out_grad), elem, static_cast<int>(width), -1, static_cast<int>(nnz),
+                                           Ptr(t.t_idx), Ptr(t.t_sid), Ptr(t.remap), idx, Ptr(t.t_w), /*skip_grad_init=*/0,
+                                           MutPtr(rows), MutPtr(inv), 1, nullptr, static_cast<int>(capacity), nullptr, stream);
+      at::Tensor inv64 = inv.scalar_type() == at::kLong ? inv : inv.to(at::kLong);
+      num_unique = t.remap.narrow(0, nnz - 1, 1).item().toLong() + 1;   // (the one wait of the step)
+      rows = rows.narrow(0, 0, num_unique);
+      inv = inv64.narrow(0, 0, num_unique);
+    } else {
+      num_unique = t.remap.narrow(0, nnz - 1, 1).item().toLong() + 1;
+      rows = at::empty({num_unique, width}, out_grad.options());
+      inv = at::empty({num_unique}, nw.idx.options());
+      ::cuembed_embedding_backward(Ptr(out_grad), elem, static_cast<int>(width), static_cast<int>(num_unique),
+                                   static_cast<int>(nnz), Ptr(t.t_idx), Ptr(t.t_sid), Ptr(t.remap), idx, Ptr(t.t_w),
+                                   /*skip_grad_init=*/0, MutPtr(rows), MutPtr(inv), stream);
+      if (inv.scalar_type() != at::kLong) inv = inv.to(at::kLong);
+    }
+    grads[0] = at::_sparse_coo_tensor_unsafe(inv.unsqueeze(0), rows, {num_categories, width},
+                                             out_grad.options().layout(at::kSparse), /*is_coalesced=*/one_block);
+    return grads;
+  }
+};
+
+// grad_kind: 0 dense (the reference), 1 sparse / fastest order, 2 sparse / the reference's order (coalesced),
+// 3 sparse / sample-blocked order (uncoalesced when the shape asks for blocks; = 1 today, kept apart for callers that
+// want to pin the behaviour).
+at::Tensor cuemb_embedding_autograd_op(const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
+                                    const at::Tensor& weights, const int64_t grad_kind, const int64_t row_loads,
+                                    const at::Tensor& sample_order) {
+  TORCH_CHECK(grad_kind >= kGradDense && grad_kind <= kGradSparseUncoalesced, "cuembed_pyt: unknown grad_kind");
+  return CuEmbEmbeddingNode::apply(params, indices, offsets,
+                                   weights.defined() ? c10::optional<at::Tensor>(weights) : c10::nullopt, grad_kind,
+                                   row_loads,
+                                   sample_order.defined() ? c10::optional<at::Tensor>(sample_order) : c10::nullopt);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(cuembed_pyt, m) {
@@ -392,6 +591,23 @@ TORCH_LIBRARY(cuembed_pyt, m) {
       "transpose_sample_ids, Tensor transpose_remapped_indices, Tensor transpose_weights) -> (Tensor, Tensor)");
   m.def("cuembed_embedding_forward_fixed(Tensor params, Tensor indices, Tensor weights, str mode) -> Tensor");
   m.def("cuembed_embedding_weight_grad(Tensor params, Tensor indices, Tensor offsets, Tensor y_grad) -> Tensor");
+  // forward + backward of cuemb_embedding as one native autograd node (see CuEmbEmbeddingNode)
+  m.def(
+      "cuemb_embedding_step(Tensor params, Tensor indices, Tensor offsets, Tensor? weights, int grad_kind, int row_loads, "
+      "Tensor? sample_order) -> Tensor");
+  m.def(
+      "cuembed_embedding_forward_hinted(Tensor params, Tensor indices, Tensor offsets, Tensor? weights, str mode, int "
+      "row_loads, Tensor? sample_order) -> Tensor");
+  m.def("cuembed_bag_order_by_length(Tensor offsets, int max_length) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(cuembed_pyt, Autograd, m) {
+  m.impl("cuemb_embedding_step", [](const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
+                                    const c10::optional<at::Tensor>& weights, int64_t grad_kind, int64_t row_loads,
+                                    const c10::optional<at::Tensor>& sample_order) {
+    return cuemb_embedding_autograd_op(params, indices, offsets, weights.has_value() ? *weights : at::Tensor(), grad_kind,
+                                       row_loads, sample_order.has_value() ? *sample_order : at::Tensor());
+  });
 }
 
 TORCH_LIBRARY_IMPL(cuembed_pyt, CUDA, m) {  // HIP tensors use the CUDA dispatch key on PyTorch-ROCm
@@ -408,4 +624,6 @@ TORCH_LIBRARY_IMPL(cuembed_pyt, CUDA, m) {  // HIP tensors use the CUDA dispatch
   m.impl("cuembed_embedding_backward_compressed", cuembed_embedding_backward_compressed_op);
   m.impl("cuembed_embedding_forward_fixed", cuembed_embedding_forward_fixed_op);
   m.impl("cuembed_embedding_weight_grad", cuembed_embedding_weight_grad_op);
+  m.impl("cuembed_embedding_forward_hinted", cuembed_embedding_forward_hinted_op);
+  m.impl("cuembed_bag_order_by_length", cuembed_bag_order_by_length_op);
 }

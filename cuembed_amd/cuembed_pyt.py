@@ -23,6 +23,7 @@ import os
 import torch
 
 from . import ops as _ops
+from . import policy as _policy
 
 BACKEND = os.environ.get("CUEMBED_PYT_BACKEND", "native")
 NATIVE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcuembed_pyt.so")
@@ -64,6 +65,11 @@ def _define_python_ops():
                 " str mode) -> Tensor")
     _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
                 " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
+    _lib.define("cuembed_embedding_forward_hinted(Tensor params, Tensor indices, Tensor offsets, Tensor? weights,"
+                " str mode, int row_loads, Tensor? sample_order) -> Tensor")
+    _lib.define("cuembed_bag_order_by_length(Tensor offsets, int max_length) -> Tensor")
+    _lib.impl("cuembed_embedding_forward_hinted", _forward_hinted_impl, "CUDA")
+    _lib.impl("cuembed_bag_order_by_length", _bag_order_impl, "CUDA")
     _lib.impl("cuembed_extract_row_ids_from_offsets", _extract_closed_impl, "CUDA")
     _lib.impl("cuembed_transpose_sample_ids", _transpose_sample_ids_impl, "CUDA")
     _lib.impl("cuembed_transpose_sample_blocks", _transpose_sample_blocks_impl, "CUDA")
@@ -103,7 +109,15 @@ def _require(cond, msg):
         raise RuntimeError("cuembed_pyt: " + msg)
 
 
-def _forward_impl(params, indices, offsets, weights, mode):
+def _forward_hinted_impl(params, indices, offsets, weights, mode, row_loads, sample_order):
+    return _forward_impl(params, indices, offsets, weights, mode, row_loads, sample_order)
+
+
+def _bag_order_impl(offsets, max_length):
+    return _ops.bag_order_by_length(offsets.contiguous(), max_length=int(max_length))
+
+
+def _forward_impl(params, indices, offsets, weights, mode, row_loads=-1, sample_order=None):
     _require(params.is_cuda and indices.is_cuda and offsets.is_cuda, "tensors must be on the GPU")
     _require(params.dtype in _FLOATS, "params must be float32 or float16")
     _require(indices.dtype in _INTS and offsets.dtype in _INTS, "indices/offsets must be int64 or int32")
@@ -113,7 +127,9 @@ def _forward_impl(params, indices, offsets, weights, mode):
         weights = weights.contiguous()
     batch_size = offsets.numel() - 1
     return _ops.embedding_forward(params.contiguous(), indices.contiguous(), offsets.contiguous(), weights,
-                                  batch_size=batch_size, num_hots=0, mode=mode)
+                                  batch_size=batch_size, num_hots=0, mode=mode,
+                                  row_loads={-1: None, 0: "default", 1: "streaming"}[int(row_loads)],
+                                  sample_order=sample_order)
 
 
 def _extract_impl(offsets, nnz):
@@ -241,8 +257,15 @@ cuembed_embedding_forward = torch.ops.cuembed_pyt.cuembed_embedding_forward
 cuembed_embedding_backward = torch.ops.cuembed_pyt.cuembed_embedding_backward
 
 
-def cuembed_forward(params, idx, offsets, weights):
-    return cuembed_embedding_forward(params, idx, offsets, weights, mode="sum")
+def cuembed_forward(params, idx, offsets, weights, hints=None):
+    if hints is None:
+        return cuembed_embedding_forward(params, idx, offsets, weights, mode="sum")
+    return torch.ops.cuembed_pyt.cuembed_embedding_forward_hinted(params, idx, offsets, weights, "sum", hints[0], hints[1])
+
+
+def _auto_hints(params, idx, offsets):
+    """(row_loads, sample_order) chosen by cuembed_amd.policy for this table and this batch; never changes a result."""
+    return _policy.row_loads(params, idx), _policy.sample_order(offsets, idx.numel())
 
 
 def _narrow_for_index_work(idx, offsets, num_categories):
@@ -285,10 +308,14 @@ def _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz):
                                         size=(ctx.num_categories, width)), None, None, None)
     sample_ids = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_offsets(offsets, nnz)
     blocks = 1
-    if ctx.sparse_grad in ("blocked", "uncoalesced"):
+    if ctx.sparse_grad != "reference":
         # while a block of samples is scattered every L2 gathers from 1 / blocks of out_grad only
         blocks = _ops.recommended_sample_blocks(out_grad.dtype, width, out_grad.size(0), nnz)
-    if blocks > 1 and ctx.sparse_grad == "blocked" and blocks <= _ops.MAX_COALESCED_BLOCKS:
+        if ctx.sparse_grad == "blocked":
+            # "blocked" promises the COALESCED tensor: never fall through to the uncoalesced path because the
+            # recommendation (up to 64 blocks for very wide rows) exceeds what the coalescing remap handles
+            blocks = min(blocks, _ops.MAX_COALESCED_BLOCKS)
+    if blocks > 1 and ctx.sparse_grad == "blocked":
         # the COALESCED gradient from the blocked order: the same rows and ids as the fully sorted order gives
         # (ComputeCompressedGradIndicesBlocked + EmbeddingBackward(sample_blocks); EmbeddingBackward at C4 0.257 -> 0.232 ms)
         t_idx, t_sid, t_w = torch.ops.cuembed_pyt.cuembed_transpose_sample_blocks(sample_ids, idx, weights,
@@ -321,13 +348,13 @@ def _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz):
 
 class _CuEmbEmbedding(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, params, idx, offsets, weights=None, sparse_grad=False):
+    def forward(ctx, params, idx, offsets, weights=None, sparse_grad=False, hints=None):
         ctx.save_for_backward(idx, offsets, weights)
         ctx.num_categories = params.size(0)
         ctx.sparse_grad = sparse_grad
         # the weight gradient (an extension; the reference returns None) needs the table rows
         ctx.params_for_weight_grad = params.detach() if (weights is not None and weights.requires_grad) else None
-        return cuembed_forward(params, idx, offsets, weights)
+        return cuembed_forward(params, idx, offsets, weights, hints)
 
     @staticmethod
     def backward(ctx, out_grad):
@@ -339,22 +366,46 @@ class _CuEmbEmbedding(torch.autograd.Function):
             idx, offsets, _ = ctx.saved_tensors
             grads[3] = torch.ops.cuembed_pyt.cuembed_embedding_weight_grad(
                 ctx.params_for_weight_grad, idx, offsets, out_grad.to(ctx.params_for_weight_grad.dtype))
-        return tuple(grads) + (None,)
+        return tuple(grads) + (None, None)
 
 
-def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False):
-    """Sum-pooled embedding bag (offsets include the last offset).  Differentiable w.r.t. params
-    and -- an extension over the reference -- w.r.t. the per-lookup weights.
-    sparse_grad=True (extension) makes params.grad a coalesced sparse COO tensor holding only the rows that
-    were looked up.  sparse_grad="blocked": the same tensor (same rows, same ids) computed from a sample-blocked
-    order -- a faster EmbeddingBackward (C4: 0.257 -> 0.232 ms) for more index work; through this op surface the
-    two cancel (0.574 vs 0.597 ms per fwd + bwd at C4), so it is not the default.  sparse_grad="uncoalesced"
-    allows a row to appear once per block of samples: the same gradient once scattered, the fastest backward
-    (0.491 ms)."""
+_GRAD_KINDS = {False: 0, True: 1, "reference": 2, "uncoalesced": 3}
+
+
+def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False, hints="auto"):
+    """Sum-pooled embedding bag (offsets include the last offset), the reference's entry point
+    (examples/pytorch/cuembed_pyt.py:48-51).  Differentiable w.r.t. params and -- an extension over the reference --
+    w.r.t. the per-lookup weights.
+
+    sparse_grad (extension; False = the reference's dense, table-sized gradient):
+      True           params.grad is a sparse COO tensor holding only the rows that were looked up, computed the fastest
+                     way for the shape: where the backward gains from scattering the batch in blocks of samples (C4) a
+                     row may appear once per block (is_coalesced=False: the same gradient once scattered or coalesced;
+                     what torch.sparse consumers -- SGD, SparseAdam, .coalesce(), .to_dense() -- take as it is);
+      "reference"    the reference's fully sorted order: always coalesced, ascending rows;
+      "blocked"      the same coalesced tensor computed from the sample-blocked order (a faster EmbeddingBackward for
+                     more index work; through this op surface the two cancel at C4);
+      "uncoalesced"  today's behaviour of True, pinned.
+    hints="auto" lets cuembed_amd.policy pick the forward's scheduling options for this table and batch (non-temporal
+    row loads, bag order); None = the library defaults.  Results never depend on hints.
+
+    Outside torch.compile the step runs as ONE native autograd node (forward, and row ids -> transpose + remap ->
+    scatter-add in the backward, one dispatcher hop each; libcuembed_pyt.so: CuEmbEmbeddingNode); under torch.compile,
+    for the weight gradient and for "blocked" it runs as a Python autograd.Function over the same ops."""
     needs_grad = params.requires_grad or (weights is not None and weights.requires_grad)
+    quiet = torch.compiler.is_compiling()
+    chosen = _auto_hints(params, idx, offsets) if (hints == "auto" and not quiet) else None
+    if chosen is not None and chosen[0] < 0 and chosen[1] is None:
+        chosen = None
     if not torch.is_grad_enabled() or not needs_grad:
-        return cuembed_forward(params, idx, offsets, weights)
-    return _CuEmbEmbedding.apply(params, idx, offsets, weights, sparse_grad)
+        return cuembed_forward(params, idx, offsets, weights, chosen)
+    native = (BACKEND == "native" and not quiet and sparse_grad in _GRAD_KINDS and
+              not (weights is not None and weights.requires_grad))
+    if native:
+        row_loads, order = chosen if chosen is not None else (-1, None)
+        return torch.ops.cuembed_pyt.cuemb_embedding_step(params, idx, offsets, weights, _GRAD_KINDS[sparse_grad],
+                                                          row_loads, order)
+    return _CuEmbEmbedding.apply(params, idx, offsets, weights, sparse_grad, chosen)
 
 
 class _CuEmbFixed(torch.autograd.Function):
@@ -471,6 +522,16 @@ def _(y_grad, num_unique, transpose_indices, transpose_sample_ids, transpose_rem
 @torch.library.register_fake("cuembed_pyt::cuembed_embedding_forward")
 def _(params, idx, offsets, weights=None, mode="sum"):
     return torch.empty((offsets.shape[0] - 1, params.shape[1]), device=params.device, dtype=params.dtype)
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_embedding_forward_hinted")
+def _(params, idx, offsets, weights=None, mode="sum", row_loads=-1, sample_order=None):
+    return torch.empty((offsets.shape[0] - 1, params.shape[1]), device=params.device, dtype=params.dtype)
+
+
+@torch.library.register_fake("cuembed_pyt::cuembed_bag_order_by_length")
+def _(offsets, max_length=0):
+    return torch.empty((offsets.shape[0] - 1,), device=offsets.device, dtype=torch.int32)
 
 
 @torch.library.register_fake("cuembed_pyt::cuembed_embedding_backward")

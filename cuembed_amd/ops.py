@@ -351,13 +351,43 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
             raise TypeError("block_row_ids must be int32 (uint32 bit patterns)")
     else:
         block_row_ids = None
+    # num_unique on the device only: the buffers' row count is the capacity the kernels check against -- too small,
+    # and nothing is written and the device's sticky overflow word is raised (capacity_overflowed()) -- never an overrun
+    capacity = min(grad_embedding.shape[0], inverse_mapping.numel()) if unknown_rows else 0
     with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
-        _lib.lib().cuembed_embedding_backward_blocked(
+        _lib.lib().cuembed_embedding_backward_bounded(
             _ptr(grad_y), et, width, -1 if unknown_rows else num_grad_embedding_rows, nnz, _ptr(transpose_indices),
             _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
             int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), int(sample_blocks),
-            _ptr(block_row_ids), _stream(grad_y))
+            _ptr(block_row_ids), int(capacity), _ptr(_overflow_word(dev)) if unknown_rows else None, _stream(grad_y))
     return grad_embedding, inverse_mapping
+
+
+_OVERFLOW_WORDS = {}
+
+
+def _overflow_word(device):
+    """The device's sticky "a compressed gradient did not fit its buffers" word (torch owns the 4 bytes; the library
+    keeps no state of its own)."""
+    key = (device.type, torch.cuda.current_device() if device.index is None else device.index)
+    w = _OVERFLOW_WORDS.get(key)
+    if w is None:
+        w = _OVERFLOW_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def capacity_overflowed(device=None, reset=False):
+    """True if any embedding_backward(num_grad_embedding_rows=None, ...) on `device` since the last reset found more
+    gradient rows on the device than its grad_embedding / inverse_mapping buffers hold (such a call writes nothing).
+    Synchronises with the device (one 4-byte read-back): call it where a sync is affordable -- e.g. once per epoch."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    w = _OVERFLOW_WORDS.get((device.type, torch.cuda.current_device() if device.index is None else device.index))
+    if w is None:
+        return False
+    hit = bool(w.item())
+    if reset:
+        w.zero_()
+    return hit
 
 
 def transpose_workspace_bytes(nnz, index_dtype, weight_dtype=None):
@@ -371,7 +401,8 @@ def transpose_workspace_bytes(nnz, index_dtype, weight_dtype=None):
     return lwork.value
 
 
-def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num_rows=None, sample_blocks=1):
+def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num_rows=None, sample_blocks=1,
+              remapped=False):
     """Stable sort of (rows[i][, weights[i]]) by key cols[i] (callers pass rows = sample ids,
     cols = lookup indices).  Returns (sorted cols, rows carried along, weights carried along).
     Generic like the reference's: `cols` are ordered as signed numbers, `rows` may hold anything.
@@ -381,7 +412,9 @@ def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num
     -- int64 rows below 2^32 then travel as 32 bits without the library reading them to find out.
     sample_blocks (optional, extension, CHANGES the result): > 1 cuts the (sample-major) input into that many
     consecutive blocks and transposes each on its own -- compressed-gradient path only, see
-    recommended_sample_blocks()."""
+    recommended_sample_blocks().
+    remapped=True (extension): a fourth result, what compute_compressed_grad_indices(sorted cols) returns, from the same
+    call -- up to 16,384 lookups the whole index work is then ONE kernel launch."""
     _check_dev("rows", rows)
     dev = rows.device
     _check_dev("cols", cols, dev)
@@ -407,13 +440,14 @@ def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num
     lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
     bits = 0 if not num_categories else max(1, int(num_categories - 1).bit_length())
     row_bits = 0 if not num_rows else max(1, int(num_rows - 1).bit_length())
+    remap = torch.empty_like(cols) if remapped else None
     if nnz > 0:
         with torch.cuda.device(rows.device):   # the launch must happen on the tensors' device
-            _lib.lib().cuembed_transpose_sample_blocks(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
-                                                       _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(workspace),
-                                                       ctypes.byref(lwork), bits, row_bits, int(sample_blocks),
-                                                       _stream(rows))
-    return t_rows, t_cols, t_w
+            _lib.lib().cuembed_transpose_remapped(_ptr(rows), _ptr(cols), _ptr(weights), nnz, it, wt,
+                                                  _ptr(t_rows), _ptr(t_cols), _ptr(t_w), _ptr(remap), _ptr(workspace),
+                                                  ctypes.byref(lwork), bits, row_bits, int(sample_blocks),
+                                                  _stream(rows))
+    return (t_rows, t_cols, t_w, remap) if remapped else (t_rows, t_cols, t_w)
 
 
 def transpose_sample_block_length(nnz, sample_blocks):
@@ -431,10 +465,11 @@ def recommended_sample_blocks(grad_dtype, embed_width, batch_size, nnz, compute_
 
 
 def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspace=None, num_categories=None,
-                            sample_blocks=1):
+                            sample_blocks=1, remapped=False):
     """extract_row_ids_from_fixed + transpose in one call without materialising the sample ids
     (cuembed::TransposeFixedHotness, extension): returns (sorted indices, sample ids, weights).
-    num_hots=1 is the concat layout.  sample_blocks as in transpose()."""
+    num_hots=1 is the concat layout.  sample_blocks and remapped (a fourth result: the compressed-gradient ids of the
+    sorted indices) as in transpose()."""
     _check_dev("indices", indices)
     dev = indices.device
     it = _index_code("indices", indices)
@@ -458,12 +493,13 @@ def transpose_fixed_hotness(indices, batch_size, num_hots, weights=None, workspa
         raise ValueError("workspace too small: need %d bytes" % need)
     lwork = ctypes.c_size_t(workspace.numel() * workspace.element_size())
     bits = 0 if not num_categories else max(1, int(num_categories - 1).bit_length())
+    remap = torch.empty((nnz,), dtype=indices.dtype, device=dev) if remapped else None
     if nnz > 0:
         with torch.cuda.device(dev):
-            _lib.lib().cuembed_transpose_fixed_hotness_sample_blocks(
+            _lib.lib().cuembed_transpose_fixed_hotness_remapped(
                 _ptr(indices), _ptr(weights), batch_size, num_hots, it, wt, _ptr(t_idx), _ptr(t_sid), _ptr(t_w),
-                _ptr(workspace), ctypes.byref(lwork), bits, int(sample_blocks), _stream(indices))
-    return t_idx, t_sid, t_w
+                _ptr(remap), _ptr(workspace), ctypes.byref(lwork), bits, int(sample_blocks), _stream(indices))
+    return (t_idx, t_sid, t_w, remap) if remapped else (t_idx, t_sid, t_w)
 
 
 def compressed_grad_workspace_bytes(nnz, index_dtype):

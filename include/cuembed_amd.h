@@ -238,6 +238,24 @@ void cuembed_transpose_fixed_hotness_sample_blocks(const void* indices, const vo
                                                    void* transpose_indices, void* transpose_sample_ids,
                                                    void* transpose_weights, char* work, size_t* lwork,
                                                    int index_bits, int sample_blocks, cuembed_stream_t stream);
+/* Extension (cuembed::Transpose / TransposeFixedHotness, `transpose_remapped_indices`): as the two calls above, and
+ * transpose_remapped_indices (nnz entries of the index type; NULL: not wanted) also receives what
+ * cuembed_compute_compressed_grad_indices would compute from transpose_rows / transpose_indices -- the same values
+ * from the same call.  Up to 16,384 lookups the WHOLE index work (row ids of a fixed-hotness batch, stable sort, remap)
+ * is ONE launch of one 1024-thread workgroup (a dependent launch costs 3.5-5 us at these sizes and the
+ * reference's sequence is about ten of them, index_transforms.cuh:95-137, :278-323); beyond that the run-head scan's
+ * launches follow the sort's on the stream and share `work`. */
+void cuembed_transpose_remapped(const void* rows, const void* cols, const void* weights, int nnz,
+                                int index_type, int weight_type, void* transpose_rows,
+                                void* transpose_cols, void* transpose_weights, void* transpose_remapped_indices,
+                                char* work, size_t* lwork, int index_bits, int row_bits, int sample_blocks,
+                                cuembed_stream_t stream);
+void cuembed_transpose_fixed_hotness_remapped(const void* indices, const void* weights, int batch_size,
+                                              int num_hots, int index_type, int weight_type,
+                                              void* transpose_indices, void* transpose_sample_ids,
+                                              void* transpose_weights, void* transpose_remapped_indices, char* work,
+                                              size_t* lwork, int index_bits, int sample_blocks,
+                                              cuembed_stream_t stream);
 int cuembed_recommended_sample_blocks(int elem_type, int embed_width, int batch_size, int64_t nnz);
 /* Lookups per block that the two calls above use: block k = lookups [k * L, (k + 1) * L), L a multiple of 4096
  * (inputs of up to 131,072 lookups are always ONE block). */
@@ -274,6 +292,20 @@ void cuembed_embedding_backward_blocked(const void* grad_y, int elem_type, int e
                                         const void* transpose_weights, int skip_grad_init,
                                         void* grad_embedding, void* inverse_mapping, int sample_blocks,
                                         const uint32_t* block_row_ids, cuembed_stream_t stream);
+/* Extension: cuembed_embedding_backward_blocked (sample_blocks <= 1, block_row_ids NULL: cuembed_embedding_backward)
+ * with a CAPACITY for the device-side row count.  With num_grad_embedding_rows < 0 only the device knows how many rows
+ * the compressed gradient has; capacity_rows > 0 states how many rows grad_embedding and inverse_mapping really hold.
+ * If the count exceeds it, nothing is written (per launch: a sample-blocked call may have written its earlier blocks)
+ * and *capacity_overflow -- a device word the caller zeroed once; may be NULL -- is OR-ed with 1: a sticky flag to read
+ * back whenever convenient instead of a silent overrun.  capacity_rows = 0: unchecked (the other entry points). */
+void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int embed_width,
+                                        int num_grad_embedding_rows, int nnz,
+                                        const void* transpose_indices, const void* transpose_sample_ids,
+                                        const void* transpose_remapped_indices, int index_type,
+                                        const void* transpose_weights, int skip_grad_init,
+                                        void* grad_embedding, void* inverse_mapping, int sample_blocks,
+                                        const uint32_t* block_row_ids, int capacity_rows,
+                                        uint32_t* capacity_overflow, cuembed_stream_t stream);
 void cuembed_extract_row_ids_from_fixed(int batch_size, int num_hots, int index_type,
                                         void* row_ids, cuembed_stream_t stream);
 void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int batch_size,

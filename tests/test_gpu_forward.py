@@ -300,9 +300,10 @@ def test_weight_gradient_all_types_and_layouts(ce, tdtype, idx):
 @pytest.mark.parametrize("dtype,index_dtype,weighted,mode", [
     (torch.float32, torch.int32, True, "sum"), (torch.float16, torch.int64, False, "mean"),
     (torch.float16, torch.int32, True, "sum"), (torch.float32, torch.int64, False, "sum")])
-def test_forward_sample_order_is_a_scheduling_hint_only(dtype, index_dtype, weighted, mode):
+def test_forward_sample_order_is_a_scheduling_hint_only(oracle, dtype, index_dtype, weighted, mode):
     """ForwardOptions::sample_order (extension): whatever permutation the samples are handed to the wavefronts in,
-    every output row holds the same bits; bag_order_by_length() is the permutation by descending bag length."""
+    every output row holds the ORACLE's bits (not merely the default order's); bag_order_by_length() is the permutation
+    by descending bag length."""
     import cuembed_amd as ce
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(11)
@@ -318,6 +319,9 @@ def test_forward_sample_order_is_a_scheduling_hint_only(dtype, index_dtype, weig
     table = torch.randn((rows, W), device=dev, generator=g).to(dtype)
     w = torch.rand((nnz,), device=dev, generator=g).to(dtype) if weighted else None
     want = ce.embedding_forward(table, idx, off, w, num_hots=0, mode=mode)
+    want_oracle = oracle.embedding_forward(table.cpu().numpy(), idx.cpu().numpy(), off.cpu().numpy(),
+                                           None if w is None else w.cpu().numpy(), num_hots=0, mode=mode)
+    assert np.array_equal(want.cpu().numpy().view(np.uint8), want_oracle.view(np.uint8))
     by_length = ce.bag_order_by_length(off, max_length=700)
     assert by_length.dtype == torch.int32 and torch.equal(torch.sort(by_length).values,
                                                             torch.arange(B, device=dev, dtype=torch.int32))
@@ -331,7 +335,7 @@ def test_forward_sample_order_is_a_scheduling_hint_only(dtype, index_dtype, weig
     for order in (by_length, torch.randperm(B, device=dev, generator=g).int(),
                   torch.arange(B - 1, -1, -1, device=dev, dtype=torch.int32)):
         got = ce.embedding_forward(table, idx, off, w, num_hots=0, mode=mode, sample_order=order)
-        assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))
+        assert np.array_equal(got.cpu().numpy().view(np.uint8), want_oracle.view(np.uint8))     # the oracle's bits
     with pytest.raises(ValueError):       # a hint for ragged bags only
         ce.embedding_forward(table, idx[:B * 2], num_hots=2, batch_size=B, sample_order=by_length)
     with pytest.raises(ValueError):

@@ -167,7 +167,7 @@ def test_op_schemas_and_dtypes(pyt):
 
 @pytest.mark.parametrize("weighted", [False, True])
 def test_sparse_gradient_extension(pyt, weighted):
-    """sparse_grad=True returns the compressed gradient as a coalesced sparse COO tensor that
+    """sparse_grad=True returns the compressed gradient as a sparse COO tensor (coalesced at this size: one block) that
     densifies to the dense-path gradient (and to nn.EmbeddingBag's)."""
     k, d, B = 20000, 64, 2048
     bag = make_bag(k, d)
@@ -219,22 +219,23 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     indices = (k * torch.rand(n, device="cuda") ** (2 if ragged else 3)).long()
     up = torch.randint(-1, 2, (B, d), device="cuda").half()
     grads = {}
-    for kind in (True, "uncoalesced", "blocked"):
+    for kind in ("reference", True, "uncoalesced", "blocked"):
         weight.grad = None
         (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=kind) * up).sum().backward()
         grads[kind] = weight.grad
     # "blocked": the coalesced gradient computed from the same sample-blocked order -- identical tensors
-    assert torch.equal(grads["blocked"]._indices(), grads[True]._indices())
-    assert torch.equal(grads["blocked"]._values(), grads[True]._values())
-    ids = grads[True]._indices()[0]
-    assert (ids[1:] > ids[:-1]).all()                                # coalesced: ascending, no duplicates
-    assert not grads["uncoalesced"].is_coalesced()
-    n_unique = grads[True]._nnz()
-    assert n_unique < grads["uncoalesced"]._nnz() <= 2 * n_unique
+    assert torch.equal(grads["blocked"]._indices(), grads["reference"]._indices())
+    assert torch.equal(grads["blocked"]._values(), grads["reference"]._values())
+    ids = grads["reference"]._indices()[0]
+    assert (ids[1:] > ids[:-1]).all()      # coalesced: ascending, no duplicates (autograd's accumulation drops the flag)
+    n_unique = grads["reference"]._nnz()
     # exact in fp16: integers below 2048, or -- with weights 0.5 / 0.25 -- multiples of 0.25 below 512
-    assert float(grads[True].to_dense().abs().max()) < (512 if ragged else 2048)
-    assert torch.equal(grads["uncoalesced"].to_dense(), grads[True].to_dense())
-    assert torch.equal(grads["uncoalesced"].coalesce()._values(), grads[True]._values())
+    assert float(grads["reference"].to_dense().abs().max()) < (512 if ragged else 2048)
+    for kind in (True, "uncoalesced"):     # True = the fastest order for the shape: the sample-blocked one here
+        assert not grads[kind].is_coalesced()
+        assert n_unique < grads[kind]._nnz() <= 2 * n_unique
+        assert torch.equal(grads[kind].to_dense(), grads["reference"].to_dense())
+        assert torch.equal(grads[kind].coalesce()._values(), grads["reference"]._values())
 
 
 @pytest.mark.parametrize("mode", ["sum", "mean", "concat"])
@@ -289,6 +290,76 @@ def test_per_sample_weights_gradient_extension(pyt, d):
     w3 = w1.detach().clone().requires_grad_(True)
     (pyt.cuemb_embedding(bag.weight.detach(), indices, offsets, w3) * up).sum().backward()
     assert torch.allclose(w3.grad, w2.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+@pytest.mark.parametrize("kind", [False, True, "reference"])
+def test_native_autograd_node_equals_the_python_function(pyt, kind, idx_dtype):
+    """Outside torch.compile cuemb_embedding runs as ONE native autograd node (CuEmbEmbeddingNode: forward, and row ids ->
+    transpose + remap -> scatter-add in the backward, the row count read back after everything is enqueued); the
+    Python autograd.Function over the same ops must give the same bits -- small (one-workgroup sort), mid-size
+    (chained sort), empty bags, weights, a non-contiguous incoming gradient."""
+    torch.manual_seed(3)
+    for k, d, B, hi in ((5000, 32, 300, 9), (200000, 64, 9000, 30)):
+        lens = torch.randint(0, hi, (B,), device="cuda")
+        offsets = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens.cumsum(0)]).to(idx_dtype)
+        n = int(offsets[-1])
+        indices = torch.randint(0, k, (n,), device="cuda").to(idx_dtype)
+        for weighted in (False, True):
+            w = torch.rand(n, device="cuda") if weighted else None
+            table = torch.randn(k, d, device="cuda")
+            up = torch.randn(d, B, device="cuda").t()           # non-contiguous
+            t1 = table.clone().requires_grad_(True)
+            y1 = pyt.cuemb_embedding(t1, indices, offsets, w, sparse_grad=kind, hints=None)
+            assert "CuEmbEmbeddingNode" in y1.grad_fn.name()
+            y1.backward(up)
+            t2 = table.clone().requires_grad_(True)
+            y2 = pyt._CuEmbEmbedding.apply(t2, indices, offsets, w, kind, None)
+            y2.backward(up)
+            assert torch.equal(y1, y2)
+            if kind is False:
+                assert torch.equal(t1.grad, t2.grad)
+            else:
+                assert t1.grad.is_sparse and t1.grad._nnz() == torch.unique(indices).numel()
+                ids = t1.grad._indices()[0]
+                assert bool((ids[1:] > ids[:-1]).all())                       # one block: ascending, no duplicates
+                assert torch.equal(t1.grad._indices(), t2.grad._indices())
+                assert torch.equal(t1.grad._values(), t2.grad._values())
+    # frozen table: no node, no gradient
+    y = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad=kind)
+    assert y.grad_fn is None
+
+
+def test_policy_hints_never_change_a_result(pyt):
+    """cuembed_amd.policy picks non-temporal row loads for a table whose batches are (nearly) all distinct rows and the
+    bag order for an offsets tensor it sees again; both are scheduling hints: same bits, and the decisions are the
+    expected ones (uniform indices over a > 1 GiB table: streaming; a power-law batch: not)."""
+    from cuembed_amd import policy
+    policy.set_enabled(True)
+    k, d, B = 2_200_000, 128, 20000          # 1.05 GiB of fp32
+    table = torch.randn(k, d, device="cuda")
+    lens = torch.randint(20, 100, (B,), device="cuda")
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens.cumsum(0)])
+    n = int(offsets[-1])
+    assert n >= policy.ORDER_MIN_LOOKUPS
+    uniform = torch.randint(0, k, (n,), device="cuda")
+    skewed = (k * torch.rand(n, device="cuda") ** 8).long()
+    assert policy.distinct_fraction(uniform) > 0.95 > policy.STREAMING_DISTINCT > policy.distinct_fraction(skewed)
+    plain = pyt.cuemb_embedding(table, uniform, offsets, None, hints=None)
+    assert policy.row_loads(table, uniform) == 1 and policy.row_loads(table.clone(), skewed) == 0
+    assert policy.sample_order(offsets, n) is None                  # first sight: nothing is prepared
+    order = policy.sample_order(offsets, n)                          # second sight: the order exists and is cached
+    assert order is not None and order.dtype == torch.int32 and policy.sample_order(offsets, n) is order
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(B, device="cuda"))
+    assert bool((lens[order.long()][1:] <= lens[order.long()][:-1]).all())         # descending bag length
+    hinted = pyt.cuemb_embedding(table, uniform, offsets, None)      # hints="auto": streaming + the cached order
+    assert torch.equal(plain, hinted)
+    t = table.clone().requires_grad_(True)
+    y = pyt.cuemb_embedding(t, uniform, offsets, None, sparse_grad=True)
+    assert torch.equal(y, plain)
+    policy.set_enabled(False)
+    assert policy.row_loads(table, uniform) == -1 and policy.sample_order(offsets, n) is None
+    policy.set_enabled(True)
 
 
 def test_ops_are_the_native_extension(pyt):

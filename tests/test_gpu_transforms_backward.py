@@ -333,13 +333,103 @@ def test_transpose_tile_boundaries_and_degenerate_keys(ce, oracle, idx):
 
 
 @pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
-def test_transpose_skips_identity_passes_on_device(ce, oracle, idx):
+@pytest.mark.parametrize("weights", [None, np.float32, np.float16], ids=["unweighted", "w32", "w16"])
+def test_one_launch_index_work_of_small_batches(ce, oracle, idx, weights):
+    """Up to 16,384 lookups the whole index work -- row ids, stable sort, remap -- is ONE launch of one 1024-thread
+    workgroup (block_sort_kernels.hpp): sizes around its round (64), chunk (1024 x rounds) and kernel-variant (4096,
+    16384) boundaries; keys with one or all varying digits, negative keys, runs longer than a wavefront; through the
+    reference-shaped call sequence, through transpose(remapped=True) and through transpose_fixed_hotness(remapped=True).
+    16,385 lookups take the tiled path: same results from the same calls."""
+    rng = np.random.default_rng(77)
+    info = np.iinfo(idx[0])
+    for nnz in (1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 3000, 4095, 4096, 4097, 5001, 8192, 12345, 16383, 16384,
+                16385):
+        kinds = [("random20", rng.integers(0, 1 << 20, nnz)), ("few", rng.integers(0, 3, nnz)),
+                 ("full", rng.integers(info.min, info.max, nnz, endpoint=True)), ("equal", np.full(nnz, 12345))]
+        for name, cols in kinds:
+            cols = cols.astype(idx[0])
+            hot = 1 if nnz % 7 else 7
+            batch = nnz // hot
+            n = batch * hot
+            if n == 0:
+                continue
+            cols = cols[:n]
+            w = None if weights is None else rng.uniform(0, 1, n).astype(weights)
+            o_sid = oracle.extract_row_ids_from_fixed(batch, hot, idx[0])
+            oi, os_, ow = oracle.transpose(o_sid, cols, w, stable=True)
+            oremap = oracle.compute_compressed_grad_indices(oi)
+
+            def check(got, what):
+                assert np.array_equal(host(got[0]), oi) and np.array_equal(host(got[1]), os_), (nnz, name, what)
+                if w is not None:
+                    assert np.array_equal(host(got[2]).view(np.uint8), ow.view(np.uint8)), (nnz, name, what)
+                if len(got) > 3:
+                    assert np.array_equal(host(got[3]), oremap), (nnz, name, what)
+
+            sid = ce.extract_row_ids_from_fixed(batch, hot, idx[1], "cuda")
+            check(ce.transpose(sid, dev(cols), dev(w)), "transpose")
+            check(ce.transpose(sid, dev(cols), dev(w), remapped=True), "transpose+remap")
+            check(ce.transpose_fixed_hotness(dev(cols), batch, hot, dev(w), remapped=True), "fixed+remap")
+            if name == "random20":
+                check(ce.transpose_fixed_hotness(dev(cols), batch, hot, dev(w), num_categories=1 << 20, remapped=True),
+                      "fixed+remap bounded")
+    assert ce._lib.lib().cuembed_peek_last_error() == 0
+
+
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+@pytest.mark.parametrize("weights", [None, np.float16], ids=["unweighted", "w16"])
+def test_transpose_chained_and_tiled_paths(ce, oracle, idx, weights):
+    """Between 16,385 and 262,144 lookups the sort runs ONE launch per pass: every scatter pass counts the histogram of
+    the next working pass with global atomics, per (destination tile of 1,024 keys, next digit), aggregated over runs
+    of equal neighbours.  Sizes around its tile and range boundaries (262,145 and up: the three-launch passes); hot
+    keys (runs far longer than a wavefront, whose atomics must aggregate), two-valued and constant keys, keys using all
+    bits incl. the sign; reference call sequence and the fused calls."""
+    rng = np.random.default_rng(5)
+    info = np.iinfo(idx[0])
+    for nnz in (16385, 17407, 17408, 17409, 65536, 100003, 262144, 262145, 270001):
+        hot_keys = np.where(rng.uniform(0, 1, nnz) < 0.4, 777, rng.integers(0, 10_000_000, nnz))
+        kinds = [("random24", rng.integers(0, 10_000_000, nnz)), ("hot", hot_keys), ("two", rng.integers(0, 2, nnz) * 65536),
+                 ("full", rng.integers(info.min, info.max, nnz, endpoint=True)), ("equal", np.full(nnz, 3))]
+        if nnz not in (17408, 65536, 262144, 262145):
+            kinds = kinds[:2] + kinds[3:4]
+        for name, cols in kinds:
+            cols = cols.astype(idx[0])
+            hot = 1 if nnz % 3 else 3
+            batch = nnz // hot
+            n = batch * hot
+            cols = cols[:n]
+            w = None if weights is None else rng.uniform(0, 1, n).astype(weights)
+            o_sid = oracle.extract_row_ids_from_fixed(batch, hot, idx[0])
+            oi, os_, ow = oracle.transpose(o_sid, cols, w, stable=True)
+            oremap = oracle.compute_compressed_grad_indices(oi)
+
+            def check(got, what):
+                assert np.array_equal(host(got[0]), oi) and np.array_equal(host(got[1]), os_), (nnz, name, what)
+                if w is not None:
+                    assert np.array_equal(host(got[2]).view(np.uint8), ow.view(np.uint8)), (nnz, name, what)
+                if len(got) > 3:
+                    assert np.array_equal(host(got[3]), oremap), (nnz, name, what)
+
+            sid = ce.extract_row_ids_from_fixed(batch, hot, idx[1], "cuda")
+            t = ce.transpose(sid, dev(cols), dev(w))
+            check(t, "transpose")
+            assert np.array_equal(host(ce.compute_compressed_grad_indices(t[0])), oremap), (nnz, name, "remap")
+            check(ce.transpose_fixed_hotness(dev(cols), batch, hot, dev(w), remapped=True), "fixed+remap")
+            if name in ("random24", "hot"):
+                check(ce.transpose(sid, dev(cols), dev(w), num_categories=10_000_000, num_rows=batch, remapped=True),
+                      "bounded+remap")
+    assert ce._lib.lib().cuembed_peek_last_error() == 0
+
+
+@pytest.mark.parametrize("nnz", [3 * 4096 + 123, 40000, 270000], ids=["one_workgroup", "chained", "tiled"])
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_transpose_skips_identity_passes_on_device(ce, oracle, idx, nnz):
     """Radix passes whose digit is the same for every key are skipped on the device and the
     remaining passes re-route their buffers: every combination of varying digits must still give
-    the stable order in the caller's output arrays (odd and even numbers of working passes)."""
+    the stable order in the caller's output arrays (odd and even numbers of working passes) -- in each of the three
+    implementations of the sort (one workgroup, one launch per pass, three launches per pass)."""
     rng = np.random.default_rng(21)
     ndig = np.dtype(idx[0]).itemsize
-    nnz = 3 * 4096 + 123
     combos = [(0,), (1,), (2,), (3,), (0, 2), (1, 2), (1, 3), (0, 1, 2), (0, 1, 2, 3)]
     if ndig == 8:
         combos += [(5,), (0, 5), (2, 4, 6), (1, 2, 3, 4, 5, 6), (0, 1, 2, 3, 4, 5, 6, 7)]
@@ -395,6 +485,62 @@ def test_backward_compressed_zero_init_without_full_memset(ce, oracle):
             ce.embedding_backward(dev(gy), None, dev(ti), dev(ts), dev(remap))       # buffers are required
         with pytest.raises(ValueError):
             ce.embedding_backward(dev(gy), None, dev(ti), dev(ts), grad_embedding=buf, inverse_mapping=ibuf)  # dense
+
+
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_backward_device_side_row_count_respects_the_buffer_capacity(ce, oracle, blocks):
+    """num_grad_embedding_rows=None (num_unique stays on the device): buffers ONE row short of num_unique must give the
+    sticky overflow flag and leave every byte alone -- the row behind the buffer included -- instead of an overrun;
+    exactly num_unique rows must work and leave the flag down."""
+    W, ncat = 64, 50000
+    B, H = (3000, 16) if blocks == 1 else (40000, 8)          # (sample blocks need > 131,072 lookups)
+    a = oracle.allocate_forward(ncat, W, B, H, alpha=1.05)
+    gy = (np.mod(oracle.allocate_grad_y(B * W).reshape(B, W), 3) - 1).astype(np.float32)
+    idx = dev(a["indices"])
+    sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, "cuda")
+    if blocks == 1:
+        ti, ts, _ = ce.transpose(sid, idx)
+        remap, pair_rows = ce.compute_compressed_grad_indices(ti), None
+    else:
+        ti, ts, _ = ce.transpose(sid, idx, sample_blocks=blocks)
+        remap, pair_rows, _ = ce.compute_compressed_grad_indices_blocked(ti, blocks)
+    nu = int(torch.unique(idx).numel())
+    ce.capacity_overflowed(reset=True)
+    # the allocation is one row LONGER than what the call is told about: the guard row shows an overrun
+    for cap, fits in ((nu, True), (nu - 1, False)):
+        whole = torch.full((cap + 1, W), 77.0, device="cuda")
+        iwhole = torch.full((cap + 1,), -9, dtype=torch.int32, device="cuda")
+        got, inv = ce.embedding_backward(dev(gy), None, ti, ts, remap, grad_embedding=whole[:cap],
+                                         inverse_mapping=iwhole[:cap], sample_blocks=blocks, block_row_ids=pair_rows)
+        torch.cuda.synchronize()
+        assert bool((whole[cap] == 77.0).all()) and int(iwhole[cap]) == -9, "wrote behind the buffer"
+        assert ce.capacity_overflowed() == (not fits)
+        if fits:
+            o_sid = oracle.extract_row_ids_from_fixed(B, H)
+            oti, ots, _ = oracle.transpose(o_sid, a["indices"])
+            want, winv = oracle.embedding_backward(gy, W, nu, oti, ots, oracle.compute_compressed_grad_indices(oti))
+            assert np.array_equal(host(inv), winv) and np.array_equal(host(got), want)
+        elif blocks == 1:
+            assert bool((whole == 77.0).all()) and bool((iwhole == -9).all()), "an over-full call must write nothing"
+    assert ce.capacity_overflowed(reset=True) is True and ce.capacity_overflowed() is False      # sticky until reset
+
+
+def test_backward_zeroes_a_large_over_allocated_tail(ce, oracle):
+    """A host-known row count far above num_unique (an over-allocated min(nnz, rows) buffer): every row past the last
+    id must read zero, also when the tail is odd-sized and starts off a 16-byte boundary."""
+    W, B, H, ncat = 34, 2000, 8, 300          # 68-byte fp16 rows: the tail starts on every 4-byte phase of a 16-byte line
+    a = oracle.allocate_forward(ncat, W, B, H, alpha=1.15, elem=np.float16)
+    sid = oracle.extract_row_ids_from_fixed(B, H)
+    ti, ts, _ = oracle.transpose(sid, a["indices"])
+    remap = oracle.compute_compressed_grad_indices(ti)
+    nu = int(remap[-1]) + 1
+    gy = (np.mod(oracle.allocate_grad_y(B * W).reshape(B, W), 3) - 1).astype(np.float16)
+    rows = nu + 70001
+    buf = torch.full((rows, W), 5.0, dtype=torch.float16, device="cuda")
+    got, inv = ce.embedding_backward(dev(gy), rows, dev(ti), dev(ts), dev(remap), skip_grad_init=False, grad_embedding=buf)
+    want, winv = oracle.embedding_backward(gy.astype(np.float32), W, nu, ti, ts, remap)
+    assert np.array_equal(host(got[:nu]).astype(np.float32), want) and np.array_equal(host(inv)[:nu], winv)
+    assert bool((got[nu:] == 0).all())
 
 
 @pytest.mark.parametrize("elem", ELEMS, ids=["f32", "f16"])

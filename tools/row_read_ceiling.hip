@@ -1,0 +1,106 @@
+// What can a random-row gather reach at all?  Loads only -- no reduction, no output rows: every wavefront reads
+// rows of R bytes at uniformly random row ids of a table far larger than the caches, 16 bytes per lane (R / 16 lanes
+// per row, 64 * 16 / R rows per wavefront instruction), K independent loads in flight per lane, and folds what it read
+// into one word so that nothing is optimised away.  The GB/s of this loop is the ceiling EmbeddingForward's gather can be
+// judged against for narrow rows (10M x 32 fp32, alpha = 0 reaches 0.49-0.58 of the HBM peak against
+// 0.72 for 512-byte rows -- is that DRAM or the kernel?).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/row_read_ceiling.hip -o tools/row_read_ceiling
+//   tools/row_read_ceiling            (prints one line per row size x loads in flight x load policy)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define HIP_OK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) {                                                                         \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));        \
+      std::exit(2);                                                                                 \
+    }                                                                                               \
+  } while (0)
+
+typedef unsigned __attribute__((ext_vector_type(4))) word4_t;
+
+// lookups: row ids; each group of (row_bytes / 16) lanes reads one row per load instruction.
+template <int K, bool kNonTemporal>
+__global__ void __launch_bounds__(256) GatherRowsKernel(const char* __restrict__ table, const int row_bytes,
+                                                        const int* __restrict__ lookups, const int64_t num_lookups,
+                                                        unsigned* __restrict__ sink) {
+  const int lanes_per_row = row_bytes / 16;
+  const int rows_per_wave = 64 / lanes_per_row;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lanes_per_row, part = lane % lanes_per_row;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  word4_t acc = word4_t{0u, 0u, 0u, 0u};
+  // wavefront w takes lookups [w * chunk, (w + 1) * chunk), K * rows_per_wave of them per iteration
+  const int64_t chunk = (num_lookups + waves - 1) / waves;
+  const int64_t begin = wave * chunk, end = begin + chunk < num_lookups ? begin + chunk : num_lookups;
+  for (int64_t i = begin; i + static_cast<int64_t>(K) * rows_per_wave <= end; i += static_cast<int64_t>(K) * rows_per_wave) {
+    word4_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int row = lookups[i + k * rows_per_wave + sub];
+      const word4_t* p = reinterpret_cast<const word4_t*>(table + static_cast<int64_t>(row) * row_bytes + part * 16);
+      v[k] = kNonTemporal ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc ^= v[k];
+  }
+  const unsigned folded = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (folded == 0x12345678u) sink[0] = folded;   // (practically never: keeps the loads)
+}
+
+template <int K, bool kNt>
+double Run(const char* table, int row_bytes, const int* lookups, int64_t n, unsigned* sink, int grid) {
+  hipEvent_t a, z;
+  HIP_OK(hipEventCreate(&a));
+  HIP_OK(hipEventCreate(&z));
+  for (int t = 0; t < 3; ++t) GatherRowsKernel<K, kNt><<<grid, 256>>>(table, row_bytes, lookups, n, sink);
+  HIP_OK(hipEventRecord(a));
+  const int iters = 10;
+  for (int t = 0; t < iters; ++t) GatherRowsKernel<K, kNt><<<grid, 256>>>(table, row_bytes, lookups, n, sink);
+  HIP_OK(hipEventRecord(z));
+  HIP_OK(hipEventSynchronize(z));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, a, z));
+  return ms / iters;
+}
+
+int main() {
+  const int64_t table_bytes = int64_t{5} << 30;       // 5 GiB: far beyond L2 (32 MiB) and the Infinity Cache (256 MiB)
+  const int64_t num_lookups = int64_t{1} << 24;       // 16.8 M rows per launch
+  char* table = nullptr;
+  int* lookups = nullptr;
+  unsigned* sink = nullptr;
+  HIP_OK(hipMalloc(&table, table_bytes));
+  HIP_OK(hipMemset(table, 1, table_bytes));
+  HIP_OK(hipMalloc(&lookups, num_lookups * sizeof(int)));
+  HIP_OK(hipMalloc(&sink, 64));
+  std::vector<int> h(num_lookups);
+  std::mt19937_64 rng(7);
+  std::printf("row_bytes,loads_in_flight,policy,grid,ms,GBps,frac_of_8TBps\n");
+  for (int row_bytes : {64, 128, 256, 512, 1024}) {
+    const int64_t rows = table_bytes / row_bytes;
+    for (auto& x : h) x = static_cast<int>(rng() % static_cast<uint64_t>(rows));
+    HIP_OK(hipMemcpy(lookups, h.data(), num_lookups * sizeof(int), hipMemcpyHostToDevice));
+    const double bytes = static_cast<double>(num_lookups) * row_bytes;
+    for (int grid : {2048, 8192}) {
+#define ROW(K, NT)                                                                                              \
+  {                                                                                                             \
+    const double ms = Run<K, NT>(table, row_bytes, lookups, num_lookups, sink, grid);                           \
+    std::printf("%d,%d,%s,%d,%.4f,%.0f,%.3f\n", row_bytes, K, NT ? "nt" : "default", grid, ms, bytes / ms / 1e6, \
+                bytes / ms / 1e6 / 8000.0);                                                                     \
+  }
+      ROW(4, false) ROW(8, false) ROW(16, false) ROW(8, true) ROW(16, true)
+#undef ROW
+    }
+  }
+  std::fflush(stdout);
+  return 0;
+}
