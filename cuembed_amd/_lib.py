@@ -37,6 +37,8 @@ def _declare(L):
     L.cuembed_get_forward_row_load_policy.argtypes = []
     L.cuembed_embedding_backward.restype = None
     L.cuembed_embedding_backward.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP]
+    L.cuembed_embedding_backward_reference_sums.restype = None
+    L.cuembed_embedding_backward_reference_sums.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP]
     L.cuembed_set_backward_tuning.restype = None
     L.cuembed_set_backward_tuning.argtypes = [_I, _I]
     L.cuembed_get_backward_tuning.restype = None
@@ -83,7 +85,7 @@ def _declare(L):
                                                      _VP]
     L.cuembed_embedding_backward_bounded.restype = None
     L.cuembed_embedding_backward_bounded.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP,
-                                                     _I, _VP, _VP]
+                                                     _I, _VP, _I, _VP]
     L.cuembed_extract_row_ids_from_fixed.restype = None
     L.cuembed_extract_row_ids_from_fixed.argtypes = [_I, _I, _I, _VP, _VP]
     L.cuembed_extract_row_ids_from_csr.restype = None

@@ -11,11 +11,12 @@ template <typename ElemT, typename IndexT>
 void Backward(const void* grad_y, int embed_width, int num_rows, int nnz, const IndexT* t_idx,
               const IndexT* t_sid, const IndexT* t_remap, const void* t_w, int skip_init,
               void* grad, IndexT* inverse_mapping, cuembed_stream_t stream, int sample_blocks = 1,
-              const uint32_t* block_row_ids = nullptr, int capacity_rows = 0, uint32_t* capacity_overflow = nullptr) {
+              const uint32_t* block_row_ids = nullptr, int capacity_rows = 0, uint32_t* capacity_overflow = nullptr,
+              int pad_to_capacity = 0) {
   cuembed::EmbeddingBackward<ElemT, IndexT>(
       static_cast<const ElemT*>(grad_y), embed_width, num_rows, nnz, t_idx, t_sid, t_remap,
       static_cast<const ElemT*>(t_w), skip_init != 0, static_cast<ElemT*>(grad), inverse_mapping,
-      Stream(stream), sample_blocks, block_row_ids, capacity_rows, capacity_overflow);
+      Stream(stream), sample_blocks, block_row_ids, capacity_rows, capacity_overflow, pad_to_capacity != 0);
 }
 }  // namespace
 
@@ -84,7 +85,7 @@ void cuembed_embedding_backward_blocked(const void* grad_y, int elem_type, int e
   cuembed_embedding_backward_bounded(grad_y, elem_type, embed_width, num_grad_embedding_rows, nnz, transpose_indices,
                                      transpose_sample_ids, transpose_remapped_indices, index_type, transpose_weights,
                                      skip_grad_init, grad_embedding, inverse_mapping, sample_blocks, block_row_ids,
-                                     0, nullptr, stream);
+                                     0, nullptr, 0, stream);
 }
 
 void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int embed_width,
@@ -94,14 +95,14 @@ void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int e
                                         const void* transpose_weights, int skip_grad_init,
                                         void* grad_embedding, void* inverse_mapping, int sample_blocks,
                                         const uint32_t* block_row_ids, int capacity_rows,
-                                        uint32_t* capacity_overflow, cuembed_stream_t stream) {
+                                        uint32_t* capacity_overflow, int pad_to_capacity, cuembed_stream_t stream) {
 #define BWD(E, I)                                                                             \
   Backward<E, I>(grad_y, embed_width, num_grad_embedding_rows, nnz,                           \
                  static_cast<const I*>(transpose_indices),                                    \
                  static_cast<const I*>(transpose_sample_ids),                                 \
                  static_cast<const I*>(transpose_remapped_indices), transpose_weights,        \
                  skip_grad_init, grad_embedding, static_cast<I*>(inverse_mapping), stream, sample_blocks, \
-                 block_row_ids, capacity_rows, capacity_overflow)
+                 block_row_ids, capacity_rows, capacity_overflow, pad_to_capacity)
   switch ((elem_type << 1) | index_type) {
     case 0: BWD(float, int32_t); break;
     case 1: BWD(float, int64_t); break;
@@ -112,6 +113,31 @@ void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int e
     default: CUEMBED_C_API_BAD_TYPE();
   }
 #undef BWD
+}
+
+void cuembed_embedding_backward_reference_sums(const void* grad_y, int elem_type, int embed_width,
+                                               int num_grad_embedding_rows, int nnz,
+                                               const void* transpose_indices, const void* transpose_sample_ids,
+                                               const void* transpose_remapped_indices, int index_type,
+                                               const void* transpose_weights, int skip_grad_init,
+                                               void* grad_embedding, void* inverse_mapping,
+                                               cuembed_stream_t stream) {
+#define BWDR(E, I)                                                                                     \
+  cuembed::EmbeddingBackwardReferenceSums<E, I>(                                                       \
+      static_cast<const E*>(grad_y), embed_width, num_grad_embedding_rows, nnz,                        \
+      static_cast<const I*>(transpose_indices), static_cast<const I*>(transpose_sample_ids),           \
+      static_cast<const I*>(transpose_remapped_indices), static_cast<const E*>(transpose_weights),     \
+      skip_grad_init != 0, static_cast<E*>(grad_embedding), static_cast<I*>(inverse_mapping), Stream(stream))
+  switch ((elem_type << 1) | index_type) {
+    case 0: BWDR(float, int32_t); break;
+    case 1: BWDR(float, int64_t); break;
+    case 2: BWDR(__half, int32_t); break;
+    case 3: BWDR(__half, int64_t); break;
+    case 4: BWDR(__hip_bfloat16, int32_t); break;
+    case 5: BWDR(__hip_bfloat16, int64_t); break;
+    default: CUEMBED_C_API_BAD_TYPE();
+  }
+#undef BWDR
 }
 
 int cuembed_recommended_sample_blocks(int elem_type, int embed_width, int batch_size, int64_t nnz) {

@@ -124,7 +124,8 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
                              const int64_t zero_rows /* ... and the rows from the last id up to here (<= 0: none) */,
                              const IndexT* run_ids, IndexT* inverse_mapping /* compressed gradient only */,
                              const int64_t sample_block_len = 0, const uint32_t* block_row_ids = nullptr,
-                             const int64_t capacity_rows = 0, uint32_t* capacity_overflow = nullptr) {
+                             const int64_t capacity_rows = 0, uint32_t* capacity_overflow = nullptr,
+                             const bool pad_to_capacity = false) {
   const DeviceShape dev = CurrentDeviceShape();
   const ScatterShape s = PlanScatter<GradT, IndexT, N>(width, nnz, split, weights != nullptr, dev);
   const dim3 block(s.lanes, s.segments_per_block, 1);
@@ -139,7 +140,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
     ZeroSharedAndTailRowsKernel<GradT, IndexT>
         <<<static_cast<unsigned>(per_launch * launches + tail_blocks), 256, 0, stream>>>(
             rows, nnz, block_len, per_launch, launch_len, launches, width, zero_rows, grad_out, pair_rows,
-            capacity_rows);
+            capacity_rows, pad_to_capacity ? run_ids : nullptr, pad_to_capacity ? inverse_mapping : nullptr);
   }
   int seg_shift = -1;
   if ((s.segment_len & (s.segment_len - 1)) == 0)
@@ -219,7 +220,11 @@ inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, 
  * and `inverse_mapping` really hold: if the device-side row count exceeds it, NOTHING is written (per launch: a
  * sample-blocked call may have written its earlier blocks) and `*capacity_overflow` (a device word the caller
  * zeroed once; may be null) is OR-ed with 1 -- a flag to read back whenever convenient instead of a silent overrun.
- * 0 = unchecked, the reference's contract.
+ * 0 = unchecked, the reference's contract.  `pad_to_capacity` (with capacity_rows > 0, a device-side count and
+ * skip_grad_init = false): the rows from the count up to the capacity are ZEROED and their inverse_mapping entries set
+ * to the batch's smallest table row, so that (inverse_mapping, grad_embedding) over all capacity_rows entries is a
+ * valid uncoalesced COO gradient -- coalescing it gives the reference's -- that a caller can hand on without ever
+ * reading the count back (the torch op does, for small batches).
  *
  * Extension: `sample_blocks` > 1 (compressed gradient only) says that the COO comes from
  * Transpose(..., sample_blocks) and transpose_remapped_indices + block_row_ids from
@@ -247,7 +252,8 @@ void EmbeddingBackward(const GradT* grad_y,
                        const int sample_blocks = 1,
                        const uint32_t* block_row_ids = nullptr,
                        const int capacity_rows = 0,
-                       uint32_t* capacity_overflow = nullptr) {
+                       uint32_t* capacity_overflow = nullptr,
+                       const bool pad_to_capacity = false) {
   static_assert(std::is_same<GradT, float>::value || std::is_same<GradT, __half>::value ||
                     std::is_same<GradT, __hip_bfloat16>::value,
                 "EmbeddingBackward: gradients must be float, __half or __hip_bfloat16");
@@ -259,6 +265,7 @@ void EmbeddingBackward(const GradT* grad_y,
   if (transpose_remapped_indices != nullptr && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
   if (transpose_remapped_indices == nullptr) CUEMBED_ASSERT(num_grad_embedding_rows >= 0);  // "unknown" is a compressed-only extension
   if (capacity_rows > 0) CUEMBED_ASSERT(transpose_remapped_indices != nullptr);            // ... and so is its capacity
+  if (pad_to_capacity) CUEMBED_ASSERT(capacity_rows > 0 && num_grad_embedding_rows < 0 && !skip_grad_init && sample_blocks <= 1);
   // Zero-initialisation.  Dense gradient: rows without lookups must read zero -> memset.
   // Compressed gradient: every row is produced by the scatter itself, so only the rows that can
   // receive atomics (and an over-allocated tail) are zeroed, by a small kernel (LaunchScatterAdd).
@@ -271,7 +278,8 @@ void EmbeddingBackward(const GradT* grad_y,
   }
   if (nnz <= 0) return;
   const bool zero_shared = !skip_grad_init && compressed;
-  const int64_t zero_rows = num_grad_embedding_rows;
+  // (padded: every row from the device-side count up to the capacity is zeroed and named, see below)
+  const int64_t zero_rows = pad_to_capacity ? capacity_rows : num_grad_embedding_rows;
   // sample-blocked order: one launch per block (the length Transpose cut the input at)
   int64_t sample_block_len = 0;
   if (sample_blocks > 1) {
@@ -292,17 +300,78 @@ void EmbeddingBackward(const GradT* grad_y,
   if (split.elems_per_lane == kMaxN)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out, split,
                                                    stream, zero_shared, zero_rows, run_ids, inverse_mapping,
-                                                   sample_block_len, block_row_ids, capacity_rows, capacity_overflow);
+                                                   sample_block_len, block_row_ids, capacity_rows, capacity_overflow,
+                                                   pad_to_capacity);
   else if (split.elems_per_lane == kMaxN / 2)
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 2>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
                                                        split, stream, zero_shared, zero_rows, run_ids, inverse_mapping,
                                                        sample_block_len, block_row_ids, capacity_rows,
-                                                       capacity_overflow);
+                                                       capacity_overflow, pad_to_capacity);
   else
     detail::LaunchScatterAdd<ElemT, IndexT, kMaxN / 4>(gy, embed_width, rows, transpose_sample_ids, w, nnz, out,
                                                        split, stream, zero_shared, zero_rows, run_ids, inverse_mapping,
                                                        sample_block_len, block_row_ids, capacity_rows,
-                                                       capacity_overflow);
+                                                       capacity_overflow, pad_to_capacity);
+}
+
+/**
+ * @brief EmbeddingBackward in the REFERENCE's arithmetic (extension, opt-in; for verification and for callers that need
+ * the reference's bits): same arguments and outputs as EmbeddingBackward, but every `grad += grad_y * weight` is done
+ * in GradT -- product and running sum rounded to GradT at every lookup, in nz order -- exactly like the CPU reference
+ * (utils/include/embedding_lookup_cpu.hpp:131-143).  Bit-identical to it for ANY data: fp16 / bf16 gradients that
+ * are not exactly representable, runs of any length.  (EmbeddingBackward keeps fp32 partial sums and rounds once per
+ * flush: identical on exactly representable data, closer to the true sum otherwise.)  A rounding chain cannot be cut
+ * into partial sums, so one run is walked by ONE lane group: slow where a row is looked up very often (the hottest row
+ * of the C4 batch: 65,528 sequential lookups).  skip_grad_init = true ADDS to what grad_embedding holds, like the
+ * reference's loop on a buffer the caller did not zero.
+ */
+template <typename GradT, typename IndexT>
+void EmbeddingBackwardReferenceSums(const GradT* grad_y,
+                                    const int embed_width,
+                                    const int num_grad_embedding_rows,
+                                    const int nnz,
+                                    const IndexT* transpose_indices,
+                                    const IndexT* transpose_sample_ids,
+                                    const IndexT* transpose_remapped_indices,
+                                    const GradT* transpose_weights,
+                                    const bool skip_grad_init,
+                                    GradT* grad_embedding,
+                                    IndexT* inverse_mapping,
+                                    const hipStream_t stream = 0) {
+  using ElemT = detail::DeviceElemT<GradT>;
+  const detail::RowSplit split = detail::SplitRow<ElemT>(embed_width, grad_y, grad_embedding);
+  const bool compressed = transpose_remapped_indices != nullptr;
+  if (compressed && nnz > 0) CUEMBED_ASSERT(inverse_mapping != nullptr);
+  CUEMBED_ASSERT(num_grad_embedding_rows >= 0);
+  // rows without lookups must read zero; rows with lookups are stored whole by the group that walks their run
+  if (!skip_grad_init && num_grad_embedding_rows > 0)
+    (void)hipMemsetAsync(grad_embedding, 0,
+                         static_cast<size_t>(num_grad_embedding_rows) * static_cast<size_t>(embed_width) * sizeof(GradT), stream);
+  if (nnz <= 0) return;
+  const IndexT* rows = compressed ? transpose_remapped_indices : transpose_indices;
+  const IndexT* run_ids = compressed ? transpose_indices : nullptr;
+  const ElemT* gy = reinterpret_cast<const ElemT*>(grad_y);
+  const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
+  ElemT* out = reinterpret_cast<ElemT*>(grad_embedding);
+  const int lanes = split.lanes_per_row;
+  const int groups = lanes >= detail::kDefaultBlockThreads ? 1 : detail::kDefaultBlockThreads / lanes;
+  const dim3 block(lanes, groups, 1);
+  const int64_t spans = (static_cast<int64_t>(nnz) + detail::kReferenceSpan - 1) / detail::kReferenceSpan;
+  const dim3 grid(static_cast<unsigned>((spans + groups - 1) / groups), 1, 1);
+  constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
+#define CUEMBED_LAUNCH_REFERENCE(NN)                                                                               \
+  do {                                                                                                             \
+    if (w != nullptr)                                                                                              \
+      detail::ReferenceSumsScatterKernel<ElemT, IndexT, NN, true><<<grid, block, 0, stream>>>(                      \
+          gy, embed_width, rows, transpose_sample_ids, w, nnz, out, skip_grad_init, run_ids, inverse_mapping);      \
+    else                                                                                                           \
+      detail::ReferenceSumsScatterKernel<ElemT, IndexT, NN, false><<<grid, block, 0, stream>>>(                     \
+          gy, embed_width, rows, transpose_sample_ids, w, nnz, out, skip_grad_init, run_ids, inverse_mapping);      \
+  } while (0)
+  if (split.elems_per_lane == kMaxN) CUEMBED_LAUNCH_REFERENCE(kMaxN);
+  else if (split.elems_per_lane == kMaxN / 2) CUEMBED_LAUNCH_REFERENCE(kMaxN / 2);
+  else CUEMBED_LAUNCH_REFERENCE(kMaxN / 4);
+#undef CUEMBED_LAUNCH_REFERENCE
 }
 
 }  // namespace cuembed

@@ -66,9 +66,10 @@ void ExtractRowIdsFromCSR(const OffsetT* offsets,
                           const hipStream_t stream = 0) {
   if (batch_size <= 0) return;
   const int threads = detail::kIndexBlockThreads;
-  const int blocks = (batch_size + detail::kCsrSamplesPerBlock - 1) / detail::kCsrSamplesPerBlock;
+  const int per_block = detail::CsrSamplesPerBlock(batch_size);
+  const int blocks = (batch_size + per_block - 1) / per_block;
   detail::ExpandCsrKernel<OffsetT, IndexT>
-      <<<blocks, threads, 0, stream>>>(offsets, batch_size, row_ids);
+      <<<blocks, threads, 0, stream>>>(offsets, batch_size, row_ids, per_block);
 }
 
 /*!

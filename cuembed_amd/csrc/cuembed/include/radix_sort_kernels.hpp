@@ -541,21 +541,6 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   bool keys_requested = false, payload_requested = false;
   constexpr int kEarlyItems = (kChained && kHasV1 && sizeof(V1) == 4) ? ITEMS : 1;
   V1 early1_out[kEarlyItems], early1_tmp[kEarlyItems];   // (kChained: a 32-bit first payload from both possible sources)
-  // kChained: this pass's per-tile counts ([tile][bin]) are added up by every workgroup itself.  Lane q of every
-  // wavefront owns bins 4 q .. 4 q + 3 (one 16-byte load per tile row), wavefront w the tiles w, w + 4, ...; the first
-  // kFoldBatch rows per wavefront (64 tiles in all) are requested HERE, before anything is waited for -- the counts came
-  // through memory-side atomics and every dependent round trip to them costs ~2 us.
-  typedef unsigned __attribute__((ext_vector_type(4))) count4_t;
-  constexpr int kFoldBatch = kChained ? 16 : 1;
-  count4_t fold_rows[kFoldBatch];
-  if constexpr (kChained) {
-    const count4_t* rows = reinterpret_cast<const count4_t*>(tile_prefix + static_cast<size_t>(pass) * num_tiles * kSortBins) + lane;
-#pragma unroll
-    for (int j = 0; j < kFoldBatch; ++j) {
-      const int t = wave + kSortWaves * j;
-      fold_rows[j] = t < num_tiles ? rows[static_cast<size_t>(t) * (kSortBins / 4)] : count4_t{0u, 0u, 0u, 0u};
-    }
-  }
   if constexpr (kChained) {
     if (pass == 0) {
       // the first pass always reads the caller's input: request it, then find out what the later passes will do
@@ -660,41 +645,17 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
     unsigned before_me, bin_sum;
     unsigned segment_start = 0;   // the tile's segment is sorted on its own: positions start at its first element
     if constexpr (kChained) {
-      __shared__ __attribute__((aligned(16))) unsigned fold_part[kSortWaves][2][kSortBins];
-      count4_t before4 = count4_t{0u, 0u, 0u, 0u}, total4 = count4_t{0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int j = 0; j < kFoldBatch; ++j) {
-        const int t = wave + kSortWaves * j;
-        if (t < tile) before4 += fold_rows[j];
-        total4 += fold_rows[j];            // (rows past num_tiles were set to zero)
-      }
-      if (num_tiles > kSortWaves * kFoldBatch) {   // more than 64 tiles: further batches of 16 rows per wavefront
-        const count4_t* rows =
-            reinterpret_cast<const count4_t*>(tile_prefix + static_cast<size_t>(pass) * num_tiles * kSortBins) + lane;
-        for (int j0 = kFoldBatch; wave + kSortWaves * j0 < num_tiles; j0 += kFoldBatch) {
-          count4_t more[kFoldBatch];
-#pragma unroll
-          for (int j = 0; j < kFoldBatch; ++j) {
-            const int t = wave + kSortWaves * (j0 + j);
-            more[j] = t < num_tiles ? rows[static_cast<size_t>(t) * (kSortBins / 4)] : count4_t{0u, 0u, 0u, 0u};
-          }
-#pragma unroll
-          for (int j = 0; j < kFoldBatch; ++j) {
-            const int t = wave + kSortWaves * (j0 + j);
-            if (t < tile) before4 += more[j];
-            total4 += more[j];
-          }
-        }
-      }
-      *reinterpret_cast<count4_t*>(&fold_part[wave][0][4 * lane]) = before4;
-      *reinterpret_cast<count4_t*>(&fold_part[wave][1][4 * lane]) = total4;
-      __syncthreads();
+      // thread `bin` adds up this pass's counts of its bin over the tiles ([tile][bin]: a coalesced row per tile, 8
+      // rows in flight).  (Four bins per lane with 16-byte loads, the tiles split over the wavefronts and the first
+      // batch requested before anything else, was built and measured: the same from 64 tiles up, 10 % slower at 16.)
+      const unsigned* counts = tile_prefix + static_cast<size_t>(pass) * num_tiles * kSortBins + tid;
       before_me = 0;
       bin_sum = 0;
-#pragma unroll
-      for (int w = 0; w < kSortWaves; ++w) {
-        before_me += fold_part[w][0][tid];
-        bin_sum += fold_part[w][1][tid];
+#pragma unroll 8
+      for (int t = 0; t < num_tiles; ++t) {
+        const unsigned c = counts[static_cast<size_t>(t) * kSortBins];
+        if (t < tile) before_me += c;
+        bin_sum += c;
       }
     } else if (bin_total != nullptr) {
       const int segment = tile / segment_tiles;
@@ -1147,11 +1108,11 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
   }
 }
 
-//! The run-head scan of 5 .. kWideSelfCountTiles tiles (up to 131,072 elements) in ONE launch: 1024-thread workgroups,
+//! The run-head scan of 5 .. kWideSelfCountTiles tiles (up to 65,536 elements) in ONE launch: 1024-thread workgroups,
 //! one per 4096-element tile; every workgroup counts the run heads before its tile itself, four times as many lanes
-//! sharing that work as in RunHeadScanKernel (at most two batches of 16 loads per lane: ~4 us for the last tile,
-//! against ~9 us for the count launch + the scan launch).  kIds output only.
-constexpr int kWideSelfCountTiles = 32;
+//! sharing that work as in RunHeadScanKernel (measured: 4.7 us at 8 tiles and 7.1 at 16 against 8.8 for the count
+//! launch + the scan launch; 9.2 at 32 tiles, hence the limit).  kIds output only.
+constexpr int kWideSelfCountTiles = 16;
 constexpr int kWideScanThreads = 1024;
 
 template <typename IndexT>
@@ -1227,7 +1188,8 @@ inline void RunHeadScanLaunch(const IndexT* indices, const size_t n, IndexT* rem
     return;
   }
   if constexpr (kOut == RunHeadOutput::kIds) {
-    if (tiles <= kWideSelfCountTiles && block_tiles == 0) {   // still one launch, on four times the lanes
+    // still one launch, on four times the lanes (64-bit elements: half as many per 16-byte load, half the range)
+    if (tiles <= kWideSelfCountTiles / static_cast<int>(sizeof(IndexT) / 4) && block_tiles == 0) {
       RunHeadScanWideKernel<IndexT><<<tiles, kWideScanThreads, 0, stream>>>(indices, static_cast<int64_t>(n), remapped);
       return;
     }

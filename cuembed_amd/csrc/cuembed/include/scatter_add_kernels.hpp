@@ -573,7 +573,9 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
                             const int64_t blocks_per_sample_block, const int64_t sample_block_len,
                             const int sample_blocks, const int width, const int64_t num_rows,
                             GradT* __restrict__ grad_out, const uint32_t* __restrict__ block_row_ids,
-                            const int64_t capacity_rows) {
+                            const int64_t capacity_rows,
+                            const IndexT* __restrict__ pad_ids /* not null: table row ids (sorted); the tail of ... */,
+                            IndexT* __restrict__ pad_inverse_mapping /* ... this array is filled with pad_ids[0] */) {
   // sample-blocked order: `rows` holds pair numbers, block_row_ids[pair] the gradient row | kSharedRowBit
   auto row_of = [&](const int64_t g) -> int64_t {
     const uint32_t r = static_cast<uint32_t>(rows[g]);
@@ -610,6 +612,14 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
   char* const p0 = reinterpret_cast<char*>(grad_out + (last_id + 1) * width);
   char* const p1 = reinterpret_cast<char*>(grad_out + num_rows * width);
   if (p0 >= p1) return;
+  if (pad_ids != nullptr) {
+    // padded gradient: the rows past the last id are zero and name a row that IS in the batch (its smallest), so that
+    // (inverse_mapping, grad_out) is a valid uncoalesced COO gradient over ALL num_rows entries
+    const IndexT first_row = pad_ids[0];
+    const int64_t tail_workers = (static_cast<int64_t>(gridDim.x) - num_blocks) * blockDim.x;
+    for (int64_t i = last_id + 1 + (b - num_blocks) * blockDim.x + threadIdx.x; i < num_rows; i += tail_workers)
+      pad_inverse_mapping[i] = first_row;
+  }
   char* a0 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p0) + 15) & ~uintptr_t{15});
   char* a1 = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(p1) & ~uintptr_t{15});
   if (a0 > p1) a0 = p1;
@@ -622,6 +632,78 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
   if (worker == 0) {
     for (char* p = p0; p < a0; p += sizeof(GradT)) *reinterpret_cast<GradT*>(p) = static_cast<GradT>(0);
     for (char* p = a1; p < p1; p += sizeof(GradT)) *reinterpret_cast<GradT*>(p) = static_cast<GradT>(0);
+  }
+}
+
+//! EmbeddingBackward in the REFERENCE's arithmetic (EmbeddingBackwardReferenceSums; opt-in, for verification): one
+//! lane group per run of equal row ids walks the run in nz order with the product and the running sum rounded to
+//! GradT at every lookup -- `grad += grad_y * weight` in GradT, the CPU reference's loop
+//! (embedding_lookup_cpu.hpp:131-143) -- so the result is bit-identical to it for ANY data.  A rounding chain cannot be
+//! cut into partial sums, hence one run = one lane group whatever its length: the hottest row of the C4 batch (65,528
+//! lookups) is walked by a single group.  8 row gathers in flight per group.
+//!   block = (lanes_per_row, groups); every group looks at kReferenceSpan consecutive lookups and walks the runs that
+//!   START there.
+constexpr int kReferenceSpan = 8;
+
+template <typename GradT, typename IndexT, int N, bool kWeighted>
+__global__ void __launch_bounds__(kMaxBlockThreads)
+ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, const IndexT* __restrict__ rows,
+                           const IndexT* __restrict__ sample_ids, const GradT* __restrict__ weights, const int64_t nnz,
+                           GradT* __restrict__ grad_out, const bool add_to_output,
+                           const IndexT* __restrict__ run_ids, IndexT* __restrict__ inverse_mapping) {
+  const int lane_x = threadIdx.x;
+  const int64_t group = static_cast<int64_t>(blockIdx.x) * blockDim.y + threadIdx.y;
+  const int64_t column0 = static_cast<int64_t>(lane_x) * N;
+  typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
+  constexpr int K = 8;
+  for (int64_t p = group * kReferenceSpan; p < (group + 1) * kReferenceSpan && p < nnz; ++p) {
+    const IndexT row = rows[p];
+    if (p > 0 && rows[p - 1] == row) continue;   // not the first lookup of its run
+    if (run_ids != nullptr && lane_x == 0) inverse_mapping[row] = run_ids[p];
+    GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
+    float acc[N];
+    if (add_to_output) {
+      const Pack<GradT, N> was = *reinterpret_cast<const Pack<GradT, N>*>(dst);
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = static_cast<float>(was.v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    }
+    for (int64_t q = p; q < nnz;) {
+      // the next K lookups of the run (fewer at its end): all gathers requested, then added in order
+      int count = 0;
+      raw_t g[K];
+      GradT w[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const bool mine = count == j && q + j < nnz && rows[q + j] == row;
+        if (mine) {
+          ++count;
+          g[j] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(sample_ids[q + j]), width));
+          if constexpr (kWeighted) w[j] = weights[q + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (j < count) {
+          const Pack<GradT, N> row_j = __builtin_bit_cast(Pack<GradT, N>, g[j]);
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+#pragma clang fp contract(off)
+            float x = static_cast<float>(row_j.v[e]);
+            if constexpr (kWeighted) x = static_cast<float>(static_cast<GradT>(x * static_cast<float>(w[j])));   // product in GradT
+            acc[e] = static_cast<float>(static_cast<GradT>(acc[e] + x));                                           // sum in GradT
+          }
+        }
+      }
+      if (count < K) break;
+      q += K;
+    }
+    Pack<GradT, N> result;
+#pragma unroll
+    for (int e = 0; e < N; ++e) result.v[e] = static_cast<GradT>(acc[e]);
+    *reinterpret_cast<Pack<GradT, N>*>(dst) = result;
   }
 }
 

@@ -416,8 +416,15 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> cuembed_transpose_fix
 // to Python, and for a sparse gradient the row count is read back AFTER everything is enqueued (the scatter runs into
 // buffers of capacity min(nnz, rows) under cuembed_embedding_backward_bounded and the result is narrowed to
 // num_unique rows), so the host waits for the device once, at the end, instead of stalling the pipeline in the middle.
-// Above kCapacityBytes of worst-case gradient the count is read back first, as before (2.1 GB at the C4 shape).
+// Above kCapacityBytes of worst-case gradient the count is read back first, as before (2.1 GB at the C4 shape; there
+// the device is the bottleneck, not the host: running the scatter into 5/4 of the table's LAST row count under the
+// capacity check and reading the count at the end was built and measured 0.53-0.63 ms against 0.49 -- 435 MB
+// allocations of changing size churn the caching allocator).
 constexpr int64_t kCapacityBytes = int64_t{192} << 20;
+// Up to this much worst-case gradient the "fastest order" kinds do not read the count back AT ALL: the gradient is
+// handed on padded to min(nnz, rows) entries (zero rows that name a row of the batch: an uncoalesced COO tensor of the
+// same value), so the host never waits for the device inside a step -- at B = 1024 the wait was a third of the step.
+constexpr int64_t kPaddedBytes = int64_t{64} << 20;
 
 enum GradKind : int64_t { kGradDense = 0, kGradSparseAuto = 1, kGradSparseReference = 2, kGradSparseUncoalesced = 3 };
 
@@ -524,25 +531,42 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     const int64_t row_bytes = width * static_cast<int64_t>(out_grad.element_size());
     at::Tensor rows, inv;
     int64_t num_unique = -1;
-    if (capacity * row_bytes <= kCapacityBytes) {
-      // everything is enqueued before the host looks at the device: rows for the worst case, narrowed afterwards
-      rows = at::empty({capacity, width}, out_grad.options());
-      inv = at::empty({capacity}, nw.idx.options());
-      ::cuembed_embedding_backward_bounded(Ptr(out_grad), elem, static_cast<int>(width), -1, static_cast<int>(nnz),
-                                           Ptr(t.t_idx), Ptr(t.t_sid), Ptr(t.remap), idx, Ptr(t.t_w), /*skip_grad_init=*/0,
-                                           MutPtr(rows), MutPtr(inv), 1, nullptr, static_cast<int>(capacity), nullptr, stream);
-      at::Tensor inv64 = inv.scalar_type() == at::kLong ? inv : inv.to(at::kLong);
-      num_unique = t.remap.narrow(0, nnz - 1, 1).item().toLong() + 1;   // (the one wait of the step)
-      rows = rows.narrow(0, 0, num_unique);
-      inv = inv64.narrow(0, 0, num_unique);
-    } else {
-      num_unique = t.remap.narrow(0, nnz - 1, 1).item().toLong() + 1;
+    const int64_t room = capacity * row_bytes <= kCapacityBytes ? capacity : 0;   // rows the scatter may write blind
+    const auto exact_backward = [&]() {
       rows = at::empty({num_unique, width}, out_grad.options());
       inv = at::empty({num_unique}, nw.idx.options());
       ::cuembed_embedding_backward(Ptr(out_grad), elem, static_cast<int>(width), static_cast<int>(num_unique),
                                    static_cast<int>(nnz), Ptr(t.t_idx), Ptr(t.t_sid), Ptr(t.remap), idx, Ptr(t.t_w),
                                    /*skip_grad_init=*/0, MutPtr(rows), MutPtr(inv), stream);
       if (inv.scalar_type() != at::kLong) inv = inv.to(at::kLong);
+    };
+    const bool padded = grad_kind != kGradSparseReference && one_block && room > 0 && room * row_bytes <= kPaddedBytes;
+    if (padded) {
+      rows = at::empty({room, width}, out_grad.options());
+      inv = at::empty({room}, nw.idx.options());
+      ::cuembed_embedding_backward_bounded(Ptr(out_grad), elem, static_cast<int>(width), -1, static_cast<int>(nnz),
+                                           Ptr(t.t_idx), Ptr(t.t_sid), Ptr(t.remap), idx, Ptr(t.t_w), /*skip_grad_init=*/0,
+                                           MutPtr(rows), MutPtr(inv), 1, nullptr, static_cast<int>(room), nullptr,
+                                           /*pad_to_capacity=*/1, stream);
+      if (inv.scalar_type() != at::kLong) inv = inv.to(at::kLong);
+      grads[0] = at::_sparse_coo_tensor_unsafe(inv.unsqueeze(0), rows, {num_categories, width},
+                                               out_grad.options().layout(at::kSparse), /*is_coalesced=*/false);
+      return grads;
+    }
+    if (room > 0) {
+      // everything is enqueued before the host looks at the device: rows for `room`, narrowed afterwards
+      rows = at::empty({room, width}, out_grad.options());
+      inv = at::empty({room}, nw.idx.options());
+      ::cuembed_embedding_backward_bounded(Ptr(out_grad), elem, static_cast<int>(width), -1, static_cast<int>(nnz),
+                                           Ptr(t.t_idx), Ptr(t.t_sid), Ptr(t.remap), idx, Ptr(t.t_w), /*skip_grad_init=*/0,
+                                           MutPtr(rows), MutPtr(inv), 1, nullptr, static_cast<int>(room), nullptr, 0, stream);
+      at::Tensor inv64 = inv.scalar_type() == at::kLong ? inv : inv.to(at::kLong);
+      num_unique = t.remap.narrow(0, nnz - 1, 1).item().toLong() + 1;   // (the one wait of the step)
+      rows = rows.narrow(0, 0, num_unique);
+      inv = inv64.narrow(0, 0, num_unique);
+    } else {
+      num_unique = t.remap.narrow(0, nnz - 1, 1).item().toLong() + 1;
+      exact_backward();
     }
     grads[0] = at::_sparse_coo_tensor_unsafe(inv.unsqueeze(0), rows, {num_categories, width},
                                              out_grad.options().layout(at::kSparse), /*is_coalesced=*/one_block);

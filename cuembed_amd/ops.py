@@ -268,7 +268,7 @@ def get_backward_tuning():
 def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, transpose_sample_ids,
                        transpose_remapped_indices=None, transpose_weights=None,
                        skip_grad_init=False, grad_embedding=None, inverse_mapping=None, sample_blocks=1,
-                       block_row_ids=None):
+                       block_row_ids=None, reference_sums=False, pad_to_capacity=False):
     """Scatter-add grad_y rows into the table gradient from index-sorted COO lookups.
 
     Full gradient: transpose_remapped_indices=None, num_grad_embedding_rows = table rows.
@@ -288,7 +288,16 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
     (transpose_remapped_indices, block_row_ids) come from compute_compressed_grad_indices_blocked(...,
     sample_blocks): the blocks are scattered one after the other (every L2 gathers from 1 / sample_blocks of
     grad_y at a time) and the result has the reference's layout: num_unique ascending rows, the fully sorted
-    order's inverse_mapping."""
+    order's inverse_mapping.
+
+    pad_to_capacity=True (with num_grad_embedding_rows=None, one block, skip_grad_init=False): the rows from the
+    device-side count up to the buffers' row count are zeroed and their inverse_mapping entries name the batch's
+    smallest table row -- (inverse_mapping, grad_embedding) as a whole is then a valid uncoalesced COO gradient whose
+    row count never has to be read back.
+
+    Extension: reference_sums=True computes every `grad += grad_y * weight` in the gradient's own type, lookup by
+    lookup in nz order, like the CPU reference (cuembed::EmbeddingBackwardReferenceSums): bit-identical to it for any
+    fp16 / bf16 / fp32 data, slow for rows that are looked up very often.  Host-known row count, one block."""
     _check_dev("grad_y", grad_y)
     dev = grad_y.device
     if grad_y.dim() != 2:
@@ -351,15 +360,27 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
             raise TypeError("block_row_ids must be int32 (uint32 bit patterns)")
     else:
         block_row_ids = None
+    if reference_sums:
+        if unknown_rows or sample_blocks > 1:
+            raise ValueError("reference_sums needs a host-known row count and a fully sorted order")
+        with torch.cuda.device(grad_y.device):
+            _lib.lib().cuembed_embedding_backward_reference_sums(
+                _ptr(grad_y), et, width, num_grad_embedding_rows, nnz, _ptr(transpose_indices), _ptr(transpose_sample_ids),
+                _ptr(transpose_remapped_indices), it, _ptr(transpose_weights), int(bool(skip_grad_init)),
+                _ptr(grad_embedding), _ptr(inverse_mapping), _stream(grad_y))
+        return grad_embedding, inverse_mapping
     # num_unique on the device only: the buffers' row count is the capacity the kernels check against -- too small,
     # and nothing is written and the device's sticky overflow word is raised (capacity_overflowed()) -- never an overrun
     capacity = min(grad_embedding.shape[0], inverse_mapping.numel()) if unknown_rows else 0
+    if pad_to_capacity and (not unknown_rows or skip_grad_init or sample_blocks > 1):
+        raise ValueError("pad_to_capacity needs num_grad_embedding_rows=None, skip_grad_init=False and one block")
     with torch.cuda.device(grad_y.device):   # the launch must happen on the tensors' device
         _lib.lib().cuembed_embedding_backward_bounded(
             _ptr(grad_y), et, width, -1 if unknown_rows else num_grad_embedding_rows, nnz, _ptr(transpose_indices),
             _ptr(transpose_sample_ids), _ptr(transpose_remapped_indices), it, _ptr(transpose_weights),
             int(bool(skip_grad_init)), _ptr(grad_embedding), _ptr(inverse_mapping), int(sample_blocks),
-            _ptr(block_row_ids), int(capacity), _ptr(_overflow_word(dev)) if unknown_rows else None, _stream(grad_y))
+            _ptr(block_row_ids), int(capacity), _ptr(_overflow_word(dev)) if unknown_rows else None,
+            int(bool(pad_to_capacity)), _stream(grad_y))
     return grad_embedding, inverse_mapping
 
 

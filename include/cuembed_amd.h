@@ -192,6 +192,19 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
                                 const void* transpose_weights, int skip_grad_init,
                                 void* grad_embedding, void* inverse_mapping,
                                 cuembed_stream_t stream);
+/* Extension (cuembed::EmbeddingBackwardReferenceSums; opt-in, for verification): cuembed_embedding_backward in the
+ * REFERENCE's arithmetic -- product and running sum rounded to the gradient type at every lookup, in nz order, as the
+ * CPU reference's loop does (embedding_lookup_cpu.hpp:131-143) -- and therefore bit-identical to it for ANY data
+ * (fp16 / bf16 gradients that are not exactly representable, runs of any length), where the default entry points
+ * keep fp32 partial sums (ARITHMETIC note above).  One lane group walks a whole run: slow for rows that are looked up
+ * very often.  num_grad_embedding_rows >= 0; skip_grad_init != 0 adds to what grad_embedding holds. */
+void cuembed_embedding_backward_reference_sums(const void* grad_y, int elem_type, int embed_width,
+                                               int num_grad_embedding_rows, int nnz,
+                                               const void* transpose_indices, const void* transpose_sample_ids,
+                                               const void* transpose_remapped_indices, int index_type,
+                                               const void* transpose_weights, int skip_grad_init,
+                                               void* grad_embedding, void* inverse_mapping,
+                                               cuembed_stream_t stream);
 void cuembed_transpose(const void* rows, const void* cols, const void* weights, int nnz,
                        int index_type, int weight_type, void* transpose_rows,
                        void* transpose_cols, void* transpose_weights, char* work, size_t* lwork,
@@ -297,7 +310,11 @@ void cuembed_embedding_backward_blocked(const void* grad_y, int elem_type, int e
  * the compressed gradient has; capacity_rows > 0 states how many rows grad_embedding and inverse_mapping really hold.
  * If the count exceeds it, nothing is written (per launch: a sample-blocked call may have written its earlier blocks)
  * and *capacity_overflow -- a device word the caller zeroed once; may be NULL -- is OR-ed with 1: a sticky flag to read
- * back whenever convenient instead of a silent overrun.  capacity_rows = 0: unchecked (the other entry points). */
+ * back whenever convenient instead of a silent overrun.  capacity_rows = 0: unchecked (the other entry points).
+ * pad_to_capacity != 0 (needs capacity_rows > 0, num_grad_embedding_rows < 0, skip_grad_init == 0, one block): the
+ * rows from the device-side count up to capacity_rows are zeroed and their inverse_mapping entries set to the batch's
+ * smallest table row -- (inverse_mapping, grad_embedding) over all capacity_rows entries is then a valid uncoalesced
+ * COO gradient (coalescing it gives the reference's) that needs no read-back of the count at all. */
 void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int embed_width,
                                         int num_grad_embedding_rows, int nnz,
                                         const void* transpose_indices, const void* transpose_sample_ids,
@@ -305,7 +322,7 @@ void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int e
                                         const void* transpose_weights, int skip_grad_init,
                                         void* grad_embedding, void* inverse_mapping, int sample_blocks,
                                         const uint32_t* block_row_ids, int capacity_rows,
-                                        uint32_t* capacity_overflow, cuembed_stream_t stream);
+                                        uint32_t* capacity_overflow, int pad_to_capacity, cuembed_stream_t stream);
 void cuembed_extract_row_ids_from_fixed(int batch_size, int num_hots, int index_type,
                                         void* row_ids, cuembed_stream_t stream);
 void cuembed_extract_row_ids_from_csr(const void* offsets, int offset_type, int batch_size,

@@ -43,7 +43,9 @@ def test_roofline_entries_are_fractions():
                          "transpose_and_remap_ms": 0.129,
                          # the C3 forward as the driver's line carries it (algorithmic bytes ABOVE the measured traffic)
                          "c3_forward": {"ms": 0.1716, "algorithmic_bytes": 2184951808, "nnz": 4201805,
-                                        "compulsory_bytes": 386000000}}}
+                                        "compulsory_bytes": 386000000},
+                         "transpose_and_remap_small_shapes": {
+                             "1024x16": {"pairs": 16384, "reference_sequence_ms": 0.038, "one_call_ms": 0.034}}}}
     bench.finish_roofline(result, traffic, cfg)
     rl = result["roofline"]
     comp = rl["hbm_bound_companion"]
@@ -55,6 +57,9 @@ def test_roofline_entries_are_fractions():
     for o in rl["other_kernels"]:
         assert 0.0 < o["traffic_frac"] <= 1.0 and o["peak"] == bench.HBM_PEAK_GBPS
         assert 0.0 < o["frac"] <= 1.0 and o["frac"] <= o["traffic_frac"] + 1e-9   # EVERY `frac` is a fraction
+        if o["traffic"] is None:            # the small-shape index work: no counter pass, launch-latency bound
+            assert "16,384 pairs" in o["kernel"] and o["one_call_ms"] > 0 and o["frac"] == o["algorithmic_frac"]
+            continue
         if "C3" in o["kernel"]:
             # a gather with re-use: the formula's bytes exceed what the fabric carried, so `frac` follows the headline's
             # convention (measured traffic) and the algorithmic figure stays beside it

@@ -182,3 +182,42 @@ def test_fp32_gradients_random_data_within_1e3(ce, oracle):
         scale = np.zeros((ncat, W))
         np.add.at(scale, ti.astype(np.int64), terms)
         assert np.all(np.abs(got.cpu().numpy().astype(np.float64) - want) <= 1e-5 * scale + 1e-30)
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("weighted", [False, True], ids=["unweighted", "weighted"])
+@pytest.mark.parametrize("compressed", [False, True], ids=["full", "compressed"])
+def test_reference_sums_opt_in_is_bit_identical_on_arbitrary_data(ce, oracle, kind, weighted, compressed):
+    """embedding_backward(..., reference_sums=True) = cuembed::EmbeddingBackwardReferenceSums: product and running sum
+    rounded to GradT at every lookup, in nz order, like the CPU reference (embedding_lookup_cpu.hpp:131-143).  On the
+    data of the tolerance tests above -- uniform(-1, 1) gradients, uniform(0, 1) weights, NOT exactly representable,
+    short runs, power-law runs and one run of 3,000 lookups -- the result must equal the oracle's BIT FOR BIT, for both
+    index types, with and without a buffer the caller pre-filled (skip_grad_init adds to it, as the reference's loop does)."""
+    rng = np.random.default_rng(14)
+    for ncat, W, B, H, alpha, long_run in ((20 * 1024, 64, 1023, 26, 0.0, 0), (4000, 40, 3100, 6, 1.15, 3000)):
+        ti, ts, tw32, gy32 = _case(oracle, rng, ncat, W, B, H, alpha=alpha, long_run=long_run)
+        if kind == "f32":
+            gy_o, gy_d = gy32, dev(gy32)
+            w_o, w_d = (tw32, dev(tw32)) if weighted else (None, None)
+        else:
+            gy_o, gy_d, _ = _to_elem(oracle, gy32, kind)
+            w_o, w_d = (None, None)
+            if weighted:
+                w_o, w_d, _ = _to_elem(oracle, tw32, kind)
+        remap = oracle.compute_compressed_grad_indices(ti) if compressed else None
+        rows = int(remap[-1]) + 1 if compressed else ncat
+        want, want_inv = oracle.embedding_backward(gy_o, W, rows, ti, ts, remap, w_o)
+        for idx_t in (np.int32, np.int64):
+            cast = lambda a: None if a is None else dev(a.astype(idx_t))
+            got, inv = ce.embedding_backward(gy_d, rows, cast(ti), cast(ts), cast(remap), w_d, reference_sums=True)
+            got_h = got.cpu().numpy() if kind == "f32" else _host(got, kind)
+            assert np.array_equal(got_h.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)), (kind, ncat, idx_t)
+            if compressed:
+                assert np.array_equal(inv.cpu().numpy(), want_inv.astype(idx_t))
+        # a pre-filled buffer: the reference's loop adds to what is there
+        if kind == "f16" and not compressed:
+            start = rng.uniform(-1, 1, (rows, W)).astype(np.float16)
+            want2, _ = oracle.embedding_backward(gy_o, W, rows, ti, ts, None, w_o, skip_grad_init=True, grad_embedding=start.copy())
+            got2, _ = ce.embedding_backward(gy_d, rows, dev(ti), dev(ts), None, w_d, skip_grad_init=True,
+                                            grad_embedding=dev(start), reference_sums=True)
+            assert np.array_equal(got2.cpu().numpy().view(np.uint16), want2.view(np.uint16))

@@ -179,12 +179,20 @@ def test_sparse_gradient_extension(pyt, weighted):
     up = torch.randn(B, d, device="cuda")
     weight = bag.weight
     weight.grad = None
-    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=True) * up).sum().backward()
+    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad="reference") * up).sum().backward()
     g_sparse = weight.grad
     assert g_sparse.is_sparse
     assert g_sparse._nnz() == torch.unique(indices).numel()        # one entry per looked-up row
     ids = g_sparse._indices()[0]
     assert (ids[1:] > ids[:-1]).all()                                # ascending, no duplicates
+    # sparse_grad=True = the fastest form for the shape: at this size the row count is never read back and the tensor is
+    # padded to min(nnz, rows) entries (zero rows naming a row of the batch) -- the same gradient once coalesced
+    weight.grad = None
+    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=True) * up).sum().backward()
+    g_fast = weight.grad
+    assert g_fast.is_sparse and not g_fast.is_coalesced() and g_fast._nnz() == min(n, k)
+    merged = g_fast.coalesce()
+    assert torch.equal(merged._indices(), g_sparse._indices()) and torch.equal(merged._values(), g_sparse._values())
     weight.grad = None
     (pyt.cuemb_embedding(weight, indices, offsets, w) * up).sum().backward()
     g_dense = weight.grad.clone()
@@ -308,7 +316,9 @@ def test_native_autograd_node_equals_the_python_function(pyt, kind, idx_dtype):
         for weighted in (False, True):
             w = torch.rand(n, device="cuda") if weighted else None
             table = torch.randn(k, d, device="cuda")
-            up = torch.randn(d, B, device="cuda").t()           # non-contiguous
+            up = torch.randint(-3, 4, (d, B), device="cuda").float().t()      # non-contiguous; integers: exact sums
+            if weighted:
+                w = torch.randint(1, 4, (n,), device="cuda").float() * 0.25
             t1 = table.clone().requires_grad_(True)
             y1 = pyt.cuemb_embedding(t1, indices, offsets, w, sparse_grad=kind, hints=None)
             assert "CuEmbEmbeddingNode" in y1.grad_fn.name()
@@ -320,14 +330,41 @@ def test_native_autograd_node_equals_the_python_function(pyt, kind, idx_dtype):
             if kind is False:
                 assert torch.equal(t1.grad, t2.grad)
             else:
-                assert t1.grad.is_sparse and t1.grad._nnz() == torch.unique(indices).numel()
-                ids = t1.grad._indices()[0]
+                g1 = t1.grad
+                if kind is True:      # small batches: padded instead of read back (see test_sparse_gradient_extension)
+                    assert g1.is_sparse and g1._nnz() == min(n, k)
+                    g1 = g1.coalesce()
+                assert g1.is_sparse and g1._nnz() == torch.unique(indices).numel()
+                ids = g1._indices()[0]
                 assert bool((ids[1:] > ids[:-1]).all())                       # one block: ascending, no duplicates
-                assert torch.equal(t1.grad._indices(), t2.grad._indices())
-                assert torch.equal(t1.grad._values(), t2.grad._values())
+                assert torch.equal(g1._indices(), t2.grad._indices())
+                assert torch.equal(g1._values(), t2.grad._values())
     # frozen table: no node, no gradient
     y = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad=kind)
     assert y.grad_fn is None
+
+
+def test_native_node_large_and_small_gradients_in_turn(pyt):
+    """The native node reads the row count back first above 192 MB of worst-case gradient, enqueues everything and
+    narrows afterwards below that ("reference") or pads and never reads it back below 64 MB (True): batches with few and
+    with many distinct rows in turn, on all three paths."""
+    torch.manual_seed(9)
+    k, d, H = 300_000, 256, 50                               # 1 KiB rows
+    table = torch.randn(k, d, device="cuda")
+    for B, kind in ((4096, True), (2048, "reference"), (1024, True)):   # 200 MB / 100 MB / 50 MB worst case
+        offsets = torch.arange(0, B * H + 1, H, device="cuda")
+        up = torch.randint(-3, 4, (B, d), device="cuda").float()     # integers: sums are exact in any order of the atomics
+        narrow = torch.randint(0, 1000, (B * H,), device="cuda")
+        wide = torch.randint(0, k, (B * H,), device="cuda")
+        t = table.clone().requires_grad_(True)
+        for step, indices in enumerate((narrow, wide, narrow)):
+            t.grad = None
+            pyt.cuemb_embedding(t, indices, offsets, None, sparse_grad=kind, hints=None).backward(up)
+            got = t.grad.coalesce() if B == 1024 else t.grad
+            t2 = table.clone().requires_grad_(True)
+            pyt._CuEmbEmbedding.apply(t2, indices, offsets, None, "reference", None).backward(up)
+            assert got._nnz() == t2.grad._nnz() == torch.unique(indices).numel(), (B, step)
+            assert torch.equal(got._indices(), t2.grad._indices()) and torch.equal(got._values(), t2.grad._values()), (B, step)
 
 
 def test_policy_hints_never_change_a_result(pyt):

@@ -5,14 +5,20 @@
 // judged against for narrow rows (10M x 32 fp32, alpha = 0 reaches 0.49-0.58 of the HBM peak against
 // 0.72 for 512-byte rows -- is that DRAM or the kernel?).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/row_read_ceiling.hip -o tools/row_read_ceiling
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I cuembed_amd/csrc tools/row_read_ceiling.hip \
+//         cuembed_amd/csrc/utils/synthetic_inputs.cpp -o tools/row_read_ceiling
 //   tools/row_read_ceiling            (prints one line per row size x loads in flight x load policy)
+//   tools/row_read_ceiling --c2 [alpha]   the HEADLINE's access pattern with loads only: 10M x 512-byte rows, batches of
+//                                     65,536 samples x 64 lookups from the reference's generator (alpha 1.15), two samples
+//                                     per wavefront walking their lookups in order, K in flight -- what EmbeddingForward's
+//                                     0.137 ms would be if pooling, index staging and the output row cost nothing.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #define HIP_OK(x)                                                                                   \
@@ -56,6 +62,82 @@ __global__ void __launch_bounds__(256) GatherRowsKernel(const char* __restrict__
   if (folded == 0x12345678u) sink[0] = folded;   // (practically never: keeps the loads)
 }
 
+// The forward's launch shape with loads only: the half-wavefront `sub` of wavefront w walks the lookups of sample
+// 2 w + sub in order, K rows in flight (32 lanes x 16 bytes = one 512-byte row per load instruction and half-wavefront).
+template <int K, bool kNonTemporal>
+__global__ void __launch_bounds__(256) GatherSamplesKernel(const char* __restrict__ table, const int* __restrict__ lookups,
+                                                           const int batch, const int hotness, unsigned* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 5, part = lane & 31;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t sample = wave * 2 + sub;
+  if (sample >= batch) return;
+  const int* mine = lookups + sample * hotness;
+  word4_t acc = word4_t{0u, 0u, 0u, 0u};
+  for (int j = 0; j + K <= hotness; j += K) {
+    word4_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const word4_t* p = reinterpret_cast<const word4_t*>(table + static_cast<int64_t>(mine[j + k]) * 512 + part * 16);
+      v[k] = kNonTemporal ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc ^= v[k];
+  }
+  const unsigned folded = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (folded == 0x12345678u) sink[0] = folded;
+}
+
+extern "C" int64_t cuembed_harness_generate_indices(int64_t num_categories, int batch, int hotness, double alpha,
+                                                    int shuffle, int permute, int index_is_64, const int32_t* offsets,
+                                                    void* out);
+
+template <int K, bool kNt>
+double RunSamples(const char* table, const int* lookups, int batches, int batch, int hotness, unsigned* sink) {
+  hipEvent_t a, z;
+  HIP_OK(hipEventCreate(&a));
+  HIP_OK(hipEventCreate(&z));
+  const int grid = (batch / 2 + 3) / 4;
+  const int64_t per_batch = static_cast<int64_t>(batch) * hotness;
+  for (int t = 0; t < 5; ++t)
+    GatherSamplesKernel<K, kNt><<<grid, 256>>>(table, lookups + (t % batches) * per_batch, batch, hotness, sink);
+  HIP_OK(hipEventRecord(a));
+  const int iters = 40;
+  for (int t = 0; t < iters; ++t)
+    GatherSamplesKernel<K, kNt><<<grid, 256>>>(table, lookups + (t % batches) * per_batch, batch, hotness, sink);
+  HIP_OK(hipEventRecord(z));
+  HIP_OK(hipEventSynchronize(z));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, a, z));
+  return ms / iters;
+}
+
+int HeadlinePattern(const double alpha) {
+  const int64_t rows = 10000000;
+  const int batch = 65536, hotness = 64, batches = 4;
+  char* table = nullptr;
+  int* lookups = nullptr;
+  unsigned* sink = nullptr;
+  HIP_OK(hipMalloc(&table, rows * 512));
+  HIP_OK(hipMemset(table, 1, rows * 512));
+  std::vector<int> h(static_cast<size_t>(batches) * batch * hotness);
+  cuembed_harness_generate_indices(rows, batches * batch, hotness, alpha, 1, 1, 0, nullptr, h.data());
+  HIP_OK(hipMalloc(&lookups, h.size() * sizeof(int)));
+  HIP_OK(hipMemcpy(lookups, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&sink, 64));
+  const double row_bytes = static_cast<double>(batch) * hotness * 512;
+  std::printf("pattern,alpha,loads_in_flight,policy,ms_per_batch,row_GBps\n");
+#define ROWS(K, NT)                                                                                          \
+  {                                                                                                          \
+    const double ms = RunSamples<K, NT>(table, lookups, batches, batch, hotness, sink);                      \
+    std::printf("c2_samples,%.2f,%d,%s,%.4f,%.0f\n", alpha, K, NT ? "nt" : "default", ms, row_bytes / ms / 1e6); \
+  }
+  ROWS(4, false) ROWS(8, false) ROWS(16, false) ROWS(32, false) ROWS(8, true) ROWS(16, true)
+#undef ROWS
+  std::fflush(stdout);
+  return 0;
+}
+
 template <int K, bool kNt>
 double Run(const char* table, int row_bytes, const int* lookups, int64_t n, unsigned* sink, int grid) {
   hipEvent_t a, z;
@@ -72,7 +154,8 @@ double Run(const char* table, int row_bytes, const int* lookups, int64_t n, unsi
   return ms / iters;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "--c2") return HeadlinePattern(argc > 2 ? std::atof(argv[2]) : 1.15);
   const int64_t table_bytes = int64_t{5} << 30;       // 5 GiB: far beyond L2 (32 MiB) and the Infinity Cache (256 MiB)
   const int64_t num_lookups = int64_t{1} << 24;       // 16.8 M rows per launch
   char* table = nullptr;
