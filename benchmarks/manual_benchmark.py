@@ -35,6 +35,8 @@ def parse():
                           ("fp16_math", False), ("compressed_grad", True), ("skip_grad_init", True),
                           ("forward_only", False), ("enable_csv", False), ("clear_caches", True)]:
         p.add_argument("--" + name, type=str2bool, nargs="?", const=True, default=default)
+    p.add_argument("--one_call_index_work", type=str2bool, nargs="?", const=True, default=False,
+                   help="also time this library's one-call form of the index work (fixed hotness only)")
     p.add_argument("--bounded_sort", type=str2bool, nargs="?", const=True, default=False,
                    help="tell Transpose that indices < num_categories (this library's extension)")
     p.add_argument("--device_table_fill", type=str2bool, nargs="?", const=True, default=None,
@@ -168,6 +170,17 @@ def run(a, table_cache=None, quiet=False):
         tb += (3 if a.compressed_grad else 2) * nnz * isz + (nnz * es if a.weighted_sum else 0)
         bw = tb * a.iterations / 1e6 / ms
         report("Transpose", ms, 0.0, bw, "Application BW [GB/s]: %.2f" % bw)
+        if getattr(a, "one_call_index_work", False) and not a.csr_input:
+            # this library's one-call form of the same index work (extension): fixed-hotness row ids are never
+            # materialised and the remapped ids come out of the transpose call (one launch up to 4,096 lookups)
+            def transpose_one_call():
+                ce.transpose_fixed_hotness(indices, B, H, weights, workspace=work,
+                                           num_categories=a.num_categories if a.bounded_sort else None,
+                                           remapped=bool(a.compressed_grad))
+
+            ms1 = timed(transpose_one_call)
+            report("Transpose_one_call", ms1, 0.0, tb * a.iterations / 1e6 / ms1,
+                   "Application BW [GB/s]: %.2f (one call: TransposeFixedHotness(..., remapped))" % (tb * a.iterations / 1e6 / ms1))
 
         # ---- backward ------------------------------------------------------------------
         num_unique = int(state["remap"][-1].item()) + 1 if a.compressed_grad else 0

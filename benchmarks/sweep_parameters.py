@@ -2,7 +2,9 @@
 """Counterpart of the reference's benchmarks/sweep_parameters.sh: the same 108-point grid
 (alpha x num_categories x embed_width x batch_size x hotness, fp32 tables, int32 indices,
 compressed gradient) run in ONE process (tables are reused between points), forward + transpose +
-backward per point, results appended to a CSV with the reference's columns plus the time per call.
+backward per point, results appended to a CSV with the reference's columns plus the time per call.  `transpose` is the
+reference's call sequence (row ids, Transpose, ComputeCompressedGradIndices); `transpose_one_call` the same index work
+through this library's one-call form (TransposeFixedHotness(..., remapped)).
 
     python benchmarks/sweep_parameters.py [--iterations 100] [--csv sweep.csv] [--order split]
 """
@@ -46,7 +48,8 @@ def main():
                 iterations=o.iterations, alpha=float(alpha), use_int64_indices=False, check_result=False,
                 half_embedding_type=False, csr_input=False, weighted_sum=False, fp16_math=False,
                 compressed_grad=True, skip_grad_init=True, forward_only=o.forward_only, enable_csv=False,
-                clear_caches=mb.str2bool(o.clear_caches), device_table_fill=True, bounded_sort=False)
+                clear_caches=mb.str2bool(o.clear_caches), device_table_fill=True, bounded_sort=False,
+                one_call_index_work=True)
             rows = mb.run(a, table_cache=cache, quiet=True)
             for name, ms, l2, dram in rows:
                 f.write("%d,%d,%d,%g,%d,%s,%s,%d,%.5f,%.2f,%.2f\n" % (cats, batch, hot, alpha, width, o.order,

@@ -190,6 +190,29 @@ def build_header_api_test(force=False):
     return exe
 
 
+def build_sort_unit_test(force=False):
+    """Compiles tests/cpp/sort_route_unit.hip: host-side unit tests of the sort's integer building blocks (buffer
+    routing, implicit payload division, tile maps, workspace plans).  The program makes no HIP call: it runs on the CPU."""
+    src = os.path.join(ROOT, "tests", "cpp", "sort_route_unit.hip")
+    exe = os.path.join(ROOT, "tests", "cpp", "sort_route_unit")
+    stamp = exe + ".stamp"
+    deps = [src]
+    for dirpath, _, files in os.walk(os.path.join(CSRC, "cuembed", "include")):
+        deps += [os.path.join(dirpath, f) for f in files]
+    digest = _digest_files(deps)
+    if not force and os.path.exists(exe) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return exe
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O1", "-std=c++17", "-I" + CSRC, src, "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for tests/cpp/sort_route_unit.hip:\n" + r.stdout)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return exe
+
+
 def build_manual_benchmark(force=False):
     """Compiles benchmarks/manual_benchmark.hip (C++ harness on the header-only API)."""
     src = os.path.join(ROOT, "benchmarks", "manual_benchmark.hip")

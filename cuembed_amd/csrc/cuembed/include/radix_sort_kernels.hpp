@@ -98,8 +98,9 @@ struct PassPlan {
   unsigned long long key_high;  //!< constant high half to put back (narrow_keys only)
 };
 
-//! ... from the three words themselves (`have_state` false: nothing is decided on the device).
-__device__ __forceinline__ PassPlan PlanPassFrom(const bool have_state, const unsigned long long state_varying,
+//! ... from the three words themselves (`have_state` false: nothing is decided on the device).  Host-callable: the
+//! routing rules are unit-tested on the CPU (tests/cpp/sort_route_unit.hip).
+__host__ __device__ __forceinline__ PassPlan PlanPassFrom(const bool have_state, const unsigned long long state_varying,
                                                  const unsigned long long state_all, const unsigned long long state_payload,
                                                  const int pass, const int passes, const SortMode& mode) {
   const bool know_keys = have_state && mode.use_varying;
@@ -110,8 +111,8 @@ __device__ __forceinline__ PassPlan PlanPassFrom(const bool have_state, const un
   PassPlan plan;
   plan.active = (active >> pass) & 1u;
   plan.first = pass == 0;
-  plan.later = __popc(active >> (pass + 1));
-  plan.next = (active >> (pass + 1)) != 0 ? pass + static_cast<int>(__ffs(static_cast<int>(active >> (pass + 1)))) : -1;
+  plan.later = __builtin_popcount(active >> (pass + 1));
+  plan.next = (active >> (pass + 1)) != 0 ? pass + __builtin_ffs(static_cast<int>(active >> (pass + 1))) : -1;
   plan.narrow_keys = mode.narrow_keys == kNarrowAlways ||
                      (mode.narrow_keys == kNarrowIfConstantHigh && know_keys && (varying >> 32) == 0);
   plan.key_high = (mode.narrow_keys == kNarrowIfConstantHigh && plan.narrow_keys)
@@ -132,7 +133,7 @@ __device__ __forceinline__ PassPlan PlanPass(const unsigned long long* __restric
 struct ArrayRoute {
   int src, dst;
 };
-__device__ __forceinline__ ArrayRoute RouteArray(const PassPlan& plan, const bool narrow) {
+__host__ __device__ __forceinline__ ArrayRoute RouteArray(const PassPlan& plan, const bool narrow) {
   ArrayRoute r;
   if (narrow) {
     r.dst = plan.later == 0 ? kBufOut : (plan.later & 1 ? kBufTmp1 : kBufTmp0);
@@ -189,7 +190,7 @@ __device__ __forceinline__ void LoadRouted(const SortArray<T>& a, const int wher
 //! XCD (tile = (b % 8) * ceil(tiles / 8) + b / 8 while that is a tile, the identity for the ragged rest), so that
 //! halves written a few workgroups apart meet in that L2 before the line leaves it (the histogram pass writes ONE
 //! 4-byte word per bin and tile: 32 neighbouring tiles share a line).  Any bijection is correct.
-__device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles, const int xcds) {
+__host__ __device__ __forceinline__ int ScatterTileOfBlock(const int b, const int num_tiles, const int xcds) {
   const int per_xcd = num_tiles / xcds;           // tiles of the rectangular part, per XCD
   if (b >= per_xcd * xcds) return b;              // ragged rest (fewer than `xcds` tiles)
   return (b % xcds) * per_xcd + (b / xcds);
@@ -1038,7 +1039,7 @@ enum class RunHeadOutput { kIds, kCompact };
 //! BlockedRankSearchKernel searches in LDS before it touches the full lists.
 constexpr unsigned kFenceStride = 256;
 
-template <typename IndexT, RunHeadOutput kOut>
+template <typename IndexT, RunHeadOutput kOut, bool kSelfCount = false>
 __global__ void __launch_bounds__(kSortThreads)
 RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
                   const unsigned* __restrict__ tile_count /* run heads per tile; null: no count launch ran (few tiles) */,
@@ -1071,8 +1072,9 @@ RunHeadScanKernel(const IndexT* __restrict__ indices, const int64_t n,
     }
   } else if (blockIdx.x > 0) {
     // no count launch (few tiles): the run heads of everything before this tile are counted here.  The tile's own
-    // first element is a head of THIS tile (WaveRunHeads); blocks (block_tiles > 0) never come this way.
-    before = CountRunHeadsBefore<IndexT>(indices, static_cast<int64_t>(blockIdx.x) * kSortTile);
+    // first element is a head of THIS tile (WaveRunHeads); blocks (block_tiles > 0) never come this way.  (A variant
+    // of its own: the batch of loads costs 52 registers that the scan of a large array must not pay.)
+    if constexpr (kSelfCount) before = CountRunHeadsBefore<IndexT>(indices, static_cast<int64_t>(blockIdx.x) * kSortTile);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
@@ -1183,7 +1185,7 @@ inline void RunHeadScanLaunch(const IndexT* indices, const size_t n, IndexT* rem
   if (n == 0) return;
   const int tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
   if (tiles == 1 || (tiles <= kSelfCountTiles && block_tiles == 0)) {  // one launch instead of two
-    RunHeadScanKernel<IndexT, kOut><<<tiles, kSortThreads, 0, stream>>>(
+    RunHeadScanKernel<IndexT, kOut, true><<<tiles, kSortThreads, 0, stream>>>(
         indices, static_cast<int64_t>(n), nullptr, false, remapped, block_tiles, unique_keys, block_start, fence_keys);
     return;
   }

@@ -77,7 +77,7 @@ inline void ImplicitPayloadDivisor(const int d, SortMode* mode) {
   mode->v1_shift = 31 + s;
 }
 
-__device__ __forceinline__ unsigned ImplicitPayload(const SortMode& mode, const int64_t i) {
+__host__ __device__ __forceinline__ unsigned ImplicitPayload(const SortMode& mode, const int64_t i) {
   return static_cast<unsigned>((static_cast<unsigned long long>(static_cast<unsigned>(i)) * mode.v1_magic) >> mode.v1_shift);
 }
 

@@ -311,6 +311,72 @@ void ExtensionTransposeKat(hipStream_t stream) {
   ExpectInt("row cache translation", translated.host(), {1, 1000, 1001, 4});
 }
 
+// Round-5 extensions of the header API: the remapped ids from the transpose call itself (one launch at this size), the
+// capacity check and the padded gradient of a device-side row count, the reference's GradT arithmetic.
+template <typename IndexT>
+void OneCallAndBoundedKat(hipStream_t stream) {
+  // README example through ONE call: indices [[4, 8], [18, 4], [8, 7], [8, 0]] (4 samples x 2) -> sorted + ids
+  DeviceArray<IndexT> idx(std::vector<IndexT>{4, 8, 18, 4, 8, 7, 8, 0});
+  DeviceArray<IndexT> t_idx(8), t_sid(8), remap(8);
+  const float* no_w = nullptr;
+  float* no_tw = nullptr;
+  size_t lwork = 0;
+  cuembed::TransposeFixedHotness<IndexT, float>(idx.ptr, no_w, 4, 2, t_idx.ptr, t_sid.ptr, no_tw, nullptr, &lwork, stream,
+                                                static_cast<int>(sizeof(IndexT) * 8), 1, remap.ptr);
+  DeviceArray<char> work(lwork);
+  cuembed::TransposeFixedHotness<IndexT, float>(idx.ptr, no_w, 4, 2, t_idx.ptr, t_sid.ptr, no_tw, work.ptr, &lwork, stream,
+                                                static_cast<int>(sizeof(IndexT) * 8), 1, remap.ptr);
+  HIP_OK(hipStreamSynchronize(stream));
+  ExpectInt("one call: sorted indices", t_idx.host(), {0, 4, 4, 7, 8, 8, 8, 18});
+  ExpectInt("one call: sample ids", t_sid.host(), {3, 0, 1, 2, 0, 2, 3, 1});
+  ExpectInt("one call: remapped ids", remap.host(), {0, 1, 1, 2, 3, 3, 3, 4});
+  // compressed backward with the row count left on the device: 5 rows; buffers of 4 rows raise the flag and stay untouched
+  const int width = 4;
+  DeviceArray<float> gy(std::vector<float>(4 * width, 1.0f));
+  DeviceArray<uint32_t> overflow(std::vector<uint32_t>{0u});
+  {
+    DeviceArray<float> grad(std::vector<float>(5 * width, 7.0f));
+    DeviceArray<IndexT> inv(std::vector<IndexT>(5, static_cast<IndexT>(-3)));
+    cuembed::EmbeddingBackward<float, IndexT>(gy.ptr, width, -1, 8, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false, grad.ptr,
+                                              inv.ptr, stream, 1, nullptr, /*capacity_rows=*/4, overflow.ptr);
+    HIP_OK(hipStreamSynchronize(stream));
+    ExpectInt("capacity 4 < 5 rows: flag raised", overflow.host(), {1});
+    ExpectAll("capacity 4 < 5 rows: nothing written", grad.host(), std::vector<float>(5 * width, 7.0f));
+  }
+  {
+    // capacity 7 with padding: rows 5 and 6 are zero and name the batch's smallest row (0)
+    DeviceArray<float> grad(std::vector<float>(7 * width, 7.0f));
+    DeviceArray<IndexT> inv(std::vector<IndexT>(7, static_cast<IndexT>(-3)));
+    cuembed::EmbeddingBackward<float, IndexT>(gy.ptr, width, -1, 8, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false, grad.ptr,
+                                              inv.ptr, stream, 1, nullptr, /*capacity_rows=*/7, overflow.ptr,
+                                              /*pad_to_capacity=*/true);
+    HIP_OK(hipStreamSynchronize(stream));
+    ExpectInt("padded: inverse mapping", inv.host(), {0, 4, 7, 8, 18, 0, 0});
+    std::vector<float> want;
+    for (float v : {1.f, 2.f, 1.f, 3.f, 1.f, 0.f, 0.f})
+      for (int c = 0; c < width; ++c) want.push_back(v);
+    ExpectAll("padded: gradient rows", grad.host(), want);
+  }
+  {
+    // the reference's GradT arithmetic (fp16: 2049 does not exist, 2048 + 1 stays 2048 -- as in the CPU reference)
+    std::vector<__half> h_gy(3 * width, __float2half(1.0f));
+    for (int c = 0; c < width; ++c) h_gy[c] = __float2half(2048.0f);
+    DeviceArray<__half> gy16(h_gy), grad16(std::vector<__half>(1 * width, __float2half(9.0f)));
+    DeviceArray<IndexT> one_row(std::vector<IndexT>{5, 5, 5}), samples(std::vector<IndexT>{0, 1, 2}), ids(std::vector<IndexT>{0, 0, 0});
+    DeviceArray<IndexT> inv(1);
+    const __half* no_w16 = nullptr;
+    cuembed::EmbeddingBackwardReferenceSums<__half, IndexT>(gy16.ptr, width, 1, 3, one_row.ptr, samples.ptr, ids.ptr, no_w16,
+                                                            false, grad16.ptr, inv.ptr, stream);
+    HIP_OK(hipStreamSynchronize(stream));
+    Expect("reference sums: 2048 + 1 + 1 in fp16", grad16.host(), {2048, 2048, 2048, 2048});
+    ExpectInt("reference sums: inverse mapping", inv.host(), {5});
+    cuembed::EmbeddingBackward<__half, IndexT>(gy16.ptr, width, 1, 3, one_row.ptr, samples.ptr, ids.ptr, no_w16, false,
+                                               grad16.ptr, inv.ptr, stream);
+    HIP_OK(hipStreamSynchronize(stream));
+    Expect("default: fp32 partial sums, one rounding", grad16.host(), {2050, 2050, 2050, 2050});
+  }
+}
+
 int main() {
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
@@ -340,6 +406,8 @@ int main() {
   // extensions
   ExtensionTransposeKat<int32_t, float>(stream);
   ExtensionTransposeKat<int64_t, __half>(stream);
+  OneCallAndBoundedKat<int32_t>(stream);
+  OneCallAndBoundedKat<int64_t>(stream);
   cuembed::SetBackwardTuning(cuembed::BackwardTuning{0, 0});
   HIP_OK(hipStreamDestroy(stream));
   if (g_failures) {

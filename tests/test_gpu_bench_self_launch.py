@@ -58,6 +58,11 @@ def test_gpus_1_line_has_the_contract_fields():
     assert line["preroll_ms"] == 0 and line["preroll_launches"] == 0      # `value` is the caller's protocol, nothing else
     assert "same clock at every N" in line["timing"] and line["config"]["index_batches_cycled"] == 4
     assert line["ms_per_step"] == line["wall_ms_per_step"]
+    # `metric` / `value` are BASELINE.json's: achieved HBM GB/s (measured fabric bytes / time), a fraction of the peak;
+    # the reference benchmark's application bandwidth (which exceeds the peak at alpha = 1.15) sits beside it
+    assert line["metric"].startswith("achieved HBM GB/s (% of peak), EmbeddingForward w=256 hot=64")
+    assert 0 < line["value"] <= 8000.0 < line["application_GBps"] and "measured L2->fabric bytes" in line["value_basis"]
+    assert abs(line["pct_of_hbm_peak_whole_job"] - 100 * line["value"] / 8000.0) < 0.02
     assert line["steady_state"]["preroll_ms"] == 100 and 0 < line["steady_state"]["ms_per_step"] < line["ms_per_step"] * 1.15
     rl = line["roofline"]
     assert rl["bound"] == "l2+fabric" and 0 < rl["frac"] <= 1.0 and rl["traffic"] > 0
