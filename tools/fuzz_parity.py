@@ -99,6 +99,22 @@ def one_case(rng, ce, O, np, torch, verbose=False):
     d_remap = ce.compute_compressed_grad_indices(d_ti)
     assert np.array_equal(d_remap.cpu().numpy(), remap), ("remap", desc)
     nu = int(remap[-1]) + 1
+    # the remapped ids from the transpose call itself (one launch up to 4,096 lookups, one per pass up to 262,144)
+    if rng.integers(0, 2) == 0:
+        r4 = ce.transpose(d_sid, dev(indices), dev(weights), num_categories=bound, num_rows=rows_bound, remapped=True)
+        assert torch.equal(r4[0], d_ti) and torch.equal(r4[1], d_ts) and torch.equal(r4[3], d_remap), ("transpose+remap", desc)
+        if not csr:
+            f4 = ce.transpose_fixed_hotness(dev(indices), B, H, dev(weights), num_categories=bound, remapped=True)
+            assert torch.equal(f4[0], d_ti) and torch.equal(f4[1], d_ts) and torch.equal(f4[3], d_remap), ("fixed+remap", desc)
+    # the reference's GradT arithmetic on data that is NOT exactly representable: bit-identical to the oracle
+    if rng.integers(0, 4) == 0 and nnz <= 400000:
+        gyr = rng.uniform(-1, 1, (B, W)).astype(elem)
+        wr = None if weights is None else rng.uniform(0, 1, nnz).astype(elem)
+        twr = None if wr is None else O.transpose(sid, indices, wr, stable=True)[2]
+        want_r, want_rinv = O.embedding_backward(gyr, W, nu, ti, ts, remap, twr)
+        got_r, got_rinv = ce.embedding_backward(dev(gyr), nu, d_ti, d_ts, d_remap, dev(twr), reference_sums=True)
+        assert np.array_equal(got_r.cpu().numpy().view(np.uint8), want_r.view(np.uint8)), ("reference sums", desc)
+        assert np.array_equal(got_rinv.cpu().numpy(), want_rinv), ("reference sums: inverse mapping", desc)
     # ---- backward: small-integer grad_y and (if weighted) weights 0.5/0.25 keep sums exact as long
     # as runs are short enough for the element type
     counts = np.bincount(remap)
@@ -121,6 +137,20 @@ def one_case(rng, ce, O, np, torch, verbose=False):
                                   inverse_mapping=ibuf)
             assert torch.equal(buf[:nu], got_c) and torch.equal(ibuf[:nu], got_inv), ("backward, num_unique on device", desc)
             assert bool((buf[nu:] == 77.0).all()) and bool((ibuf[nu:] == -3).all()), ("rows past the last id", desc)
+            # ... padded: the tail is zero and names the batch's smallest row; one row short: the flag, nothing written
+            ce.capacity_overflowed(reset=True)
+            ce.embedding_backward(dev(gy), None, d_ti, d_ts, d_remap, d_tw if use_w else None, grad_embedding=buf,
+                                  inverse_mapping=ibuf, pad_to_capacity=True)
+            assert torch.equal(buf[:nu], got_c) and torch.equal(ibuf[:nu], got_inv), ("padded gradient", desc)
+            assert bool((buf[nu:] == 0).all()) and bool((ibuf[nu:] == int(ti[0])).all()), ("padding", desc)
+            assert not ce.capacity_overflowed()
+            if nu > 1:
+                short = torch.full((nu - 1, W), 55.0, dtype=got_c.dtype, device="cuda")
+                ishort = torch.full((nu - 1,), -4, dtype=d_ti.dtype, device="cuda")
+                ce.embedding_backward(dev(gy), None, d_ti, d_ts, d_remap, d_tw if use_w else None, grad_embedding=short,
+                                      inverse_mapping=ishort)
+                assert ce.capacity_overflowed(reset=True) and bool((short == 55.0).all()) and bool((ishort == -4).all()), \
+                    ("capacity one row short", desc)
         want_d = None
         if ncat * W <= 40_000_000:
             want_d, _ = O.embedding_backward(gy.astype(np.float32), W, ncat, ti, ts, None, w32)
