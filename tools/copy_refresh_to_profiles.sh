@@ -21,6 +21,7 @@ cp $S/bwd_blocked_coalesced_probe.json profiles/r05_bwd_blocked_coalesced_probe_
 cp $S/c3_balance_probe.json profiles/r05_c3_balance_probe.json
 cp $S/traffic_rows.txt profiles/r05_traffic_rows.txt
 cp $S/torch_step_profile_b1024.txt profiles/r05_torch_step_profile_b1024.txt
+cp $S/torch_policy_probe.json profiles/r05_torch_policy_probe.json
 cp $S/small_sort_reference_sequence.txt profiles/r05_small_sort_reference_sequence.txt
 cp $S/small_sort_one_call.txt profiles/r05_small_sort_one_call.txt
 cp $S/headline_pattern_loads_only_ceiling.csv profiles/r05_headline_pattern_loads_only_ceiling.csv

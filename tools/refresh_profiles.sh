@@ -30,6 +30,7 @@ python tools/c3_balance_probe.py > "$O/c3_balance_probe.json" 2>> "$O/torch_prob
 CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_python_ctypes_ops.jsonl" 2>> "$O/torch_probe.err"
 python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
 python tools/torch_step_profile.py > "$O/torch_step_profile_b1024.txt" 2>&1
+python tools/torch_policy_probe.py > "$O/torch_policy_probe.json" 2>> "$O/torch_probe.err"
 # index work of the sweep grid's small and mid-size shapes: reference call sequence and the one-call form
 SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1 32768:16" bash tools/small_sort_trace.sh refresh_ref > /dev/null 2>&1
 EXTRA="--fused_row_ids --fused_remap" SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1" bash tools/small_sort_trace.sh refresh_one_call > /dev/null 2>&1
