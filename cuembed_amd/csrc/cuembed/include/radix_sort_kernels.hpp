@@ -203,12 +203,12 @@ __host__ __device__ __forceinline__ int ScatterTileOfBlock(const int b, const in
 //! its keys, and the OR of its 64-bit first payloads (`payload64`, or nullptr), go to
 //! tile_bits[kStateWords * tile + ...].
 template <typename KeyT, int ITEMS = kSortItems, bool kChained = false>
-__global__ void __launch_bounds__(kSortThreads)
-RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int pass, const int passes,
-                         const SortMode mode, unsigned* __restrict__ tile_hist, const int num_tiles,
-                         unsigned long long* __restrict__ tile_bits,
-                         const unsigned long long* __restrict__ state,
-                         const unsigned long long* __restrict__ payload64, const int xcds) {
+__device__ __forceinline__ void
+RadixTileHistogramBody(const SortArray<KeyT>& keys, const int64_t n, const int pass, const int passes,
+                       const SortMode& mode, unsigned* __restrict__ tile_hist, const int num_tiles,
+                       unsigned long long* __restrict__ tile_bits,
+                       const unsigned long long* __restrict__ state,
+                       const unsigned long long* __restrict__ payload64, const int xcds, const int block) {
   __shared__ unsigned count[kSortWaves][kSortBins];  // one sub-histogram per wave: 4x less contention
   __shared__ unsigned long long wave_bits[kSortWaves][kStateWords];
   const int tid = threadIdx.x;
@@ -225,7 +225,7 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
     high = static_cast<KeyT>(plan.key_high);
     where = RouteArray(plan, narrow).src;
   }
-  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles, xcds);
+  const int tile = ScatterTileOfBlock(block, num_tiles, xcds);
   const int64_t base = static_cast<int64_t>(tile) * (kSortThreads * ITEMS) + tid;
   KeyT key[ITEMS];
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
@@ -306,6 +306,17 @@ RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int 
   }
 }
 
+template <typename KeyT, int ITEMS = kSortItems, bool kChained = false>
+__global__ void __launch_bounds__(kSortThreads)
+RadixTileHistogramKernel(const SortArray<KeyT> keys, const int64_t n, const int pass, const int passes,
+                         const SortMode mode, unsigned* __restrict__ tile_hist, const int num_tiles,
+                         unsigned long long* __restrict__ tile_bits,
+                         const unsigned long long* __restrict__ state,
+                         const unsigned long long* __restrict__ payload64, const int xcds) {
+  RadixTileHistogramBody<KeyT, ITEMS, kChained>(keys, n, pass, passes, mode, tile_hist, num_tiles, tile_bits, state,
+                                                payload64, xcds, static_cast<int>(blockIdx.x));
+}
+
 //! Block-wide exclusive scan helper (256 threads): returns the exclusive prefix of `v` and the
 //! block total through `total`.
 __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* total) {
@@ -337,12 +348,12 @@ __device__ __forceinline__ unsigned BlockExclusiveScan(unsigned v, unsigned* tot
 //! the tiles' OR/AND words into `state` (single writer, so nothing has to be zeroed first).
 //! Few tiles (<= kFoldScanTiles): the per-bin work is folded into the scatter kernel and only
 //! that extra workgroup is launched (grid = 1), in pass 0.
-__global__ void __launch_bounds__(kSortThreads)
-RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
-                     unsigned* __restrict__ bin_total, const int pass, const int passes, const SortMode mode,
-                     const unsigned long long* __restrict__ tile_bits,
-                     unsigned long long* __restrict__ state, const int segment_tiles) {
-  if (blockIdx.x == gridDim.x - 1 && gridDim.x % kSortBins != 0) {  // the extra workgroup of pass 0
+__device__ __forceinline__ void
+RadixScanTilesBody(unsigned* __restrict__ tile_hist, const int num_tiles,
+                   unsigned* __restrict__ bin_total, const int pass, const int passes, const SortMode& mode,
+                   const unsigned long long* __restrict__ tile_bits,
+                   unsigned long long* __restrict__ state, const int segment_tiles, const int block, const int grid) {
+  if (block == grid - 1 && grid % kSortBins != 0) {  // the extra workgroup of pass 0
     __shared__ unsigned long long wave_bits[kSortWaves][kStateWords];
     unsigned long long any = 0ull, all = ~0ull, pay = 0ull;
     for (int t = threadIdx.x; t < num_tiles; t += kSortThreads) {
@@ -375,14 +386,15 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
       state[kStateVarying] = any & ~all;
       state[kStateAllBits] = all;
       state[kStatePayloadBits] = pay;
+      state[kStateWords] = 0ull;      // the arrival counter of RadixHighPassesKernel's grid barrier
     }
     return;
   }
   if (pass > 0 && !PlanPass(state, pass, passes, mode).active) return;
   // workgroup (segment, bin): the tiles of one segment (a block of the input that is sorted on its own;
   // one segment = the whole input unless the caller asked for sample blocks)
-  const int bin = blockIdx.x % kSortBins;
-  const int segment = blockIdx.x / kSortBins;
+  const int bin = block % kSortBins;
+  const int segment = block / kSortBins;
   const int first = segment * segment_tiles;
   const int last = first + segment_tiles < num_tiles ? first + segment_tiles : num_tiles;
   unsigned* row = tile_hist + static_cast<size_t>(bin) * num_tiles;
@@ -407,7 +419,16 @@ RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
     }
     carry += total;
   }
-  if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;   // [segment][bin]
+  if (threadIdx.x == 0) bin_total[block] = carry;   // [segment][bin]
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+RadixScanTilesKernel(unsigned* __restrict__ tile_hist, const int num_tiles,
+                     unsigned* __restrict__ bin_total, const int pass, const int passes, const SortMode mode,
+                     const unsigned long long* __restrict__ tile_bits,
+                     unsigned long long* __restrict__ state, const int segment_tiles) {
+  RadixScanTilesBody(tile_hist, num_tiles, bin_total, pass, passes, mode, tile_bits, state, segment_tiles,
+                     static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 }
 
 //! Stable rank of the tile's keys by the digit at `shift`.  Lane l of wave w holds the keys at
@@ -512,14 +533,14 @@ __device__ __forceinline__ void StageAndStore(unsigned char* stage_raw, const T 
 // workgroup adds up the per-tile counts it needs itself (no scan launch), and the OR / AND words of the keys are folded
 // by every workgroup of pass 0 (no extra workgroup): 12-16 launches become 1 + the number of passes.
 template <typename KeyT, typename V1, typename V2, int ITEMS = kSortItems, bool kChained = false>
-__global__ void __launch_bounds__(kSortThreads, 4)
-RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
-                   const int64_t n, const int pass, const int passes, const SortMode mode,
-                   const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
-                   const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles,
-                   const int xcds, unsigned* next_hist = nullptr /* kChained: the [pass][tile][bin] words, writable */,
-                   const unsigned long long* __restrict__ tile_bits = nullptr /* kChained, pass 0: the tiles' OR / AND words */,
-                   unsigned long long* __restrict__ state_out = nullptr /* kChained, pass 0: where their fold goes */) {
+__device__ __forceinline__ void
+RadixScatterBody(const SortArray<KeyT>& keys, const SortArray<V1>& v1, const SortArray<V2>& v2,
+                 const int64_t n, const int pass, const int passes, const SortMode& mode,
+                 const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
+                 const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles,
+                 const int xcds, unsigned* next_hist /* kChained: the [pass][tile][bin] words, writable */,
+                 const unsigned long long* __restrict__ tile_bits /* kChained, pass 0: the tiles' OR / AND words */,
+                 unsigned long long* __restrict__ state_out /* kChained, pass 0: where their fold goes */, const int block) {
   constexpr int kTile = kSortThreads * ITEMS;
   constexpr bool kHasV1 = !std::is_same<V1, NoPayload>::value;
   constexpr bool kHasV2 = !std::is_same<V2, NoPayload>::value;
@@ -531,7 +552,7 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  const int tile = ScatterTileOfBlock(static_cast<int>(blockIdx.x), num_tiles, xcds);
+  const int tile = ScatterTileOfBlock(block, num_tiles, xcds);
   const int64_t tile_base = static_cast<int64_t>(tile) * kTile;
   const int count = static_cast<int>(n - tile_base < kTile ? n - tile_base : kTile);
   const int64_t wave_base = tile_base + wave * (64 * ITEMS);
@@ -577,10 +598,11 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
           pay |= fold[w][2];
         }
         plan = PlanPassFrom(true, any & ~all, all, pay, 0, passes, mode);
-        if (blockIdx.x == 0 && tid == 0) {   // (every workgroup computes the same three words; one writes them)
+        if (block == 0 && tid == 0) {   // (every workgroup computes the same three words; one writes them)
           state_out[kStateVarying] = any & ~all;
           state_out[kStateAllBits] = all;
           state_out[kStatePayloadBits] = pay;
+          state_out[kStateWords] = 0ull;      // (RadixHighPassesKernel's arrival counter)
         }
       } else {
         plan = PlanPassFrom(false, 0ull, 0ull, 0ull, 0, passes, mode);
@@ -749,14 +771,17 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
   }
 }
 
-//! Largest input the one-workgroup sort takes (tuning: CUEMBED_BLOCK_SORT_MAX, read once; never above kBlockSortMax).
-inline int BlockSortLimit() {
-  static const int limit = [] {
-    const char* e = std::getenv("CUEMBED_BLOCK_SORT_MAX");
-    const int v = e != nullptr ? std::atoi(e) : kBlockSortMax;
-    return v < 1 ? 1 : (v > kBlockSortMax ? kBlockSortMax : v);
-  }();
-  return limit;
+template <typename KeyT, typename V1, typename V2, int ITEMS = kSortItems, bool kChained = false>
+__global__ void __launch_bounds__(kSortThreads, 4)
+RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2,
+                   const int64_t n, const int pass, const int passes, const SortMode mode,
+                   const unsigned* __restrict__ tile_prefix, const unsigned* __restrict__ bin_total,
+                   const int num_tiles, const unsigned long long* __restrict__ state, const int segment_tiles,
+                   const int xcds, unsigned* next_hist = nullptr, const unsigned long long* __restrict__ tile_bits = nullptr,
+                   unsigned long long* __restrict__ state_out = nullptr) {
+  RadixScatterBody<KeyT, V1, V2, ITEMS, kChained>(keys, v1, v2, n, pass, passes, mode, tile_prefix, bin_total, num_tiles,
+                                                  state, segment_tiles, xcds, next_hist, tile_bits, state_out,
+                                                  static_cast<int>(blockIdx.x));
 }
 
 //! Inputs of up to this many keys are sorted by the chained kernels (one launch per pass, RadixScatterKernel<...,
@@ -768,6 +793,97 @@ constexpr int kChainedSortItems = 4;
 inline int ChainedSortTiles(const size_t n) {
   const size_t tile = static_cast<size_t>(kSortThreads) * kChainedSortItems;
   return static_cast<int>((n + tile - 1) / tile);
+}
+
+// ---------------------------------------------------------------------------
+// The HIGH WORD of 64-bit keys in one launch.  Lookup indices are below 2^31 (the API's row counts are `int`), so
+// passes 4..7 of an int64 sort through the reference signature (all 64 bits: index_transforms.cuh:108-136) are
+// skipped on the device practically always -- but the host cannot know, and twelve launches that return at once cost
+// ~45 us (C4, int64: 0.187 ms against 0.129 with a key bound).  This kernel is ALL of them: one workgroup per compute
+// unit (resident together by construction), which returns at once when no high digit varies and otherwise runs the
+// working passes itself -- histogram, scan and scatter of every tile in turn, separated by a grid-wide barrier
+// (arrival counter + agent-scope release / acquire, docs: cdna_hip_programming.md G16).  Slower than the tiled
+// launches when it has work (a generic COO transpose with keys beyond 2^32), the same result.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void SortGridBarrier(unsigned* counter, unsigned* epoch) {
+  __syncthreads();                                   // every thread's stores of the phase are issued
+  *epoch += gridDim.x;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // write this XCD's dirty lines back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < *epoch) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // drop what other XCDs have rewritten
+  }
+  __syncthreads();
+}
+
+template <typename KeyT, typename V1, typename V2>
+__global__ void __launch_bounds__(kSortThreads)
+RadixHighPassesKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2, const int64_t n,
+                      const int first_pass, const int passes, const SortMode mode, unsigned* tile_hist,
+                      unsigned* bin_total, const int num_tiles, unsigned long long* state, const int segment_tiles,
+                      const int segments, const int xcds) {
+  bool any = false;
+  for (int p = first_pass; p < passes; ++p) any = any || PlanPass(state, p, passes, mode).active;
+  if (!any) return;                                  // (the same three words for every workgroup)
+  unsigned* counter = reinterpret_cast<unsigned*>(state + kStateWords);
+  unsigned epoch = 0;
+  const int grid = static_cast<int>(gridDim.x);
+  const int scan_blocks = kSortBins * segments;
+  for (int p = first_pass; p < passes; ++p) {
+    if (!PlanPass(state, p, passes, mode).active) continue;
+    for (int b = static_cast<int>(blockIdx.x); b < num_tiles; b += grid) {
+      RadixTileHistogramBody<KeyT, kSortItems, false>(keys, n, p, passes, mode, tile_hist, num_tiles, nullptr, state,
+                                                      nullptr, xcds, b);
+      __syncthreads();
+    }
+    SortGridBarrier(counter, &epoch);
+    for (int b = static_cast<int>(blockIdx.x); b < scan_blocks; b += grid) {
+      RadixScanTilesBody(tile_hist, num_tiles, bin_total, p, passes, mode, nullptr, state, segment_tiles, b, scan_blocks);
+      __syncthreads();
+    }
+    SortGridBarrier(counter, &epoch);
+    for (int b = static_cast<int>(blockIdx.x); b < num_tiles; b += grid) {
+      RadixScatterBody<KeyT, V1, V2, kSortItems, false>(keys, v1, v2, n, p, passes, mode, tile_hist, bin_total, num_tiles,
+                                                        state, segment_tiles, xcds, nullptr, nullptr, nullptr, b);
+      __syncthreads();
+    }
+    SortGridBarrier(counter, &epoch);
+  }
+}
+
+//! ... and the same for the chained passes (inputs of up to kChainedSortMax keys): one scatter phase per working pass.
+template <typename KeyT, typename V1, typename V2>
+__global__ void __launch_bounds__(kSortThreads)
+RadixHighPassesChainedKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2, const int64_t n,
+                             const int first_pass, const int passes, const SortMode mode, unsigned* tile_hist,
+                             const int num_tiles, unsigned long long* state, const int xcds) {
+  bool any = false;
+  for (int p = first_pass; p < passes; ++p) any = any || PlanPass(state, p, passes, mode).active;
+  if (!any) return;
+  unsigned* counter = reinterpret_cast<unsigned*>(state + kStateWords);
+  unsigned epoch = 0;
+  const int grid = static_cast<int>(gridDim.x);
+  for (int p = first_pass; p < passes; ++p) {
+    if (!PlanPass(state, p, passes, mode).active) continue;
+    for (int b = static_cast<int>(blockIdx.x); b < num_tiles; b += grid) {
+      RadixScatterBody<KeyT, V1, V2, kChainedSortItems, true>(keys, v1, v2, n, p, passes, mode, tile_hist, nullptr, num_tiles,
+                                                              state, num_tiles, xcds, tile_hist, nullptr, nullptr, b);
+      __syncthreads();
+    }
+    SortGridBarrier(counter, &epoch);   // the next pass adds up the counts this one left with atomics
+  }
+}
+
+//! Largest input the one-workgroup sort takes (tuning: CUEMBED_BLOCK_SORT_MAX, read once; never above kBlockSortMax).
+inline int BlockSortLimit() {
+  static const int limit = [] {
+    const char* e = std::getenv("CUEMBED_BLOCK_SORT_MAX");
+    const int v = e != nullptr ? std::atoi(e) : kBlockSortMax;
+    return v < 1 ? 1 : (v > kBlockSortMax ? kBlockSortMax : v);
+  }();
+  return limit;
 }
 
 template <typename KeyT, typename V1, typename V2>
@@ -800,8 +916,8 @@ struct RadixSortPlan {
     tile_bits = off;
     off += SortAlign(static_cast<size_t>(kStateWords) * (chained_tiles > num_tiles ? chained_tiles : num_tiles) *
                      sizeof(unsigned long long));
-    varying = off;
-    off += SortAlign(kStateWords * sizeof(unsigned long long));
+    varying = off;   // the three state words + the arrival counter of RadixHighPassesKernel
+    off += SortAlign((kStateWords + 1) * sizeof(unsigned long long));
     total = off;
   }
 };
@@ -877,16 +993,28 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     const int tiles = plan.chained_tiles;
     RadixTileHistogramKernel<KeyT, kChainedSortItems, true><<<tiles, kSortThreads, 0, stream>>>(
         keys, count, 0, plan.passes, mode, tile_hist, tiles, tile_bits, nullptr, payload64, xcds);
-    for (int p = 0; p < plan.passes; ++p)
+    // (64-bit keys through the reference signature: the passes over the high word are one launch, see above)
+    const int launched_passes = (sizeof(KeyT) == 8 && plan.passes > 4 && mode.use_varying) ? 4 : plan.passes;
+    for (int p = 0; p < launched_passes; ++p)
       RadixScatterKernel<KeyT, V1, V2, kChainedSortItems, true><<<tiles, kSortThreads, 0, stream>>>(
           keys, v1, v2, count, p, plan.passes, mode, tile_hist, nullptr, tiles, state, tiles, xcds, tile_hist,
           p == 0 ? tile_bits : nullptr, state);
+    if constexpr (sizeof(KeyT) == 8) {
+      if (launched_passes < plan.passes) {
+        const int units = CurrentDeviceShape().compute_units;
+        RadixHighPassesChainedKernel<KeyT, V1, V2><<<tiles < units ? tiles : units, kSortThreads, 0, stream>>>(
+            keys, v1, v2, count, launched_passes, plan.passes, mode, tile_hist, tiles, state, xcds);
+      }
+    }
     if (remapped != nullptr)
       RunHeadScan<typename std::make_signed<KeyT>::type>(
           reinterpret_cast<const typename std::make_signed<KeyT>::type*>(keys_out), n, remapped, work, stream);
     return;
   }
-  for (int p = 0; p < plan.passes; ++p) {
+  // 64-bit keys through the reference signature: the four passes over the high word are ONE launch (see
+  // RadixHighPassesKernel); it needs the three state words, which such a sort always has
+  const int tiled_passes = (sizeof(KeyT) == 8 && plan.passes > 4 && mode.use_varying && !fold_scan) ? 4 : plan.passes;
+  for (int p = 0; p < tiled_passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64, xcds);
     const int scan_blocks = (fold_scan ? 0 : kSortBins * segments) + (p == 0 && device_state ? 1 : 0);
@@ -896,6 +1024,14 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     RadixScatterKernel<KeyT, V1, V2><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, v1, v2, count, p, plan.passes, mode, tile_hist, fold_scan ? nullptr : bin_total,
         plan.num_tiles, state, segment_tiles, xcds);
+  }
+  if constexpr (sizeof(KeyT) == 8) {
+    if (tiled_passes < plan.passes) {
+      const int units = CurrentDeviceShape().compute_units;
+      RadixHighPassesKernel<KeyT, V1, V2><<<plan.num_tiles < units ? plan.num_tiles : units, kSortThreads, 0, stream>>>(
+          keys, v1, v2, count, tiled_passes, plan.passes, mode, tile_hist, bin_total, plan.num_tiles, state, segment_tiles,
+          segments, xcds);
+    }
   }
   if (remapped != nullptr)
     RunHeadScan<typename std::make_signed<KeyT>::type>(reinterpret_cast<const typename std::make_signed<KeyT>::type*>(keys_out),
