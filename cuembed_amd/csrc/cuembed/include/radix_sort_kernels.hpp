@@ -85,6 +85,22 @@ enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
 enum : int { kStateVarying = 0, kStateAllBits = 1, kStatePayloadBits = 2, kStateWords = 3 };
 
+//! Arrival counters of the grid barrier: a top counter and one per group of workgroups (blockIdx % groups), 256 bytes
+//! apart (an arrival costs ~10 ns on ONE address, tools/ticket_probe.hip; eight groups arrive side by side).  They
+//! sit behind the three state words and are zeroed by whoever writes those.
+constexpr int kBarrierGroups = 8;
+constexpr int kBarrierStride = 64;     // in counters (unsigned)
+constexpr int kBarrierWords = (kBarrierGroups + 1) * kBarrierStride / 2;   // in state words (unsigned long long)
+__device__ __forceinline__ unsigned* SortBarrierCounters(unsigned long long* state) {
+  return reinterpret_cast<unsigned*>(state + kStateWords + 1);
+}
+__device__ __forceinline__ void ZeroSortBarrier(unsigned long long* state) {
+  unsigned* c = SortBarrierCounters(state);
+#pragma unroll
+  for (int g = 0; g <= kBarrierGroups; ++g) c[g * kBarrierStride] = 0u;
+}
+
+
 //! What the device knows about the arrays after pass 0: state[kStateVarying] = bits in which keys
 //! differ, state[kStateAllBits] = AND of all keys, state[kStatePayloadBits] = OR of all 64-bit first
 //! payloads.  state == nullptr: nothing is decided on the device (fixed route, all passes run).
@@ -386,7 +402,7 @@ RadixScanTilesBody(unsigned* __restrict__ tile_hist, const int num_tiles,
       state[kStateVarying] = any & ~all;
       state[kStateAllBits] = all;
       state[kStatePayloadBits] = pay;
-      state[kStateWords] = 0ull;      // the arrival counter of RadixHighPassesKernel's grid barrier
+      ZeroSortBarrier(state);         // the arrival counters of RadixHighPassesKernel's grid barrier
     }
     return;
   }
@@ -602,7 +618,7 @@ RadixScatterBody(const SortArray<KeyT>& keys, const SortArray<V1>& v1, const Sor
           state_out[kStateVarying] = any & ~all;
           state_out[kStateAllBits] = all;
           state_out[kStatePayloadBits] = pay;
-          state_out[kStateWords] = 0ull;      // (RadixHighPassesKernel's arrival counter)
+          ZeroSortBarrier(state_out);         // (RadixHighPassesKernel's arrival counters)
         }
       } else {
         plan = PlanPassFrom(false, 0ull, 0ull, 0ull, 0, passes, mode);
@@ -802,17 +818,29 @@ inline int ChainedSortTiles(const size_t n) {
 // ~45 us (C4, int64: 0.187 ms against 0.129 with a key bound).  This kernel is ALL of them: one workgroup per compute
 // unit (resident together by construction), which returns at once when no high digit varies and otherwise runs the
 // working passes itself -- histogram, scan and scatter of every tile in turn, separated by a grid-wide barrier
-// (arrival counter + agent-scope release / acquire, docs: cdna_hip_programming.md G16).  Slower than the tiled
-// launches when it has work (a generic COO transpose with keys beyond 2^32), the same result.
+// (arrival counters + agent-scope release / acquire, docs: cdna_hip_programming.md G16).  The same result, but SLOW
+// when it has work (a generic COO transpose whose keys go beyond 2^32; tools/persistent_sort_probe.hip, 4.2 M keys
+// using all 64 bits: 0.529 ms against 0.285 as 24 launches): a barrier with its fences costs 5 us at 256 workgroups
+// and 12 us at 768 -- more than the launch boundary it replaces (every workgroup's release walks its XCD's L2) -- and
+// a phase at one workgroup per compute unit runs at a third of the launched kernels' rate.  That measurement is also
+// why the WHOLE sort is not one persistent launch.  CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 brings the launches back.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void SortGridBarrier(unsigned* counter, unsigned* epoch) {
+__device__ __forceinline__ void SortGridBarrier(unsigned* counters, unsigned* epoch) {
   __syncthreads();                                   // every thread's stores of the phase are issued
-  *epoch += gridDim.x;
+  *epoch += 1u;
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // write this XCD's dirty lines back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < *epoch) __builtin_amdgcn_s_sleep(4);
+    const unsigned grid = gridDim.x;
+    const unsigned groups = grid < static_cast<unsigned>(kBarrierGroups) ? grid : static_cast<unsigned>(kBarrierGroups);
+    const unsigned g = blockIdx.x % groups;
+    const unsigned members = (grid - g + groups - 1) / groups;    // workgroups with blockIdx % groups == g
+    const unsigned before =
+        __hip_atomic_fetch_add(counters + (1 + g) * kBarrierStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == members * *epoch)                          // the group's last arrival tells the top counter
+      __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * *epoch)
+      __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // drop what other XCDs have rewritten
   }
   __syncthreads();
@@ -827,7 +855,7 @@ RadixHighPassesKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const 
   bool any = false;
   for (int p = first_pass; p < passes; ++p) any = any || PlanPass(state, p, passes, mode).active;
   if (!any) return;                                  // (the same three words for every workgroup)
-  unsigned* counter = reinterpret_cast<unsigned*>(state + kStateWords);
+  unsigned* counter = SortBarrierCounters(state);
   unsigned epoch = 0;
   const int grid = static_cast<int>(gridDim.x);
   const int scan_blocks = kSortBins * segments;
@@ -862,7 +890,7 @@ RadixHighPassesChainedKernel(const SortArray<KeyT> keys, const SortArray<V1> v1,
   bool any = false;
   for (int p = first_pass; p < passes; ++p) any = any || PlanPass(state, p, passes, mode).active;
   if (!any) return;
-  unsigned* counter = reinterpret_cast<unsigned*>(state + kStateWords);
+  unsigned* counter = SortBarrierCounters(state);
   unsigned epoch = 0;
   const int grid = static_cast<int>(gridDim.x);
   for (int p = first_pass; p < passes; ++p) {
@@ -874,6 +902,16 @@ RadixHighPassesChainedKernel(const SortArray<KeyT> keys, const SortArray<V1> v1,
     }
     SortGridBarrier(counter, &epoch);   // the next pass adds up the counts this one left with atomics
   }
+}
+
+//! CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 (read once): the passes over the high word of 64-bit keys as launches of their own
+//! again -- for a process whose keys really use more than 32 bits (see RadixHighPassesKernel: 0.53 against 0.28 ms).
+inline bool HighWordInOneLaunch() {
+  static const bool v = [] {
+    const char* e = std::getenv("CUEMBED_SORT_HIGH_WORD_LAUNCHES");
+    return !(e != nullptr && std::atoi(e) != 0);
+  }();
+  return v;
 }
 
 //! Largest input the one-workgroup sort takes (tuning: CUEMBED_BLOCK_SORT_MAX, read once; never above kBlockSortMax).
@@ -917,7 +955,7 @@ struct RadixSortPlan {
     off += SortAlign(static_cast<size_t>(kStateWords) * (chained_tiles > num_tiles ? chained_tiles : num_tiles) *
                      sizeof(unsigned long long));
     varying = off;   // the three state words + the arrival counter of RadixHighPassesKernel
-    off += SortAlign((kStateWords + 1) * sizeof(unsigned long long));
+    off += SortAlign((kStateWords + 1 + kBarrierWords) * sizeof(unsigned long long));
     total = off;
   }
 };
@@ -994,7 +1032,8 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     RadixTileHistogramKernel<KeyT, kChainedSortItems, true><<<tiles, kSortThreads, 0, stream>>>(
         keys, count, 0, plan.passes, mode, tile_hist, tiles, tile_bits, nullptr, payload64, xcds);
     // (64-bit keys through the reference signature: the passes over the high word are one launch, see above)
-    const int launched_passes = (sizeof(KeyT) == 8 && plan.passes > 4 && mode.use_varying) ? 4 : plan.passes;
+    const int launched_passes =
+        (sizeof(KeyT) == 8 && plan.passes > 4 && mode.use_varying && HighWordInOneLaunch()) ? 4 : plan.passes;
     for (int p = 0; p < launched_passes; ++p)
       RadixScatterKernel<KeyT, V1, V2, kChainedSortItems, true><<<tiles, kSortThreads, 0, stream>>>(
           keys, v1, v2, count, p, plan.passes, mode, tile_hist, nullptr, tiles, state, tiles, xcds, tile_hist,
@@ -1013,7 +1052,8 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   }
   // 64-bit keys through the reference signature: the four passes over the high word are ONE launch (see
   // RadixHighPassesKernel); it needs the three state words, which such a sort always has
-  const int tiled_passes = (sizeof(KeyT) == 8 && plan.passes > 4 && mode.use_varying && !fold_scan) ? 4 : plan.passes;
+  const int tiled_passes =
+      (sizeof(KeyT) == 8 && plan.passes > 4 && mode.use_varying && !fold_scan && HighWordInOneLaunch()) ? 4 : plan.passes;
   for (int p = 0; p < tiled_passes; ++p) {
     RadixTileHistogramKernel<KeyT><<<plan.num_tiles, kSortThreads, 0, stream>>>(
         keys, count, p, plan.passes, mode, tile_hist, plan.num_tiles, tile_bits, state, payload64, xcds);
