@@ -801,11 +801,22 @@ RadixScatterKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const Sor
 }
 
 //! Inputs of up to this many keys are sorted by the chained kernels (one launch per pass, RadixScatterKernel<...,
-//! kChained>), in tiles of kSortThreads * ChainedSortItems(n) keys: small tiles while that leaves at most 256 of them
-//! -- a workgroup then ranks 4 rounds of 64 keys per wavefront instead of 16, and 64-256 compute units work on a pass
-//! instead of 16-64.
-constexpr size_t kChainedSortMax = size_t{1} << 18;
+//! kChained>), in tiles of kSortThreads * kChainedSortItems keys -- a workgroup then ranks 4 rounds of 64 keys per
+//! wavefront instead of 16, and 64-224 compute units work on a pass instead of 16-56.  The limit is where the tiled
+//! passes catch up (profiles/r05_chained_sort_limit.txt: 196,608 keys 60.7 against 66.7 us, 262,144 keys 70.8 against
+//! 67.3): a pass's atomics grow with the keys (one per key in a pass whose next digit is random), three launches do not.
+//! In 4096-key tiles beyond that (fewer, longer sums over the tiles) the same scheme is slower than the tiled passes
+//! at every size tried (524,288 keys: 99.6 against 70.5 us; 1,048,576: 147 against 78).
+constexpr size_t kChainedSortMax = size_t{224} << 10;
 constexpr int kChainedSortItems = 4;
+inline size_t ChainedSortLimit() {   // tuning: CUEMBED_CHAINED_SORT_MAX (read once; never above kChainedSortMax)
+  static const size_t limit = [] {
+    const char* e = std::getenv("CUEMBED_CHAINED_SORT_MAX");
+    const long long v = e != nullptr ? std::atoll(e) : static_cast<long long>(kChainedSortMax);
+    return v < 0 ? size_t{0} : (static_cast<size_t>(v) > kChainedSortMax ? kChainedSortMax : static_cast<size_t>(v));
+  }();
+  return limit;
+}
 inline int ChainedSortTiles(const size_t n) {
   const size_t tile = static_cast<size_t>(kSortThreads) * kChainedSortItems;
   return static_cast<int>((n + tile - 1) / tile);
@@ -935,7 +946,7 @@ struct RadixSortPlan {
     if (passes < 1) passes = 1;
     num_tiles = static_cast<int>((n + kSortTile - 1) / kSortTile);
     if (num_tiles < 1) num_tiles = 1;
-    chained_tiles = (n > 0 && n <= kChainedSortMax) ? ChainedSortTiles(n) : 0;
+    chained_tiles = (n > 0 && n <= ChainedSortLimit()) ? ChainedSortTiles(n) : 0;
     size_t off = 0;
     keys_tmp = off;
     off += SortAlign(n * sizeof(KeyT));

@@ -118,7 +118,7 @@ static void TileMaps() {
 }
 
 static void Plans() {
-  for (size_t n : {size_t{1}, size_t{4096}, size_t{4097}, size_t{16384}, size_t{16385}, size_t{262144}, size_t{262145},
+  for (size_t n : {size_t{1}, size_t{4096}, size_t{4097}, size_t{16384}, size_t{16385}, size_t{229376}, size_t{229377}, size_t{262145},
                    size_t{1} << 22, size_t{1} << 27}) {
     const RadixSortPlan<uint64_t, int64_t, float> plan(n, 64);
     CHECK(plan.passes == 8, "64 key bits are 8 passes");

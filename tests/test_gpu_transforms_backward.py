@@ -379,18 +379,18 @@ def test_one_launch_index_work_of_small_batches(ce, oracle, idx, weights):
 @pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
 @pytest.mark.parametrize("weights", [None, np.float16], ids=["unweighted", "w16"])
 def test_transpose_chained_and_tiled_paths(ce, oracle, idx, weights):
-    """Between 16,385 and 262,144 lookups the sort runs ONE launch per pass: every scatter pass counts the histogram of
+    """Between 4,097 and 229,376 lookups the sort runs ONE launch per pass: every scatter pass counts the histogram of
     the next working pass with global atomics, per (destination tile of 1,024 keys, next digit), aggregated over runs
-    of equal neighbours.  Sizes around its tile and range boundaries (262,145 and up: the three-launch passes); hot
+    of equal neighbours.  Sizes around its tile and range boundaries (229,377 and up: the three-launch passes); hot
     keys (runs far longer than a wavefront, whose atomics must aggregate), two-valued and constant keys, keys using all
     bits incl. the sign; reference call sequence and the fused calls."""
     rng = np.random.default_rng(5)
     info = np.iinfo(idx[0])
-    for nnz in (16385, 17407, 17408, 17409, 65536, 100003, 262144, 262145, 270001):
+    for nnz in (16385, 17407, 17408, 17409, 65536, 100003, 229376, 229377, 262144, 270001):
         hot_keys = np.where(rng.uniform(0, 1, nnz) < 0.4, 777, rng.integers(0, 10_000_000, nnz))
         kinds = [("random24", rng.integers(0, 10_000_000, nnz)), ("hot", hot_keys), ("two", rng.integers(0, 2, nnz) * 65536),
                  ("full", rng.integers(info.min, info.max, nnz, endpoint=True)), ("equal", np.full(nnz, 3))]
-        if nnz not in (17408, 65536, 262144, 262145):
+        if nnz not in (17408, 65536, 229376, 229377):
             kinds = kinds[:2] + kinds[3:4]
         for name, cols in kinds:
             cols = cols.astype(idx[0])

@@ -99,7 +99,7 @@ def one_case(rng, ce, O, np, torch, verbose=False):
     d_remap = ce.compute_compressed_grad_indices(d_ti)
     assert np.array_equal(d_remap.cpu().numpy(), remap), ("remap", desc)
     nu = int(remap[-1]) + 1
-    # the remapped ids from the transpose call itself (one launch up to 4,096 lookups, one per pass up to 262,144)
+    # the remapped ids from the transpose call itself (one launch up to 4,096 lookups, one per pass up to 229,376)
     if rng.integers(0, 2) == 0:
         r4 = ce.transpose(d_sid, dev(indices), dev(weights), num_categories=bound, num_rows=rows_bound, remapped=True)
         assert torch.equal(r4[0], d_ti) and torch.equal(r4[1], d_ts) and torch.equal(r4[3], d_remap), ("transpose+remap", desc)
