@@ -231,6 +231,9 @@ RadixTileHistogramBody(const SortArray<KeyT>& keys, const int64_t n, const int p
   const int wave = tid >> 6;
   const int shift = 8 * pass;
   const unsigned flip = SignFlip(mode, pass);
+  const int tile = ScatterTileOfBlock(block, num_tiles, xcds);
+  const int64_t base = static_cast<int64_t>(tile) * (kSortThreads * ITEMS) + tid;
+  KeyT key[ITEMS];
   int where = kBufIn;
   bool narrow = false;
   KeyT high = 0;
@@ -241,10 +244,9 @@ RadixTileHistogramBody(const SortArray<KeyT>& keys, const int64_t n, const int p
     high = static_cast<KeyT>(plan.key_high);
     where = RouteArray(plan, narrow).src;
   }
-  const int tile = ScatterTileOfBlock(block, num_tiles, xcds);
-  const int64_t base = static_cast<int64_t>(tile) * (kSortThreads * ITEMS) + tid;
-  KeyT key[ITEMS];
   LoadRouted<KeyT>(keys, where, narrow, n, base, kSortThreads, high, key);  // all loads in flight first
+  // (requesting 32-bit keys from both possible sources before the state words arrive, as the chained scatter does, was
+  // measured here and in the tiled scatter: nothing at 0.5 M keys, slower from 2 M up -- twice the key reads)
 #pragma unroll
   for (int w = 0; w < kSortWaves; ++w) count[w][tid] = 0;
   __syncthreads();
@@ -406,7 +408,6 @@ RadixScanTilesBody(unsigned* __restrict__ tile_hist, const int num_tiles,
     }
     return;
   }
-  if (pass > 0 && !PlanPass(state, pass, passes, mode).active) return;
   // workgroup (segment, bin): the tiles of one segment (a block of the input that is sorted on its own;
   // one segment = the whole input unless the caller asked for sample blocks)
   const int bin = block % kSortBins;
@@ -418,11 +419,20 @@ RadixScanTilesBody(unsigned* __restrict__ tile_hist, const int num_tiles,
   // four consecutive tiles per thread and round: 1024 tiles (4.19 M keys) are ONE round -- one load, one block scan,
   // one store per thread instead of four dependent rounds (this kernel is all latency: 4.7 -> see EXPERIMENTS)
   constexpr int kPerThread = 4;
+  // (the first round is requested BEFORE the state words say whether this pass runs at all: one memory round trip
+  // instead of two in a row)
+  unsigned ahead[kPerThread];
+  {
+    const int t0 = first + static_cast<int>(threadIdx.x) * kPerThread;
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) ahead[q] = t0 + q < last ? row[t0 + q] : 0u;
+  }
+  if (pass > 0 && !PlanPass(state, pass, passes, mode).active) return;
   for (int base = first; base < last; base += kSortThreads * kPerThread) {
     const int t0 = base + static_cast<int>(threadIdx.x) * kPerThread;
     unsigned v[kPerThread];
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) v[q] = t0 + q < last ? row[t0 + q] : 0u;
+    for (int q = 0; q < kPerThread; ++q) v[q] = base == first ? ahead[q] : (t0 + q < last ? row[t0 + q] : 0u);
     unsigned mine = 0;
 #pragma unroll
     for (int q = 0; q < kPerThread; ++q) mine += v[q];
