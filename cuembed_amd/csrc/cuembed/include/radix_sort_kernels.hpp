@@ -836,12 +836,13 @@ inline int ChainedSortTiles(const size_t n) {
 // The HIGH WORD of 64-bit keys in one launch.  Lookup indices are below 2^31 (the API's row counts are `int`), so
 // passes 4..7 of an int64 sort through the reference signature (all 64 bits: index_transforms.cuh:108-136) are
 // skipped on the device practically always -- but the host cannot know, and twelve launches that return at once cost
-// ~45 us (C4, int64: 0.187 ms against 0.129 with a key bound).  This kernel is ALL of them: one workgroup per compute
-// unit (resident together by construction), which returns at once when no high digit varies and otherwise runs the
+// ~45 us (C4, int64: 0.187 ms against 0.129 with a key bound).  This kernel is ALL of them: one workgroup per four
+// compute units (resident together: HighWordWorkgroups below), which returns at once when no high digit varies and otherwise runs the
 // working passes itself -- histogram, scan and scatter of every tile in turn, separated by a grid-wide barrier
 // (arrival counters + agent-scope release / acquire, docs: cdna_hip_programming.md G16).  The same result, but SLOW
 // when it has work (a generic COO transpose whose keys go beyond 2^32; tools/persistent_sort_probe.hip, 4.2 M keys
-// using all 64 bits: 0.529 ms against 0.285 as 24 launches): a barrier with its fences costs 5 us at 256 workgroups
+// using all 64 bits: 0.529 ms with one workgroup per compute unit, 1.07 ms with the quarter grid, against 0.285 as
+// 24 launches): a barrier with its fences costs 5 us at 256 workgroups
 // and 12 us at 768 -- more than the launch boundary it replaces (every workgroup's release walks its XCD's L2) -- and
 // a phase at one workgroup per compute unit runs at a third of the launched kernels' rate.  That measurement is also
 // why the WHOLE sort is not one persistent launch.  CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 brings the launches back.
@@ -925,8 +926,18 @@ RadixHighPassesChainedKernel(const SortArray<KeyT> keys, const SortArray<V1> v1,
   }
 }
 
+//! Grid of the high-word kernels: a QUARTER of the compute units.  Their workgroups wait for each other at the grid
+//! barriers, so all of them have to be resident together -- alone they always are, and with 3 such workgroups fitting
+//! a compute unit (160 VGPRs, 43 KB LDS) it would take MORE THAN TWELVE of these kernels executing at the same time,
+//! each with keys beyond 2^32, to leave one of them waiting for slots the others hold (a process has 4 hardware queues
+//! by default, GPU_MAX_HW_QUEUES).  Kernels that find no work (every lookup index) return at once and wait for nobody.
+inline int HighWordWorkgroups() {
+  const int units = CurrentDeviceShape().compute_units / 4;
+  return units < 1 ? 1 : units;
+}
+
 //! CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 (read once): the passes over the high word of 64-bit keys as launches of their own
-//! again -- for a process whose keys really use more than 32 bits (see RadixHighPassesKernel: 0.53 against 0.28 ms).
+//! again -- for a process whose keys really use more than 32 bits (see RadixHighPassesKernel: 1.07 against 0.28 ms).
 inline bool HighWordInOneLaunch() {
   static const bool v = [] {
     const char* e = std::getenv("CUEMBED_SORT_HIGH_WORD_LAUNCHES");
@@ -1061,7 +1072,7 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
           p == 0 ? tile_bits : nullptr, state);
     if constexpr (sizeof(KeyT) == 8) {
       if (launched_passes < plan.passes) {
-        const int units = CurrentDeviceShape().compute_units;
+        const int units = HighWordWorkgroups();
         RadixHighPassesChainedKernel<KeyT, V1, V2><<<tiles < units ? tiles : units, kSortThreads, 0, stream>>>(
             keys, v1, v2, count, launched_passes, plan.passes, mode, tile_hist, tiles, state, xcds);
       }
@@ -1088,7 +1099,7 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   }
   if constexpr (sizeof(KeyT) == 8) {
     if (tiled_passes < plan.passes) {
-      const int units = CurrentDeviceShape().compute_units;
+      const int units = HighWordWorkgroups();
       RadixHighPassesKernel<KeyT, V1, V2><<<plan.num_tiles < units ? plan.num_tiles : units, kSortThreads, 0, stream>>>(
           keys, v1, v2, count, tiled_passes, plan.passes, mode, tile_hist, bin_total, plan.num_tiles, state, segment_tiles,
           segments, xcds);
