@@ -17,6 +17,7 @@
 // are listed in INTEGRATION.md section 4.
 #include <ATen/ATen.h>
 #include <ATen/DeviceGuard.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
@@ -553,6 +554,12 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
                                                out_grad.options().layout(at::kSparse), /*is_coalesced=*/false);
       return grads;
     }
+    // (from here on the host has to read the row count: not something a HIP graph can hold)
+    TORCH_CHECK(c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None,
+                "cuembed_pyt: this sparse gradient needs its row count on the host and cannot be captured into a graph: "
+                "sparse_grad=True is capture-safe while min(lookups, rows) gradient rows fit ", kPaddedBytes >> 20,
+                " MiB (here ", (capacity * row_bytes) >> 20, " MiB", grad_kind == kGradSparseReference ? ", and "
+                "sparse_grad=\"reference\" always reads the count" : "", "); sparse_grad=False always is");
     if (room > 0) {
       // everything is enqueued before the host looks at the device: rows for `room`, narrowed afterwards
       rows = at::empty({room, width}, out_grad.options());

@@ -367,6 +367,51 @@ def test_native_node_large_and_small_gradients_in_turn(pyt):
             assert torch.equal(got._indices(), t2.grad._indices()) and torch.equal(got._values(), t2.grad._values()), (B, step)
 
 
+def test_native_step_replays_from_a_hip_graph(pyt):
+    """Forward + backward of the op captured into a torch.cuda.CUDAGraph and replayed on NEW indices in the same buffers:
+    the dense gradient and the padded sparse gradient (no read-back, no host decision inside the step) are capturable
+    -- the way to run launch-bound batches (tools/torch_graph_step_probe.py: B = 1024, 0.095 -> 0.074 ms) -- and a
+    gradient that needs its row count on the host says so instead of failing inside HIP."""
+    torch.manual_seed(4)
+    k, d, B, H = 50_000, 64, 512, 16
+    table = torch.randn(k, d, device="cuda").requires_grad_(True)
+    offsets = torch.arange(0, B * H + 1, H, device="cuda")
+    up = torch.randint(-3, 4, (B, d), device="cuda").float()
+    first = torch.randint(0, k, (B * H,), device="cuda")
+    second = torch.randint(0, 2000, (B * H,), device="cuda")
+    indices = first.clone()
+    side = torch.cuda.Stream()
+    for kind in (False, True):
+        def step():
+            out = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad=kind, hints=None)
+            (g,) = torch.autograd.grad(out, table, up)
+            return out, g
+        with torch.cuda.stream(side):     # (warm-up and capture on one side stream: torch's capture rules)
+            indices.copy_(first)
+            step()
+            torch.cuda.current_stream().synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out_g, grad_g = step()
+            indices.copy_(second)
+            graph.replay()
+            torch.cuda.current_stream().synchronize()
+            got_out, got_grad = out_g.clone(), (grad_g.to_dense() if kind else grad_g.clone())
+            want_out, want_grad = step()
+            torch.cuda.current_stream().synchronize()
+        assert torch.equal(got_out, want_out), kind
+        assert torch.equal(got_grad, want_grad.to_dense() if kind else want_grad), kind
+        if kind:
+            assert grad_g._nnz() == B * H and not grad_g.is_coalesced()      # padded to min(lookups, rows) entries
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(graph, stream=side):
+                out = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad="reference", hints=None)
+                torch.autograd.grad(out, table, up)
+    torch.cuda.synchronize()
+
+
 def test_policy_hints_never_change_a_result(pyt):
     """cuembed_amd.policy picks non-temporal row loads for a table whose batches are (nearly) all distinct rows and the
     bag order for an offsets tensor it sees again; both are scheduling hints: same bits, and the decisions are the

@@ -27,6 +27,8 @@ cp $S/small_sort_one_call.txt profiles/r05_small_sort_one_call.txt
 cp $S/headline_pattern_loads_only_ceiling.csv profiles/r05_headline_pattern_loads_only_ceiling.csv
 cp $S/row_read_ceiling.csv profiles/r05_row_read_ceiling.csv
 cp $S/narrow_row_probe.jsonl profiles/r05_narrow_row_probe.jsonl
+cp $S/torch_graph_step_probe.json profiles/r05_torch_graph_step_probe.json
+cp $S/forward_parts_probe.csv profiles/r05_forward_parts_probe.csv
 cp $S/traffic_c2.json profiles/traffic_c2.json
 cp $S/traffic_c3.json profiles/traffic_c3.json
 ls -la profiles | grep r05

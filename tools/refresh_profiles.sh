@@ -31,6 +31,7 @@ CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py > "$O/torch_op_st
 python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
 python tools/torch_step_profile.py > "$O/torch_step_profile_b1024.txt" 2>&1
 python tools/torch_policy_probe.py > "$O/torch_policy_probe.json" 2>> "$O/torch_probe.err"
+python tools/torch_graph_step_probe.py > "$O/torch_graph_step_probe.json" 2>> "$O/torch_probe.err"
 # index work of the sweep grid's small and mid-size shapes: reference call sequence and the one-call form
 SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1 32768:16" bash tools/small_sort_trace.sh refresh_ref > /dev/null 2>&1
 EXTRA="--fused_row_ids --fused_remap" SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1" bash tools/small_sort_trace.sh refresh_one_call > /dev/null 2>&1
@@ -40,6 +41,8 @@ cp "$R/gpurun_out/small_sort_refresh_one_call.txt" "$O/small_sort_one_call.txt"
 tools/row_read_ceiling > "$O/row_read_ceiling.csv" 2> "$O/row_read_ceiling.err"
 tools/row_read_ceiling --c2 1.15 > "$O/headline_pattern_loads_only_ceiling.csv" 2>> "$O/row_read_ceiling.err"
 tools/row_read_ceiling --c2 0 >> "$O/headline_pattern_loads_only_ceiling.csv" 2>> "$O/row_read_ceiling.err"
+tools/row_read_ceiling --c2-parts 1.15 > "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
+tools/row_read_ceiling --c2-parts 0 >> "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
 python tools/narrow_row_probe.py > "$O/narrow_row_probe.jsonl" 2>> "$O/row_read_ceiling.err"
 python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
 # profiler passes last (they clock lower); the program goes directly after `--`
