@@ -211,7 +211,7 @@ void cuembed_transpose_sample_blocks(const void* rows, const void* cols, const v
 }
 
 // Extension: ... and ComputeCompressedGradIndices' output from the same call (cuembed::Transpose,
-// transpose_remapped_indices): ONE launch for the whole index work of a batch of up to 16,384 lookups.
+// transpose_remapped_indices): ONE launch for the whole index work of a batch of up to 4,096 lookups.
 void cuembed_transpose_remapped(const void* rows, const void* cols, const void* weights, int nnz,
                                 int index_type, int weight_type, void* transpose_rows,
                                 void* transpose_cols, void* transpose_weights, void* transpose_remapped_indices,

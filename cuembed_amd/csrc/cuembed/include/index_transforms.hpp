@@ -156,7 +156,7 @@ void TranslateIndicesForRowCache(const IndexT* indices,
  *    of grad_y only (C4: EmbeddingBackward 0.258 -> 0.191 ms with 2 blocks, 572 k -> 679 k gradient rows).
  *    RecommendedSampleBlocks() picks the count.  Never use it with a dense gradient.
  *  - `transpose_remapped_indices` (default nullptr).  Not null: also receives ComputeCompressedGradIndices' output for
- *    the sorted indices (nnz entries) -- the same values, one call.  Up to 16,384 lookups the whole thing is ONE launch
+ *    the sorted indices (nnz entries) -- the same values, one call.  Up to 4,096 lookups the whole thing is ONE launch
  *    of one workgroup (block_sort_kernels.hpp: a dependent launch costs 3.5-5 us at these sizes, the reference's
  *    sequence is ~10 of them); beyond, the run-head scan's launches follow the sort's on the stream, sharing `work`.
  */

@@ -435,7 +435,7 @@ def transpose(rows, cols, weights=None, workspace=None, num_categories=None, num
     consecutive blocks and transposes each on its own -- compressed-gradient path only, see
     recommended_sample_blocks().
     remapped=True (extension): a fourth result, what compute_compressed_grad_indices(sorted cols) returns, from the same
-    call -- up to 16,384 lookups the whole index work is then ONE kernel launch."""
+    call -- up to 4,096 lookups the whole index work is then ONE kernel launch, up to 229,376 one launch per radix pass."""
     _check_dev("rows", rows)
     dev = rows.device
     _check_dev("cols", cols, dev)

@@ -254,7 +254,7 @@ void cuembed_transpose_fixed_hotness_sample_blocks(const void* indices, const vo
 /* Extension (cuembed::Transpose / TransposeFixedHotness, `transpose_remapped_indices`): as the two calls above, and
  * transpose_remapped_indices (nnz entries of the index type; NULL: not wanted) also receives what
  * cuembed_compute_compressed_grad_indices would compute from transpose_rows / transpose_indices -- the same values
- * from the same call.  Up to 16,384 lookups the WHOLE index work (row ids of a fixed-hotness batch, stable sort, remap)
+ * from the same call.  Up to 4,096 lookups the WHOLE index work (row ids of a fixed-hotness batch, stable sort, remap)
  * is ONE launch of one 1024-thread workgroup (a dependent launch costs 3.5-5 us at these sizes and the
  * reference's sequence is about ten of them, index_transforms.cuh:95-137, :278-323); beyond that the run-head scan's
  * launches follow the sort's on the stream and share `work`. */

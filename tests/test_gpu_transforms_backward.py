@@ -335,11 +335,11 @@ def test_transpose_tile_boundaries_and_degenerate_keys(ce, oracle, idx):
 @pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
 @pytest.mark.parametrize("weights", [None, np.float32, np.float16], ids=["unweighted", "w32", "w16"])
 def test_one_launch_index_work_of_small_batches(ce, oracle, idx, weights):
-    """Up to 16,384 lookups the whole index work -- row ids, stable sort, remap -- is ONE launch of one 1024-thread
-    workgroup (block_sort_kernels.hpp): sizes around its round (64), chunk (1024 x rounds) and kernel-variant (4096,
-    16384) boundaries; keys with one or all varying digits, negative keys, runs longer than a wavefront; through the
+    """Up to 4,096 lookups the whole index work -- row ids, stable sort, remap -- is ONE launch of one 1024-thread
+    workgroup (block_sort_kernels.hpp): sizes around its round (64), chunk (1024 x rounds) and range (4096) boundaries,
+    and on into the one-launch-per-pass range; keys with one or all varying digits, negative keys, runs longer than a wavefront; through the
     reference-shaped call sequence, through transpose(remapped=True) and through transpose_fixed_hotness(remapped=True).
-    16,385 lookups take the tiled path: same results from the same calls."""
+    Same results from the same calls on either side."""
     rng = np.random.default_rng(77)
     info = np.iinfo(idx[0])
     for nnz in (1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 3000, 4095, 4096, 4097, 5001, 8192, 12345, 16383, 16384,
