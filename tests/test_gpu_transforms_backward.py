@@ -654,3 +654,45 @@ def test_transpose_fixed_hotness_without_sample_id_array(ce, oracle, idx):
             oi, os_, _ = oracle.transpose(oracle.extract_row_ids_from_fixed(B, H, idx[0]), cols, None, stable=True)
             got = ce.transpose_fixed_hotness(dev(cols), B, H)
             assert np.array_equal(host(got[0]), oi) and np.array_equal(host(got[1]), os_), (B, H)
+
+
+_KNOB_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+import cuembed_amd as ce
+
+rng = np.random.default_rng(3)
+for dt, tt in ((np.int32, torch.int32), (np.int64, torch.int64)):
+    info = np.iinfo(dt)
+    for nnz in (900, 1001, 5000, 19999, 20001, 70000, 300000):
+        for name, cols in (("full", rng.integers(info.min, info.max, nnz, endpoint=True)),
+                           ("rows", rng.integers(0, 5_000_000, nnz))):
+            cols = cols.astype(dt)
+            sid = np.arange(nnz, dtype=dt)
+            order = np.argsort(cols, kind="stable")
+            t = ce.transpose(torch.from_numpy(sid).cuda(), torch.from_numpy(cols).cuda(), None, remapped=True)
+            assert np.array_equal(t[0].cpu().numpy(), cols[order]), (dt, nnz, name)
+            assert np.array_equal(t[1].cpu().numpy(), sid[order]), (dt, nnz, name)
+            heads = np.concatenate(([0], (cols[order][1:] != cols[order][:-1]).astype(np.int64)))
+            assert np.array_equal(t[3].cpu().numpy(), np.cumsum(heads).astype(dt)), (dt, nnz, name)
+assert ce._lib.lib().cuembed_peek_last_error() == 0
+print("knobs ok")
+"""
+
+
+def test_sort_regime_knobs_give_the_same_order():
+    """CUEMBED_BLOCK_SORT_MAX, CUEMBED_CHAINED_SORT_MAX and CUEMBED_SORT_HIGH_WORD_LAUNCHES move the limits between the
+    sort's three implementations and bring back the launched passes over the high word of 64-bit keys (the code the
+    default build only runs through RadixHighPassesKernel): in a process of its own with all three set, sizes on both
+    sides of the moved limits, keys using every bit and keys that are table rows -- the stable order and the run-head
+    ids of a plain numpy argsort."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUEMBED_BLOCK_SORT_MAX="1000", CUEMBED_CHAINED_SORT_MAX="20000",
+               CUEMBED_SORT_HIGH_WORD_LAUNCHES="1")
+    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT.format(root=root)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "knobs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
