@@ -5,7 +5,7 @@
 // reference does with ~10 cub launches (index_transforms.cuh:95-137, :278-323) -- without a single intermediate array.
 // Why one workgroup: at these sizes a dependent launch is not bound by its work but by its cold start, ~3.5-5 us each
 // on MI355X (profiles/r05_small_sort_baseline.txt: the 12-14 launches of the tiled path are 55-65 us for 16 k pairs
-// whatever the kernels do), while 1024 threads of one CU rank 16 k keys per pass in a few us.
+// whatever the kernels do), while 1024 threads of one CU rank 4 k keys per pass in about 2 us.
 //   * 1024 threads = 16 wavefronts, four per SIMD; wavefront w owns `chunk` = 64 * ceil(n / 1024) CONSECUTIVE positions,
 //     64 per round, so the number of ranking rounds follows n (1,024 pairs: ONE round per wavefront and pass; the
 //     256-thread kernel this replaces gave all 1,024 keys to wavefront 0: 19.7 us).
