@@ -53,17 +53,24 @@ inline int ChooseSegmentLen(const int64_t nnz, const int lanes_per_row, const De
   return len;
 }
 
-//! Column slices for the backward gather (see SegmentedScatterAddKernel 2b): slices of at
-//! least 128 bytes (one L2 line), at most one per XCD and a divisor of the XCD count (8 on a full chip: rows of
-//! 1 KiB and more; a single-XCD partition never slices; measured at the
-//! C4 index set: fp32 W = 256 0.579 -> 0.540 ms, fp16 W = 512 0.580 -> 0.546 ms against 4 slices).
-//! Only for >= 1M lookups: EmbeddingBackward is not told the batch size, and with few lookups
-//! grad_y fits the L2s anyway (measured: 0.340 -> 0.290 ms at C4, but 25 -> 28 us at nnz = 262k).
+//! Column slices for the backward gather (see SegmentedScatterAddKernel 2b): at most one per XCD and a divisor of the
+//! XCD count; a single-XCD partition never slices.  EmbeddingBackward is not told the batch size (how much of grad_y an
+//! L2 fronts), so the rule goes by the number of lookups:
+//!   >= 2^20 lookups: slices of at least 128 bytes (one L2 line) -- 4 for 512-byte rows, 8 for rows of 1 KiB and more
+//!                    (measured at the C4 index set: 0.340 -> 0.290 ms; fp32 W = 256 0.579 -> 0.540 ms against 4 slices);
+//!   >= 2^17 lookups: slices of at least 256 bytes -- 2 for 512-byte rows, 4 for 1 KiB.  Measured over 60 shapes of
+//!                    131 k - 786 k lookups (profiles/r05_backward_mid_size_slices.txt): B = 16,384 x H = 16 26.5 ->
+//!                    19.1 us, 32,768 x 16 44.8 -> 36.2, 16,384 x 32 (1 KiB rows) 92.7 -> 52.1; small batches with long
+//!                    bags (grad_y fits the L2s anyway) -3 ... +3 %; the one shape that loses is hotness 1 with a
+//!                    quarter of a million samples (1 KiB rows, uniform indices: +7 %).  128-byte slices there: up to
+//!                    +13 % on small batches, hence the wider slices;
+//!   fewer: no slices (the launch floor).
 inline int ChooseColumnSlices(const size_t row_bytes, const int lanes_per_row, const int64_t nnz,
                               const DeviceShape& dev) {
   int slices = 1;
-  while (nnz >= (int64_t{1} << 20) && slices * 2 <= dev.xcds && dev.xcds % (slices * 2) == 0 &&
-         row_bytes / (slices * 2) >= 128 && lanes_per_row % (slices * 2) == 0)
+  const size_t min_slice_bytes = nnz >= (int64_t{1} << 20) ? 128 : 256;
+  while (nnz >= (int64_t{1} << 17) && slices * 2 <= dev.xcds && dev.xcds % (slices * 2) == 0 &&
+         row_bytes / (slices * 2) >= min_slice_bytes && lanes_per_row % (slices * 2) == 0)
     slices *= 2;
   const int v = BackwardTuningCell(1).load(std::memory_order_relaxed);
   if (v >= 1 && v <= dev.xcds && dev.xcds % v == 0 && lanes_per_row % v == 0) slices = v;
@@ -176,7 +183,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
  * @brief How many sample blocks Transpose(..., sample_blocks) should cut a batch into so that, while one
  * block is being scattered, the part of grad_y an L2 gathers from fits that L2 (extension; see Transpose()).
  * grad_y is `batch_size` rows of `embed_width` GradT; EmbeddingBackward gives every XCD a column slice of
- * the row (ChooseColumnSlices: >= 128 bytes, only from 2^20 lookups up), so an L2 fronts
+ * the row (ChooseColumnSlices: >= 128 bytes from 2^20 lookups up), so an L2 fronts
  * batch_size x slice bytes -- 8.4 MB at C4 for 4 MiB of L2.  Returns 1 when nothing is to be gained.
  */
 template <typename GradT>
