@@ -23,7 +23,7 @@ static void Launch(const void* table, int width, int batch, const int* indices, 
       <<<grid, block, lds, stream>>>(static_cast<const _Float16*>(table), width, batch, indices,
                                      static_cast<const int*>(nullptr), num_hots,
                                      static_cast<const _Float16*>(nullptr), false,
-                                     static_cast<_Float16*>(out), SLICES);
+                                     static_cast<_Float16*>(out), SLICES, /*stream_rows=*/false);
 }
 
 extern "C" int variant_count() { return 13; }
