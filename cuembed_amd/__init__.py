@@ -16,7 +16,8 @@ from .ops import (CONCAT, MEAN, SUM, ComputeCompressedGradIndices, EmbeddingBack
                   embedding_weight_grad, bag_order_by_length, capacity_overflowed,
                   extract_row_ids_for_concat, extract_row_ids_from_csr,
                   extract_row_ids_from_fixed, forward_launch_shape, backward_launch_shape, device_shape, get_forward_reduction_order,
-                  set_forward_reduction_order, set_forward_row_load_policy, get_forward_row_load_policy, transpose, transpose_fixed_hotness,
+                  set_forward_reduction_order, set_forward_row_load_policy, get_forward_row_load_policy, set_forward_wide_load, transpose,
+                  transpose_fixed_hotness,
                   transpose_workspace_bytes)
 
 __version__ = "0.1.0"

@@ -35,6 +35,8 @@ def _declare(L):
     L.cuembed_set_forward_row_load_policy.argtypes = [_I]
     L.cuembed_get_forward_row_load_policy.restype = _I
     L.cuembed_get_forward_row_load_policy.argtypes = []
+    L.cuembed_set_forward_wide_load.restype = None
+    L.cuembed_set_forward_wide_load.argtypes = [_I]
     L.cuembed_embedding_backward.restype = None
     L.cuembed_embedding_backward.argtypes = [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP]
     L.cuembed_embedding_backward_reference_sums.restype = None

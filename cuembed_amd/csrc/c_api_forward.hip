@@ -180,6 +180,10 @@ void cuembed_set_forward_row_load_policy(int policy) {
 int cuembed_get_forward_row_load_policy(void) {
   return static_cast<int>(cuembed::GetForwardRowLoadPolicy());
 }
+void cuembed_set_forward_wide_load(int mode) {
+  CUEMBED_ASSERT(mode >= 0 && mode <= 2);
+  cuembed::SetForwardWideLoad(mode);
+}
 
 int cuembed_peek_last_error(void) { return static_cast<int>(hipPeekAtLastError()); }
 

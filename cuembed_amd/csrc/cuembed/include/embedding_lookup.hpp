@@ -81,6 +81,16 @@ inline std::atomic<int>& ForwardRowLoadCell() {
 }
 }  // namespace detail
 
+namespace detail {
+//! Tuning / tests only (results never depend on it): 0 = the launcher decides, 1 = never the wide-load kernel for small
+//! batches, 2 = whenever its shape allows it.
+inline std::atomic<int>& ForwardWideLoadCell() {
+  static std::atomic<int> cell{0};
+  return cell;
+}
+}  // namespace detail
+inline void SetForwardWideLoad(const int mode) { detail::ForwardWideLoadCell().store(mode, std::memory_order_relaxed); }
+
 inline void SetForwardReductionOrder(ReductionOrder order) {
   detail::ForwardOrderCell().store(static_cast<int>(order), std::memory_order_relaxed);
 }
@@ -107,6 +117,10 @@ constexpr int kDefaultBlockThreads = 256;
 //! Below this many wavefronts the sequential mapping cannot cover the chip's 1024 SIMDs
 //! twice; the split kernel (one sample per 256-thread workgroup) is then considered.
 constexpr int64_t kSplitBelowWaves = 2048;
+//! ... and when the bit-exact wide-load kernel is taken (ForwardWideLoadPays below).
+constexpr int64_t kWideLoadMaxWaves = 256;
+constexpr int kWideLoadMinHotness = 32;
+constexpr int kWideLoadCsrBatch = 1024;
 //! Index (+weight) staging budget per workgroup.  Small enough that eight
 //! 256-thread workgroups still fit a CU's 160 KiB LDS.
 constexpr int kMaxStageBytes = 16 * 1024;
@@ -189,6 +203,31 @@ inline ForwardLaunch PlanForward(const int embed_width, const void* params, cons
   return f;
 }
 
+//! Whether GatherReduceWideLoadKernel (one sample per workgroup; bit-exact) is taken instead of the sequential kernel.
+//! Shape: the row splits over a power-of-two number of lanes and is at most 1 KiB.  Size, from the measured crossover
+//! (tools/small_batch_forward_probe.py, profiles/r05_small_batch_forward_probe.csv; device times of graph replays):
+//!   CSR bags: up to 1,024 samples (one round of workgroups on the chip) -- the sequential kernel walks the two bags of a
+//!             wavefront in lockstep: 256 samples x U[0,128] lookups of 128-byte rows 12.2 -> 4.5 us, 1,024 samples of
+//!             512-byte rows 12.6 -> 11.5; from 2,048 samples on it loses (512-byte rows: 16 -> 21 us) except for rows of
+//!             up to 128 bytes, which still gain there (13.2 -> 9.3 us) and lose from 4,096;
+//!   fixed hotness: from 32 lookups per sample, while the sequential mapping has at most min(256, 2 x hotness)
+//!             wavefronts (1,024 x 64 lookups of 128-byte rows 4.6 -> 4.2 us, 256 x 64 of 512-byte rows 5.0 -> 4.1,
+//!             1,024 x 256 of 128-byte rows 15.2 -> 8.2); below 32 lookups per sample the sequential kernel is at the
+//!             launch floor and the wide one 0.5-1 us above it.
+inline bool ForwardWideLoadPays(const int lanes, const size_t row_bytes, const int batch, const int num_hots,
+                                const bool is_csr) {
+  const int mode = ForwardWideLoadCell().load(std::memory_order_relaxed);
+  const bool shape_ok = lanes >= 1 && lanes <= kWideLoadThreads && kWideLoadThreads % lanes == 0 && batch > 0 &&
+                        row_bytes <= static_cast<size_t>(kWideLoadMaxRowBytes);
+  if (!shape_ok || mode == 1) return false;
+  if (mode == 2) return true;
+  if (is_csr) return batch <= (row_bytes <= 128 ? 2 * kWideLoadCsrBatch : kWideLoadCsrBatch);
+  const int64_t waves = static_cast<int64_t>(batch) * lanes / 64;
+  const int64_t limit = 2 * static_cast<int64_t>(num_hots) < kWideLoadMaxWaves ? 2 * static_cast<int64_t>(num_hots)
+                                                                              : kWideLoadMaxWaves;
+  return num_hots >= kWideLoadMinHotness && waves <= limit;
+}
+
 template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N>
 inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indices,
                                const OffsetT* offsets, const ElemT* weights, int batch,
@@ -209,6 +248,19 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
     else
       GatherReduceSplitKernel<ElemT, AccT, IndexT, OffsetT, N, false><<<sgrid, sblock, 0, stream>>>(
           table, width, batch, indices, offsets, num_hots, weights, is_mean, out);
+    return;
+  }
+  // small batches, bit-exact: one sample per workgroup, a bag's loads spread over all of its threads, the adds in order
+  if (ForwardWideLoadPays(lanes, static_cast<size_t>(width) * sizeof(ElemT), batch, num_hots, offsets != nullptr)) {
+    const dim3 wblock(lanes, kWideLoadThreads / lanes, 1);
+    const size_t chunk = static_cast<size_t>(kForwardUnroll) * (kWideLoadThreads / lanes);
+    const size_t lds = chunk * lanes * sizeof(Pack<ElemT, N>) + (weighted ? chunk * sizeof(ElemT) : 0);
+    if (weighted)
+      GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, true><<<dim3(batch, 1, 1), wblock, lds, stream>>>(
+          table, width, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
+    else
+      GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, false><<<dim3(batch, 1, 1), wblock, lds, stream>>>(
+          table, width, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
     return;
   }
   const dim3 block(f.split.lanes_per_row, f.split.rows_per_block, 1);

@@ -547,6 +547,114 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
   StorePack<ElemT, N>(out + sample * width + static_cast<int64_t>(column_lane) * N, result);
 }
 
+// ---------------------------------------------------------------------------
+// Sum / mean for SMALL batches, BIT-EXACT: one sample per 256-thread workgroup, the LOADS of a bag spread over the
+// whole workgroup, the ADDS kept in lookup order.
+//   block = (lanes_per_row, slices) with lanes_per_row * slices = 256; grid = batch; rows of at most 1 KiB
+//   dynamic LDS = kForwardUnroll * slices rows (+ as many weights): 32 KB with 16-byte lanes
+// With few samples the sequential kernel leaves most of the chip idle and walks a bag in rounds of kForwardUnroll
+// rows, one memory round trip each (1024 samples x 64 lookups of 128-byte rows: 8 rounds).  Here slice s of the
+// workgroup requests lookups s, s + slices, ... -- kForwardUnroll x slices rows (64 for 512-byte rows, 256 for
+// 128-byte ones) in flight at once, ONE round trip for most bags -- and parks them in LDS.  Then one thread per
+// 32-BIT WORD of the row (not per 16-byte pack: four times the lanes, on all four SIMDs) pools its one or two elements
+// out of LDS in lookup order with the very operations of the sequential kernel -- acc = acc + row [* w], one IEEE
+// operation each (Arith) -- so the result has the same bits, which is why this kernel is taken by default where it
+// pays (ForwardWideLoadPays) while the re-associating split kernel above stays an option.
+// ---------------------------------------------------------------------------
+constexpr int kWideLoadThreads = 256;
+constexpr int kWideLoadMaxRowBytes = 4 * kWideLoadThreads;   // one 32-bit word per thread in the pooling phase
+
+template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N, bool kWeighted>
+__global__ void __launch_bounds__(kWideLoadThreads)
+GatherReduceWideLoadKernel(const ElemT* __restrict__ table, const int width, const IndexT* __restrict__ indices,
+                           const OffsetT* __restrict__ offsets,  // null => fixed hotness
+                           const int num_hots, const ElemT* __restrict__ weights, const bool is_mean,
+                           ElemT* __restrict__ out, const bool stream_rows) {
+  using A = Arith<AccT>;
+  constexpr int kWordElems = 4 / static_cast<int>(sizeof(ElemT));   // elements in a 32-bit word: 1 (fp32) or 2
+  extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds_raw[];
+  const int lane_x = threadIdx.x;
+  const int lanes = blockDim.x;
+  const int slice = threadIdx.y;
+  const int slices = blockDim.y;
+  const int tid = slice * lanes + lane_x;
+  const int64_t sample = blockIdx.x;
+  int64_t begin;
+  int hot = num_hots;
+  if (offsets != nullptr) {
+    begin = static_cast<int64_t>(offsets[sample]);
+    hot = static_cast<int>(static_cast<int64_t>(offsets[sample + 1]) - begin);
+  } else {
+    begin = sample * num_hots;
+  }
+  const int chunk = kForwardUnroll * slices;   // lookups parked in LDS at a time
+  Pack<ElemT, N>* stage = reinterpret_cast<Pack<ElemT, N>*>(wide_lds_raw);       // [chunk][lanes]
+  ElemT* stage_w = reinterpret_cast<ElemT*>(stage + static_cast<size_t>(chunk) * lanes);   // [chunk]
+  const Pack<ElemT, kWordElems>* stage_words = reinterpret_cast<const Pack<ElemT, kWordElems>*>(wide_lds_raw);
+  const int row_words = width / kWordElems;    // <= kWideLoadThreads (the launcher's condition)
+  const bool pools = tid < row_words;
+  const IndexT* my_idx = indices + begin;
+  const ElemT* my_w = weights + begin;
+  const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
+  AccT acc[kWordElems];
+#pragma unroll
+  for (int e = 0; e < kWordElems; ++e) acc[e] = static_cast<AccT>(0);
+  float weight_sum = 0.f;
+  for (int c0 = 0; c0 < hot; c0 += chunk) {
+    const int n = hot - c0 < chunk ? hot - c0 : chunk;
+    Pack<ElemT, N> row[kForwardUnroll];
+    // (unconditional loads on a clamped lookup: a predicate per element would make the compiler merge the register
+    // array at every branch; what a clamped lookup fetched is simply not parked)
+#pragma unroll
+    for (int u = 0; u < kForwardUnroll; ++u) {
+      const int j = slice + u * slices;
+      const int64_t r = WidenIndex(my_idx[c0 + (j < n ? j : 0)]);
+      const ElemT* p = RowPtr(lane_base, r, width);
+      row[u] = stream_rows ? LoadPackStreaming<ElemT, N>(p) : LoadPack<ElemT, N>(p);
+    }
+    if constexpr (kWeighted) {
+      for (int j = tid; j < n; j += kWideLoadThreads) stage_w[j] = my_w[c0 + j];
+    }
+#pragma unroll
+    for (int u = 0; u < kForwardUnroll; ++u) {
+      const int j = slice + u * slices;
+      if (j < n) stage[static_cast<size_t>(j) * lanes + lane_x] = row[u];
+    }
+    __syncthreads();
+    if (pools) {
+      const Pack<ElemT, kWordElems>* mine = stage_words + tid;
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) {
+        const Pack<ElemT, kWordElems> v = mine[static_cast<size_t>(j) * row_words];
+        if constexpr (kWeighted) {
+          const ElemT w = stage_w[j];
+          const AccT wa = A::widen(w);
+          weight_sum += static_cast<float>(w);
+#pragma unroll
+          for (int e = 0; e < kWordElems; ++e) acc[e] = A::add(acc[e], A::mul(A::widen(v.v[e]), wa));
+        } else {
+#pragma unroll
+          for (int e = 0; e < kWordElems; ++e) acc[e] = A::add(acc[e], A::widen(v.v[e]));
+        }
+      }
+    }
+    __syncthreads();   // the next chunk overwrites the parked rows
+  }
+  if (!pools) return;
+  // epilogue as FinishPooledRow (mean: scale by the reciprocal of the accumulated weight, zeros when that is 0)
+  if (is_mean) {
+    if constexpr (!kWeighted) weight_sum = static_cast<float>(hot);
+    const float inv = (weight_sum == 0.f) ? 0.f : 1.0f / weight_sum;
+    const AccT scale = static_cast<AccT>(inv);
+#pragma unroll
+    for (int e = 0; e < kWordElems; ++e) acc[e] = A::mul(acc[e], scale);
+  }
+  Pack<ElemT, kWordElems> result;
+#pragma unroll
+  for (int e = 0; e < kWordElems; ++e) result.v[e] = static_cast<ElemT>(acc[e]);
+  StorePackStreaming<ElemT, kWordElems>(out + sample * width + static_cast<int64_t>(tid) * kWordElems, result);
+}
+
 //! acc + <row, g> over the N elements of a pack, fp32 accumulation.  16-bit tables use the packed
 //! dot instructions (v_dot2_f32_f16 / v_dot2_f32_bf16: two products and the add per instruction,
 //! no separate conversions).

@@ -80,6 +80,13 @@ def set_forward_row_load_policy(policy):
     _lib.lib().cuembed_set_forward_row_load_policy(_ROW_LOADS[policy])
 
 
+def set_forward_wide_load(mode="auto"):
+    """Tuning / tests (never changes a result): whether small batches take the wide-load forward kernel (one sample per
+    workgroup, a bag's rows requested at once, pooled in lookup order) -- "auto" (the launcher decides), "never", "always"
+    (whenever the row shape allows it)."""
+    _lib.lib().cuembed_set_forward_wide_load({"auto": 0, "never": 1, "always": 2}[mode])
+
+
 def get_forward_row_load_policy():
     return "streaming" if _lib.lib().cuembed_get_forward_row_load_policy() else "default"
 

@@ -369,6 +369,11 @@ int cuembed_get_forward_reduction_order(void);
  * other users of the library passes the options per call instead: */
 void cuembed_set_forward_row_load_policy(int policy);
 int cuembed_get_forward_row_load_policy(void);
+/* cuembed::SetForwardWideLoad (tuning / tests; never changes a result).  Small batches of sum / mean lookups take a
+ * kernel with one sample per workgroup that requests a whole bag's rows at once and pools them in lookup order out of LDS
+ * (bit-identical to the sequential kernel; the reference has one mapping for every batch size,
+ * embedding_lookup.cuh:186-208).  0 = the launcher decides (default), 1 = never, 2 = whenever the row shape allows it. */
+void cuembed_set_forward_wide_load(int mode);
 /* cuembed_embedding_forward with per-call options (cuembed::ForwardOptions): reduction_order 0 / 1,
  * row_load_policy 0 / 1, or -1 = the process-wide default.  No state is read or written when both are >= 0. */
 void cuembed_embedding_forward_with_options(const void* params, int elem_type, int embed_width,

@@ -340,3 +340,43 @@ def test_forward_sample_order_is_a_scheduling_hint_only(oracle, dtype, index_dty
         ce.embedding_forward(table, idx[:B * 2], num_hots=2, batch_size=B, sample_order=by_length)
     with pytest.raises(ValueError):
         ce.embedding_forward(table, idx, off, w, num_hots=0, sample_order=by_length.long())
+
+
+@pytest.mark.parametrize("elem,fp16_math", [(ELEMS[0], False), (ELEMS[1], False), (ELEMS[1], True)],
+                         ids=["f32", "f16", "f16math"])
+@pytest.mark.parametrize("W", [1, 2, 6, 8, 32, 64, 100, 128, 256], ids=lambda w: "w%d" % w)
+def test_forward_wide_load_small_batches_same_bits(ce, oracle, elem, fp16_math, W):
+    """Small batches take GatherReduceWideLoadKernel (one sample per workgroup, a bag's rows requested at once, pooled in
+    lookup order out of LDS): forced on ("always") wherever the row shape allows it and forced off ("never"), both must
+    give the oracle's bits -- sum / mean, weighted, fixed hotness (also longer than one LDS chunk) and ragged CSR bags
+    with empty ones, rows from 4 bytes to 1 KiB incl. widths whose lanes do not divide 256 (those stay sequential)."""
+    if elem[0] == np.float16 and W % 2:
+        pytest.skip("row bytes must be a multiple of 4")
+    rng = np.random.default_rng(1000 + W)
+    rows, B = 3000, 23
+    table = rng.uniform(-1, 1, (rows, W)).astype(elem[0])
+    try:
+        for H in (1, 7, 33, 70, 300):
+            idx = rng.integers(0, rows, (B, H)).astype(np.int32)
+            w = rng.uniform(-1, 1, (B, H)).astype(elem[0])
+            lens = rng.integers(0, 2 * H + 1, B)
+            lens[3] = 0
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            idx_csr = rng.integers(0, rows, int(off[-1])).astype(np.int64)
+            w_csr = rng.uniform(-1, 1, int(off[-1])).astype(elem[0])
+            for mode, weighted in (("sum", False), ("sum", True), ("mean", False), ("mean", True)):
+                want = oracle.embedding_forward(table, idx.ravel(), None, w.ravel() if weighted else None, num_hots=H,
+                                                mode=mode, fp16_math=fp16_math)
+                want_csr = oracle.embedding_forward(table, idx_csr, off, w_csr if weighted else None, num_hots=0, mode=mode,
+                                                    fp16_math=fp16_math)
+                for force in ("always", "never", "auto"):
+                    ce.set_forward_wide_load(force)
+                    got = ce.embedding_forward(dev(table), dev(idx.ravel()), None, dev(w.ravel()) if weighted else None,
+                                               num_hots=H, mode=mode, fp16_math=fp16_math)
+                    assert (bits(got.cpu().numpy()) == bits(want)).all(), (H, mode, weighted, force)
+                    got = ce.embedding_forward(dev(table), dev(idx_csr), dev(off), dev(w_csr) if weighted else None,
+                                               num_hots=0, mode=mode, fp16_math=fp16_math)
+                    assert (bits(got.cpu().numpy()) == bits(want_csr)).all(), (H, mode, weighted, force, "csr")
+    finally:
+        ce.set_forward_wide_load("auto")
+    assert ce._lib.lib().cuembed_peek_last_error() == 0
