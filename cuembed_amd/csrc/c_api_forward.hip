@@ -135,6 +135,18 @@ void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width
   out[3] = static_cast<int>(f.grid);
   out[4] = static_cast<int>(f.stage_bytes);
   out[5] = f.staged ? 1 : 0;
+  // small batches of sum / mean lookups: the wide-load kernel (one sample per workgroup, rows parked in LDS)
+  const size_t elem_bytes = elem_type == CUEMBED_F32 ? 4 : 2;
+  const size_t row_bytes = static_cast<size_t>(embed_width) * elem_bytes;
+  if (!concat && cuembed::GetForwardReductionOrder() == cuembed::ReductionOrder::kSequential &&
+      cuembed::detail::ForwardWideLoadPays(f.split.lanes_per_row, row_bytes, batch_size, num_hots, is_csr != 0)) {
+    const size_t chunk = static_cast<size_t>(cuembed::detail::kForwardUnroll) *
+                         (cuembed::detail::kWideLoadThreads / f.split.lanes_per_row);
+    out[2] = 1;
+    out[3] = batch_size;
+    out[4] = static_cast<int>(chunk * row_bytes + (is_weighted ? chunk * elem_bytes : 0));
+    out[5] = 2;
+  }
 }
 
 void cuembed_embedding_weight_grad(const void* params, int elem_type, int embed_width,

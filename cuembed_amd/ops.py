@@ -99,7 +99,7 @@ def forward_launch_shape(elem_dtype, index_dtype, embed_width, batch_size, num_h
                                             batch_size, num_hots, int(is_csr), int(is_weighted),
                                             _MODES[mode], out)
     return dict(elems_per_lane=out[0], lanes_per_row=out[1], samples_per_block=out[2],
-                grid=out[3], lds_bytes=out[4], staged=bool(out[5]))
+                grid=out[3], lds_bytes=out[4], staged=out[5] == 1, wide_load=out[5] == 2)
 
 
 def device_shape():

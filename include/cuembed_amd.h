@@ -410,7 +410,8 @@ void cuembed_get_backward_tuning(int* out2);
 /* ---- introspection ------------------------------------------------------- */
 /* Launch shape the forward would use (no launch): out[0] = elements per lane,
  * out[1] = lanes per row, out[2] = samples per workgroup, out[3] = grid size,
- * out[4] = dynamic LDS bytes, out[5] = 1 if indices are staged in LDS. */
+ * out[4] = dynamic LDS bytes, out[5] = 1 if indices are staged in LDS, 2 if the batch is small enough for the
+ * wide-load kernel (one sample per workgroup, the bag's rows parked in LDS; out[2] = 1, out[3] = batch_size). */
 void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width, int batch_size,
                                   int num_hots, int is_csr, int is_weighted, int mode,
                                   int* out);

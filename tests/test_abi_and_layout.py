@@ -61,7 +61,7 @@ def test_launch_shapes_of_baseline_configs():
     # C2: 512-byte fp16 rows -> 32 lanes x 16 B, two samples per wavefront, 8 per workgroup
     s = ce.forward_launch_shape(torch.float16, torch.int32, 256, 65536, 64)
     assert s == dict(elems_per_lane=8, lanes_per_row=32, samples_per_block=8, grid=8192,
-                     lds_bytes=8 * 64 * 4, staged=True)
+                     lds_bytes=8 * 64 * 4, staged=True, wide_load=False)
     # C1: 128-byte fp32 rows -> 8 lanes, 32 samples per workgroup
     s = ce.forward_launch_shape(torch.float32, torch.int32, 32, 1024, 8)
     assert (s["elems_per_lane"], s["lanes_per_row"], s["samples_per_block"], s["grid"]) == (4, 8, 32, 32)
@@ -72,6 +72,27 @@ def test_launch_shapes_of_baseline_configs():
     assert ce.forward_launch_shape(torch.float32, torch.int32, 514, 8, 4)["elems_per_lane"] == 2
     assert ce.forward_launch_shape(torch.float16, torch.int32, 514, 8, 4)["elems_per_lane"] == 2
     assert ce.forward_launch_shape(torch.float32, torch.int32, 3, 8, 4)["elems_per_lane"] == 1
+    # small batches: the wide-load kernel (one sample per workgroup, 8 x slices rows parked in LDS = 32 KB with 16-byte
+    # lanes) -- CSR up to 1,024 samples (2,048 for rows <= 128 bytes), fixed hotness from 32 lookups per sample while the
+    # sequential mapping has at most min(256, 2 x hotness) wavefronts; never for concat, rows > 1 KiB or odd lane counts
+    wide = ce.forward_launch_shape(torch.float32, torch.int32, 32, 1024, 64)
+    assert wide["wide_load"] and (wide["samples_per_block"], wide["grid"], wide["lds_bytes"]) == (1, 1024, 32768)
+    assert ce.forward_launch_shape(torch.float16, torch.int32, 256, 256, 64, is_weighted=True)["lds_bytes"] == 32768 + 64 * 2
+    for args, kw, want in [((torch.float32, torch.int32, 32, 1024, 16), {}, False),        # too few lookups per sample
+                           ((torch.float32, torch.int32, 32, 1024, 32), {}, False),        # 128 wavefronts > 2 x 32
+                           ((torch.float32, torch.int32, 32, 512, 32), {}, True),
+                           ((torch.float32, torch.int32, 32, 2048, 256), {}, True),        # 256 wavefronts
+                           ((torch.float32, torch.int32, 32, 4096, 256), {}, False),
+                           ((torch.float16, torch.int32, 256, 1024, 64), {}, False),       # 512 wavefronts
+                           ((torch.float16, torch.int32, 256, 256, 64), {}, True),
+                           ((torch.float16, torch.int32, 256, 1024, 0), dict(is_csr=True), True),
+                           ((torch.float16, torch.int32, 256, 1025, 0), dict(is_csr=True), False),
+                           ((torch.float32, torch.int32, 32, 2048, 0), dict(is_csr=True), True),
+                           ((torch.float32, torch.int32, 32, 2049, 0), dict(is_csr=True), False),
+                           ((torch.float32, torch.int32, 512, 16, 64), {}, False),         # 2 KiB rows
+                           ((torch.float32, torch.int32, 100, 16, 64), {}, False),         # 25 lanes
+                           ((torch.float32, torch.int32, 32, 16, 64), dict(mode="concat"), False)]:
+        assert ce.forward_launch_shape(*args, **kw)["wide_load"] == want, (args, kw)
 
 
 def test_backward_planner_follows_the_device_it_is_told_about():
