@@ -31,7 +31,8 @@ for B in (16, 256, 1024, 2048, 4096, 8192):
                     lens = torch.randint(0, 2 * H + 1, (B,), device="cuda")
                     offsets = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
                     offsets[1:] = torch.cumsum(lens, 0)
-                    idx = torch.randint(0, rows, (int(offsets[-1].item()),), device="cuda", dtype=torch.int32)
+                    nnz = int(offsets[-1].item())     # (the same power-law stream as the fixed layout, cut into ragged bags)
+                    idx = torch.from_numpy(harness.generate_indices(rows, max(nnz, 1), 1, alpha=1.05).astype(np.int32)).cuda().view(-1)[:nnz]
                 outs, times = {}, {}
                 for mode in ("never", "always", "auto"):
                     ce.set_forward_wide_load(mode)
