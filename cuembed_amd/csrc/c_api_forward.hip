@@ -138,13 +138,16 @@ void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width
   // small batches of sum / mean lookups: the wide-load kernel (one sample per workgroup, rows parked in LDS)
   const size_t elem_bytes = elem_type == CUEMBED_F32 ? 4 : 2;
   const size_t row_bytes = static_cast<size_t>(embed_width) * elem_bytes;
-  if (!concat && cuembed::GetForwardReductionOrder() == cuembed::ReductionOrder::kSequential &&
-      cuembed::detail::ForwardWideLoadPays(f.split.lanes_per_row, row_bytes, batch_size, num_hots, is_csr != 0)) {
+  const int wide = (!concat && cuembed::GetForwardReductionOrder() == cuembed::ReductionOrder::kSequential)
+                       ? cuembed::detail::ForwardWideLoadSamples(f.split.lanes_per_row, row_bytes, batch_size, num_hots,
+                                                                 is_csr != 0)
+                       : 0;
+  if (wide > 0) {
     const size_t chunk = static_cast<size_t>(cuembed::detail::kForwardUnroll) *
-                         (cuembed::detail::kWideLoadThreads / f.split.lanes_per_row);
-    out[2] = 1;
-    out[3] = batch_size;
-    out[4] = static_cast<int>(chunk * row_bytes + (is_weighted ? chunk * elem_bytes : 0));
+                         (cuembed::detail::kWideLoadThreads / (f.split.lanes_per_row * wide));
+    out[2] = wide;
+    out[3] = (batch_size + wide - 1) / wide;
+    out[4] = static_cast<int>(wide * (chunk * row_bytes + (is_weighted ? chunk * elem_bytes : 0)));
     out[5] = 2;
   }
 }
@@ -193,7 +196,7 @@ int cuembed_get_forward_row_load_policy(void) {
   return static_cast<int>(cuembed::GetForwardRowLoadPolicy());
 }
 void cuembed_set_forward_wide_load(int mode) {
-  CUEMBED_ASSERT(mode >= 0 && mode <= 2);
+  CUEMBED_ASSERT(mode >= 0 && mode <= 8);
   cuembed::SetForwardWideLoad(mode);
 }
 

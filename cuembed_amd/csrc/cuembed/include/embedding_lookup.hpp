@@ -82,8 +82,9 @@ inline std::atomic<int>& ForwardRowLoadCell() {
 }  // namespace detail
 
 namespace detail {
-//! Tuning / tests only (results never depend on it): 0 = the launcher decides, 1 = never the wide-load kernel for small
-//! batches, 2 = whenever its shape allows it.
+//! Tuning / tests only (results never depend on it): 0 = the launcher decides, 1 = never the wide-load kernel, 2 = whenever
+//! its shape allows it with one sample per workgroup, 3 / 4 / 5 / ... = with 2 / 4 / 8 / ... samples per workgroup (as far as
+//! the row allows).
 inline std::atomic<int>& ForwardWideLoadCell() {
   static std::atomic<int> cell{0};
   return cell;
@@ -214,18 +215,40 @@ inline ForwardLaunch PlanForward(const int embed_width, const void* params, cons
 //!             wavefronts (1,024 x 64 lookups of 128-byte rows 4.6 -> 4.2 us, 256 x 64 of 512-byte rows 5.0 -> 4.1,
 //!             1,024 x 256 of 128-byte rows 15.2 -> 8.2); below 32 lookups per sample the sequential kernel is at the
 //!             launch floor and the wide one 0.5-1 us above it.
-inline bool ForwardWideLoadPays(const int lanes, const size_t row_bytes, const int batch, const int num_hots,
-                                const bool is_csr) {
+//! Returns the samples per workgroup (a power of two; 1 = the shapes above), or 0 when the sequential kernel is taken.
+//!   CSR, larger batches of narrow rows: several samples per workgroup, lanes x slices threads and a part of the LDS
+//!             each (a sample needs one thread per 32-bit word of the row for the pooling), as many as keep the grid at
+//!             kWideLoadCsrBatch workgroups, while samples x row bytes <= 512.
+inline int ForwardWideLoadSamples(const int lanes, const size_t row_bytes, const int batch, const int num_hots,
+                                  const bool is_csr) {
   const int mode = ForwardWideLoadCell().load(std::memory_order_relaxed);
   const bool shape_ok = lanes >= 1 && lanes <= kWideLoadThreads && kWideLoadThreads % lanes == 0 && batch > 0 &&
-                        row_bytes <= static_cast<size_t>(kWideLoadMaxRowBytes);
-  if (!shape_ok || mode == 1) return false;
-  if (mode == 2) return true;
-  if (is_csr) return batch <= (row_bytes <= 128 ? 2 * kWideLoadCsrBatch : kWideLoadCsrBatch);
+                        row_bytes >= 4 && row_bytes <= static_cast<size_t>(kWideLoadMaxRowBytes);
+  if (!shape_ok || mode == 1) return 0;
+  int most = 1;   // samples a workgroup can hold: one pooling thread per word of the row, for every sample
+  while (most * 2 * (row_bytes / 4) <= static_cast<size_t>(kWideLoadThreads) && most * 2 * lanes <= kWideLoadThreads) most *= 2;
+  if (mode >= 2) {                       // forced: 2 -> 1 sample per workgroup, 3 -> 2, 4 -> 4, ...
+    const int want = 1 << (mode - 2);
+    return want < most ? want : most;
+  }
+  if (is_csr) {
+    // measured (profiles/r05_csr_mid_batch_forward_probe.csv): several samples per workgroup pay while samples x row
+    // bytes <= 512 -- 4,096 bags of 128-byte rows 13.6 -> 8.9 us (4 per workgroup), 8,192 bags of 64-byte rows 27 -> 12;
+    // 256-byte rows gain with 2 (2,048 bags: 10.6 -> 9.2) and lose with 4, 512-byte rows lose with 2 (13 -> 19)
+    const int allowed = static_cast<int>(512 / row_bytes) > 1 ? static_cast<int>(512 / row_bytes) : 1;
+    int samples = 1;
+    while (samples < most && samples < allowed && (batch + samples - 1) / samples > kWideLoadCsrBatch) samples *= 2;
+    const int64_t limit = row_bytes <= 128 && samples == 1 ? 2 * kWideLoadCsrBatch : kWideLoadCsrBatch;
+    return (batch + samples - 1) / samples <= limit ? samples : 0;
+  }
   const int64_t waves = static_cast<int64_t>(batch) * lanes / 64;
   const int64_t limit = 2 * static_cast<int64_t>(num_hots) < kWideLoadMaxWaves ? 2 * static_cast<int64_t>(num_hots)
                                                                               : kWideLoadMaxWaves;
-  return num_hots >= kWideLoadMinHotness && waves <= limit;
+  return num_hots >= kWideLoadMinHotness && waves <= limit ? 1 : 0;
+}
+inline bool ForwardWideLoadPays(const int lanes, const size_t row_bytes, const int batch, const int num_hots,
+                                const bool is_csr) {
+  return ForwardWideLoadSamples(lanes, row_bytes, batch, num_hots, is_csr) > 0;
 }
 
 template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N>
@@ -251,16 +274,19 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
     return;
   }
   // small batches, bit-exact: one sample per workgroup, a bag's loads spread over all of its threads, the adds in order
-  if (ForwardWideLoadPays(lanes, static_cast<size_t>(width) * sizeof(ElemT), batch, num_hots, offsets != nullptr)) {
-    const dim3 wblock(lanes, kWideLoadThreads / lanes, 1);
-    const size_t chunk = static_cast<size_t>(kForwardUnroll) * (kWideLoadThreads / lanes);
-    const size_t lds = chunk * lanes * sizeof(Pack<ElemT, N>) + (weighted ? chunk * sizeof(ElemT) : 0);
+  if (const int samples = ForwardWideLoadSamples(lanes, static_cast<size_t>(width) * sizeof(ElemT), batch, num_hots,
+                                                 offsets != nullptr)) {
+    const int slices = kWideLoadThreads / (lanes * samples);
+    const dim3 wblock(lanes, slices, samples);
+    const dim3 wgrid(static_cast<unsigned>((batch + samples - 1) / samples), 1, 1);
+    const size_t chunk = static_cast<size_t>(kForwardUnroll) * slices;
+    const size_t lds = samples * (chunk * lanes * sizeof(Pack<ElemT, N>) + (weighted ? chunk * sizeof(ElemT) : 0));
     if (weighted)
-      GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, true><<<dim3(batch, 1, 1), wblock, lds, stream>>>(
-          table, width, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
+      GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, true><<<wgrid, wblock, lds, stream>>>(
+          table, width, batch, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
     else
-      GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, false><<<dim3(batch, 1, 1), wblock, lds, stream>>>(
-          table, width, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
+      GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, false><<<wgrid, wblock, lds, stream>>>(
+          table, width, batch, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
     return;
   }
   const dim3 block(f.split.lanes_per_row, f.split.rows_per_block, 1);

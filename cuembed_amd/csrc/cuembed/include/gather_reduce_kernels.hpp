@@ -550,8 +550,9 @@ GatherReduceSplitKernel(const ElemT* __restrict__ table,
 // ---------------------------------------------------------------------------
 // Sum / mean for SMALL batches, BIT-EXACT: one sample per 256-thread workgroup, the LOADS of a bag spread over the
 // whole workgroup, the ADDS kept in lookup order.
-//   block = (lanes_per_row, slices) with lanes_per_row * slices = 256; grid = batch; rows of at most 1 KiB
-//   dynamic LDS = kForwardUnroll * slices rows (+ as many weights): 32 KB with 16-byte lanes
+//   block = (lanes_per_row, slices, samples) with lanes_per_row * slices * samples = 256; grid = ceil(batch / samples);
+//   rows of at most 1 KiB; dynamic LDS = kForwardUnroll * slices rows (+ as many weights) per sample: 32 KB with
+//   16-byte lanes whatever the split
 // With few samples the sequential kernel leaves most of the chip idle and walks a bag in rounds of kForwardUnroll
 // rows, one memory round trip each (1024 samples x 64 lookups of 128-byte rows: 8 rounds).  Here slice s of the
 // workgroup requests lookups s, s + slices, ... -- kForwardUnroll x slices rows (64 for 512-byte rows, 256 for
@@ -566,33 +567,52 @@ constexpr int kWideLoadMaxRowBytes = 4 * kWideLoadThreads;   // one 32-bit word 
 
 template <typename ElemT, typename AccT, typename IndexT, typename OffsetT, int N, bool kWeighted>
 __global__ void __launch_bounds__(kWideLoadThreads)
-GatherReduceWideLoadKernel(const ElemT* __restrict__ table, const int width, const IndexT* __restrict__ indices,
-                           const OffsetT* __restrict__ offsets,  // null => fixed hotness
+GatherReduceWideLoadKernel(const ElemT* __restrict__ table, const int width, const int batch,
+                           const IndexT* __restrict__ indices, const OffsetT* __restrict__ offsets,  // null => fixed hotness
                            const int num_hots, const ElemT* __restrict__ weights, const bool is_mean,
                            ElemT* __restrict__ out, const bool stream_rows) {
   using A = Arith<AccT>;
   constexpr int kWordElems = 4 / static_cast<int>(sizeof(ElemT));   // elements in a 32-bit word: 1 (fp32) or 2
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds_raw[];
+  __shared__ int longest_bag;
+  // block = (lanes, slices, samples): `samples` > 1 (narrow rows, larger batches) gives every sample of the workgroup
+  // lanes x slices threads of its own and its own part of the LDS; the samples only meet at the barriers
   const int lane_x = threadIdx.x;
   const int lanes = blockDim.x;
   const int slice = threadIdx.y;
   const int slices = blockDim.y;
-  const int tid = slice * lanes + lane_x;
-  const int64_t sample = blockIdx.x;
-  int64_t begin;
-  int hot = num_hots;
-  if (offsets != nullptr) {
-    begin = static_cast<int64_t>(offsets[sample]);
-    hot = static_cast<int>(static_cast<int64_t>(offsets[sample + 1]) - begin);
-  } else {
-    begin = sample * num_hots;
+  const int sub = threadIdx.z;
+  const int samples = blockDim.z;
+  const int team = lanes * slices;             // threads of one sample
+  const int tid = slice * lanes + lane_x;      // ... and this thread among them
+  const int64_t sample = static_cast<int64_t>(blockIdx.x) * samples + sub;
+  const bool present = sample < batch;
+  int64_t begin = 0;
+  int hot = 0;
+  if (present) {
+    if (offsets != nullptr) {
+      begin = static_cast<int64_t>(offsets[sample]);
+      hot = static_cast<int>(static_cast<int64_t>(offsets[sample + 1]) - begin);
+    } else {
+      begin = sample * num_hots;
+      hot = num_hots;
+    }
   }
-  const int chunk = kForwardUnroll * slices;   // lookups parked in LDS at a time
-  Pack<ElemT, N>* stage = reinterpret_cast<Pack<ElemT, N>*>(wide_lds_raw);       // [chunk][lanes]
-  ElemT* stage_w = reinterpret_cast<ElemT*>(stage + static_cast<size_t>(chunk) * lanes);   // [chunk]
-  const Pack<ElemT, kWordElems>* stage_words = reinterpret_cast<const Pack<ElemT, kWordElems>*>(wide_lds_raw);
-  const int row_words = width / kWordElems;    // <= kWideLoadThreads (the launcher's condition)
-  const bool pools = tid < row_words;
+  int rounds_for = hot;                        // every sample of the workgroup takes part in every round's barriers
+  if (samples > 1) {
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) longest_bag = 0;
+    __syncthreads();
+    if (tid == 0) atomicMax(&longest_bag, hot);
+    __syncthreads();
+    rounds_for = longest_bag;
+  }
+  const int chunk = kForwardUnroll * slices;   // lookups of one sample parked in LDS at a time
+  Pack<ElemT, N>* stage = reinterpret_cast<Pack<ElemT, N>*>(wide_lds_raw) + static_cast<size_t>(sub) * chunk * lanes;  // [chunk][lanes]
+  ElemT* stage_w = reinterpret_cast<ElemT*>(reinterpret_cast<Pack<ElemT, N>*>(wide_lds_raw) +
+                                            static_cast<size_t>(samples) * chunk * lanes) + static_cast<size_t>(sub) * chunk;
+  const Pack<ElemT, kWordElems>* stage_words = reinterpret_cast<const Pack<ElemT, kWordElems>*>(stage);
+  const int row_words = width / kWordElems;    // <= team (the launcher's condition)
+  const bool pools = present && tid < row_words;
   const IndexT* my_idx = indices + begin;
   const ElemT* my_w = weights + begin;
   const ElemT* lane_base = table + static_cast<int64_t>(lane_x) * N;
@@ -600,25 +620,28 @@ GatherReduceWideLoadKernel(const ElemT* __restrict__ table, const int width, con
 #pragma unroll
   for (int e = 0; e < kWordElems; ++e) acc[e] = static_cast<AccT>(0);
   float weight_sum = 0.f;
-  for (int c0 = 0; c0 < hot; c0 += chunk) {
-    const int n = hot - c0 < chunk ? hot - c0 : chunk;
-    Pack<ElemT, N> row[kForwardUnroll];
-    // (unconditional loads on a clamped lookup: a predicate per element would make the compiler merge the register
-    // array at every branch; what a clamped lookup fetched is simply not parked)
+  for (int c0 = 0; c0 < rounds_for; c0 += chunk) {
+    const int left = hot - c0;
+    const int n = left < 0 ? 0 : (left < chunk ? left : chunk);
+    if (n > 0) {
+      Pack<ElemT, N> row[kForwardUnroll];
+      // (unconditional loads on a clamped lookup: a predicate per element would make the compiler merge the register
+      // array at every branch; what a clamped lookup fetched is simply not parked)
 #pragma unroll
-    for (int u = 0; u < kForwardUnroll; ++u) {
-      const int j = slice + u * slices;
-      const int64_t r = WidenIndex(my_idx[c0 + (j < n ? j : 0)]);
-      const ElemT* p = RowPtr(lane_base, r, width);
-      row[u] = stream_rows ? LoadPackStreaming<ElemT, N>(p) : LoadPack<ElemT, N>(p);
-    }
-    if constexpr (kWeighted) {
-      for (int j = tid; j < n; j += kWideLoadThreads) stage_w[j] = my_w[c0 + j];
-    }
+      for (int u = 0; u < kForwardUnroll; ++u) {
+        const int j = slice + u * slices;
+        const int64_t r = WidenIndex(my_idx[c0 + (j < n ? j : 0)]);
+        const ElemT* p = RowPtr(lane_base, r, width);
+        row[u] = stream_rows ? LoadPackStreaming<ElemT, N>(p) : LoadPack<ElemT, N>(p);
+      }
+      if constexpr (kWeighted) {
+        for (int j = tid; j < n; j += team) stage_w[j] = my_w[c0 + j];
+      }
 #pragma unroll
-    for (int u = 0; u < kForwardUnroll; ++u) {
-      const int j = slice + u * slices;
-      if (j < n) stage[static_cast<size_t>(j) * lanes + lane_x] = row[u];
+      for (int u = 0; u < kForwardUnroll; ++u) {
+        const int j = slice + u * slices;
+        if (j < n) stage[static_cast<size_t>(j) * lanes + lane_x] = row[u];
+      }
     }
     __syncthreads();
     if (pools) {

@@ -83,8 +83,10 @@ def set_forward_row_load_policy(policy):
 def set_forward_wide_load(mode="auto"):
     """Tuning / tests (never changes a result): whether small batches take the wide-load forward kernel (one sample per
     workgroup, a bag's rows requested at once, pooled in lookup order) -- "auto" (the launcher decides), "never", "always"
-    (whenever the row shape allows it)."""
-    _lib.lib().cuembed_set_forward_wide_load({"auto": 0, "never": 1, "always": 2}[mode])
+    (whenever the row shape allows it), "always2" / "always4" / ... (with that many samples per workgroup, as far as the row
+    allows)."""
+    codes = {"auto": 0, "never": 1, "always": 2, "always2": 3, "always4": 4, "always8": 5, "always16": 6}
+    _lib.lib().cuembed_set_forward_wide_load(codes[mode])
 
 
 def get_forward_row_load_policy():

@@ -372,7 +372,8 @@ int cuembed_get_forward_row_load_policy(void);
 /* cuembed::SetForwardWideLoad (tuning / tests; never changes a result).  Small batches of sum / mean lookups take a
  * kernel with one sample per workgroup that requests a whole bag's rows at once and pools them in lookup order out of LDS
  * (bit-identical to the sequential kernel; the reference has one mapping for every batch size,
- * embedding_lookup.cuh:186-208).  0 = the launcher decides (default), 1 = never, 2 = whenever the row shape allows it. */
+ * embedding_lookup.cuh:186-208).  0 = the launcher decides (default), 1 = never, 2 = whenever the row shape allows it,
+ * 3 / 4 / 5 / ... = likewise with 2 / 4 / 8 / ... samples sharing a workgroup (narrow rows; as far as the row allows). */
 void cuembed_set_forward_wide_load(int mode);
 /* cuembed_embedding_forward with per-call options (cuembed::ForwardOptions): reduction_order 0 / 1,
  * row_load_policy 0 / 1, or -1 = the process-wide default.  No state is read or written when both are >= 0. */
@@ -411,7 +412,7 @@ void cuembed_get_backward_tuning(int* out2);
 /* Launch shape the forward would use (no launch): out[0] = elements per lane,
  * out[1] = lanes per row, out[2] = samples per workgroup, out[3] = grid size,
  * out[4] = dynamic LDS bytes, out[5] = 1 if indices are staged in LDS, 2 if the batch is small enough for the
- * wide-load kernel (one sample per workgroup, the bag's rows parked in LDS; out[2] = 1, out[3] = batch_size). */
+ * wide-load kernel (out[2] = 1, or a few samples of narrow rows, per workgroup; the bags' rows parked in LDS). */
 void cuembed_forward_launch_shape(int elem_type, int index_type, int embed_width, int batch_size,
                                   int num_hots, int is_csr, int is_weighted, int mode,
                                   int* out);

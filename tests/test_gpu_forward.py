@@ -347,8 +347,8 @@ def test_forward_sample_order_is_a_scheduling_hint_only(oracle, dtype, index_dty
 @pytest.mark.parametrize("W", [1, 2, 6, 8, 32, 64, 100, 128, 256], ids=lambda w: "w%d" % w)
 def test_forward_wide_load_small_batches_same_bits(ce, oracle, elem, fp16_math, W):
     """Small batches take GatherReduceWideLoadKernel (one sample per workgroup, a bag's rows requested at once, pooled in
-    lookup order out of LDS): forced on ("always") wherever the row shape allows it and forced off ("never"), both must
-    give the oracle's bits -- sum / mean, weighted, fixed hotness (also longer than one LDS chunk) and ragged CSR bags
+    lookup order out of LDS): forced on ("always", and with several samples sharing a workgroup) wherever the row shape
+    allows it and forced off ("never"), all must give the oracle's bits -- sum / mean, weighted, fixed hotness (also longer than one LDS chunk) and ragged CSR bags
     with empty ones, rows from 4 bytes to 1 KiB incl. widths whose lanes do not divide 256 (those stay sequential)."""
     if elem[0] == np.float16 and W % 2:
         pytest.skip("row bytes must be a multiple of 4")
@@ -369,7 +369,7 @@ def test_forward_wide_load_small_batches_same_bits(ce, oracle, elem, fp16_math, 
                                                 mode=mode, fp16_math=fp16_math)
                 want_csr = oracle.embedding_forward(table, idx_csr, off, w_csr if weighted else None, num_hots=0, mode=mode,
                                                     fp16_math=fp16_math)
-                for force in ("always", "never", "auto"):
+                for force in ("always", "always2", "always4", "always16", "never", "auto"):   # 1 / 2 / 4 / 16 samples per workgroup
                     ce.set_forward_wide_load(force)
                     got = ce.embedding_forward(dev(table), dev(idx.ravel()), None, dev(w.ravel()) if weighted else None,
                                                num_hots=H, mode=mode, fp16_math=fp16_math)
