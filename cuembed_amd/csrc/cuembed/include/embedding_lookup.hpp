@@ -218,7 +218,7 @@ inline ForwardLaunch PlanForward(const int embed_width, const void* params, cons
 //! Returns the samples per workgroup (a power of two; 1 = the shapes above), or 0 when the sequential kernel is taken.
 //!   CSR, larger batches of narrow rows: several samples per workgroup, lanes x slices threads and a part of the LDS
 //!             each (a sample needs one thread per 32-bit word of the row for the pooling), as many as keep the grid at
-//!             kWideLoadCsrBatch workgroups, while samples x row bytes <= 512.
+//!             kWideLoadCsrBatch workgroups, while samples x row bytes <= 1024 (rows of up to 128 bytes) or 512.
 inline int ForwardWideLoadSamples(const int lanes, const size_t row_bytes, const int batch, const int num_hots,
                                   const bool is_csr) {
   const int mode = ForwardWideLoadCell().load(std::memory_order_relaxed);
@@ -233,9 +233,11 @@ inline int ForwardWideLoadSamples(const int lanes, const size_t row_bytes, const
   }
   if (is_csr) {
     // measured (profiles/r05_csr_mid_batch_forward_probe.csv): several samples per workgroup pay while samples x row
-    // bytes <= 512 -- 4,096 bags of 128-byte rows 13.6 -> 8.9 us (4 per workgroup), 8,192 bags of 64-byte rows 27 -> 12;
-    // 256-byte rows gain with 2 (2,048 bags: 10.6 -> 9.2) and lose with 4, 512-byte rows lose with 2 (13 -> 19)
-    const int allowed = static_cast<int>(512 / row_bytes) > 1 ? static_cast<int>(512 / row_bytes) : 1;
+    // bytes <= 1024 for rows of up to 128 bytes -- 4,096 bags of 128-byte rows 13.6 -> 8.9 us (4 per workgroup), 8,192
+    // bags 19.2 -> 18.5 (fp16: 24.8 -> 19.1; 8), 16,384 bags of 64-byte rows 32 -> 20 (16) -- and <= 512 beyond: 256-byte
+    // rows gain with 2 (2,048 bags: 10.6 -> 9.2) and lose with 4 (15.0 -> 17.5), 512-byte rows lose with 2 (13 -> 19)
+    const int budget = row_bytes <= 128 ? 1024 : 512;
+    const int allowed = static_cast<int>(budget / row_bytes) > 1 ? static_cast<int>(budget / row_bytes) : 1;
     int samples = 1;
     while (samples < most && samples < allowed && (batch + samples - 1) / samples > kWideLoadCsrBatch) samples *= 2;
     const int64_t limit = row_bytes <= 128 && samples == 1 ? 2 * kWideLoadCsrBatch : kWideLoadCsrBatch;

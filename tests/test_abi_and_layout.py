@@ -87,18 +87,20 @@ def test_launch_shapes_of_baseline_configs():
                            ((torch.float16, torch.int32, 256, 256, 64), {}, True),
                            ((torch.float16, torch.int32, 256, 1024, 0), dict(is_csr=True), True),
                            ((torch.float16, torch.int32, 256, 1025, 0), dict(is_csr=True), False),   # 512-byte rows: 1 sample per workgroup only
-                           ((torch.float32, torch.int32, 32, 4096, 0), dict(is_csr=True), True),     # 128-byte rows: up to 4
-                           ((torch.float32, torch.int32, 32, 4097, 0), dict(is_csr=True), False),
+                           ((torch.float32, torch.int32, 32, 8192, 0), dict(is_csr=True), True),     # 128-byte rows: up to 8
+                           ((torch.float32, torch.int32, 32, 8193, 0), dict(is_csr=True), False),
                            ((torch.float32, torch.int32, 64, 2048, 0), dict(is_csr=True), True),     # 256-byte rows: up to 2
                            ((torch.float32, torch.int32, 64, 2049, 0), dict(is_csr=True), False),
                            ((torch.float32, torch.int32, 512, 16, 64), {}, False),         # 2 KiB rows
                            ((torch.float32, torch.int32, 100, 16, 64), {}, False),         # 25 lanes
                            ((torch.float32, torch.int32, 32, 16, 64), dict(mode="concat"), False)]:
         assert ce.forward_launch_shape(*args, **kw)["wide_load"] == want, (args, kw)
-    # CSR batches of narrow rows beyond 1,024 samples: several samples per workgroup while samples x row bytes <= 512
+    # CSR batches of narrow rows beyond 1,024 samples: several samples per workgroup while samples x row bytes <= 1024
+    # (rows of up to 128 bytes) or 512 (wider ones)
     many = ce.forward_launch_shape(torch.float32, torch.int32, 32, 4000, 0, is_csr=True)
     assert many["wide_load"] and (many["samples_per_block"], many["grid"], many["lds_bytes"]) == (4, 1000, 32768)
     assert ce.forward_launch_shape(torch.float32, torch.int32, 8, 16384, 0, is_csr=True)["samples_per_block"] == 16
+    assert ce.forward_launch_shape(torch.float32, torch.int32, 8, 32768, 0, is_csr=True)["samples_per_block"] == 32
 
 
 def test_backward_planner_follows_the_device_it_is_told_about():
