@@ -103,6 +103,25 @@ def test_launch_shapes_of_baseline_configs():
     assert ce.forward_launch_shape(torch.float32, torch.int32, 8, 32768, 0, is_csr=True)["samples_per_block"] == 32
 
 
+def test_backward_column_slices_follow_the_lookup_count():
+    """ChooseColumnSlices: no slices below 2^17 lookups, slices of >= 256 bytes from there, of >= 128 bytes from 2^20 on
+    (measured: profiles/r05_backward_mid_size_slices.txt); never more than one per XCD, never on a single-XCD partition."""
+    import torch
+    import cuembed_amd as ce
+
+    def slices(dtype, width, nnz, **kw):
+        return ce.backward_launch_shape(dtype, torch.int32, width, nnz, compute_units=256, xcds=8, **kw)["column_slices"]
+    for nnz, want_512, want_1k, want_256 in [((1 << 17) - 1, 1, 1, 1), (1 << 17, 2, 4, 1), ((1 << 20) - 1, 2, 4, 1),
+                                             (1 << 20, 4, 8, 2), (1 << 24, 4, 8, 2)]:
+        assert slices(torch.float16, 256, nnz) == want_512, nnz          # 512-byte rows
+        assert slices(torch.float32, 128, nnz) == want_512, nnz
+        assert slices(torch.float32, 256, nnz) == want_1k, nnz           # 1 KiB rows
+        assert slices(torch.float32, 64, nnz) == want_256, nnz           # 256-byte rows
+        assert slices(torch.float32, 32, nnz) == 1, nnz                  # 128-byte rows are one L2 line
+    assert ce.backward_launch_shape(torch.float16, torch.int32, 256, 1 << 22, compute_units=32, xcds=1)["column_slices"] == 1
+    assert ce.backward_launch_shape(torch.float32, torch.int32, 1024, 1 << 22, compute_units=128, xcds=4)["column_slices"] == 4
+
+
 def test_backward_planner_follows_the_device_it_is_told_about():
     """The launch heuristics take the chip's shape from the device (cuembed::detail::DeviceShape; the reference asks
     the runtime per call, embedding_lookup.cuh:348-395) instead of assuming a full MI355X.  Host arithmetic only:
