@@ -147,7 +147,7 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
     ZeroSharedAndTailRowsKernel<GradT, IndexT>
         <<<static_cast<unsigned>(per_launch * launches + tail_blocks), 256, 0, stream>>>(
             rows, nnz, block_len, per_launch, launch_len, launches, width, zero_rows, grad_out, pair_rows,
-            capacity_rows, pad_to_capacity ? run_ids : nullptr, pad_to_capacity ? inverse_mapping : nullptr);
+            capacity_rows, pad_to_capacity);
   }
   int seg_shift = -1;
   if ((s.segment_len & (s.segment_len - 1)) == 0)
@@ -174,6 +174,11 @@ inline void LaunchScatterAdd(const GradT* grad_y, int width, const IndexT* rows,
       else CUEMBED_LAUNCH_SCATTER(false, false, kBackwardWindowMisses);
     }
 #undef CUEMBED_LAUNCH_SCATTER
+  }
+  if (pad_to_capacity && zero_rows > 0) {   // the zeroed rows past the count get their row ids (see NamePaddedRowsKernel)
+    const int64_t blocks = (zero_rows + 255) / 256;
+    NamePaddedRowsKernel<IndexT><<<static_cast<unsigned>(blocks < 1024 ? blocks : 1024), 256, 0, stream>>>(
+        rows, nnz, inverse_mapping, zero_rows);
   }
 }
 
@@ -229,7 +234,7 @@ inline int RecommendedSampleBlocks(const int embed_width, const int batch_size, 
  * zeroed once; may be null) is OR-ed with 1 -- a flag to read back whenever convenient instead of a silent overrun.
  * 0 = unchecked, the reference's contract.  `pad_to_capacity` (with capacity_rows > 0, a device-side count and
  * skip_grad_init = false): the rows from the count up to the capacity are ZEROED and their inverse_mapping entries set
- * to the batch's smallest table row, so that (inverse_mapping, grad_embedding) over all capacity_rows entries is a
+ * to rows of the batch (different ones, in turn), so that (inverse_mapping, grad_embedding) over all capacity_rows entries is a
  * valid uncoalesced COO gradient -- coalescing it gives the reference's -- that a caller can hand on without ever
  * reading the count back (the torch op does, for small batches).
  *

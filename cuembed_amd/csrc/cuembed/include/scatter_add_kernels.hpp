@@ -567,6 +567,23 @@ inline int64_t ZeroTailBlocks(const int64_t zero_rows, const DeviceShape& dev) {
   return pieces < cap ? pieces : cap;
 }
 
+//! Padded gradient (EmbeddingBackward(..., pad_to_capacity)): the rows past the device-side count are zero (the kernel
+//! below) and must NAME rows so that (inverse_mapping, grad) over all num_rows entries is a valid uncoalesced COO
+//! gradient.  They name rows of the batch itself -- a consumer with per-row state then touches no row the batch did not --
+//! and DIFFERENT ones: entry i names the row of entry (i - unique) mod unique, i.e. every looked-up row gets at most
+//! ceil(padding / unique) extra zero entries.  (Naming one row for the whole tail, as a first version did, makes
+//! torch's coalesce() and index_add_ serialise tens of thousands of adds on that row: 46 ms for a 65,536-entry gradient.)
+//! Launched after the scatter, which writes inverse_mapping[0, unique).
+template <typename IndexT>
+__global__ void __launch_bounds__(256)
+NamePaddedRowsKernel(const IndexT* __restrict__ dense_ids /* sorted; the last one is unique - 1 */, const int64_t nnz,
+                     IndexT* __restrict__ inverse_mapping, const int64_t num_rows) {
+  const int64_t unique = static_cast<int64_t>(dense_ids[nnz - 1]) + 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = unique + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < num_rows; i += stride)
+    inverse_mapping[i] = inverse_mapping[(i - unique) % unique];
+}
+
 template <typename GradT, typename IndexT>
 __global__ void __launch_bounds__(256)
 ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, const int block_len,
@@ -574,8 +591,7 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
                             const int sample_blocks, const int width, const int64_t num_rows,
                             GradT* __restrict__ grad_out, const uint32_t* __restrict__ block_row_ids,
                             const int64_t capacity_rows,
-                            const IndexT* __restrict__ pad_ids /* not null: table row ids (sorted); the tail of ... */,
-                            IndexT* __restrict__ pad_inverse_mapping /* ... this array is filled with pad_ids[0] */) {
+                            const bool pad_tail /* padded gradient: the rows past the last id are zeroed up to num_rows */) {
   // sample-blocked order: `rows` holds pair numbers, block_row_ids[pair] the gradient row | kSharedRowBit
   auto row_of = [&](const int64_t g) -> int64_t {
     const uint32_t r = static_cast<uint32_t>(rows[g]);
@@ -612,14 +628,7 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
   char* const p0 = reinterpret_cast<char*>(grad_out + (last_id + 1) * width);
   char* const p1 = reinterpret_cast<char*>(grad_out + num_rows * width);
   if (p0 >= p1) return;
-  if (pad_ids != nullptr) {
-    // padded gradient: the rows past the last id are zero and name a row that IS in the batch (its smallest), so that
-    // (inverse_mapping, grad_out) is a valid uncoalesced COO gradient over ALL num_rows entries
-    const IndexT first_row = pad_ids[0];
-    const int64_t tail_workers = (static_cast<int64_t>(gridDim.x) - num_blocks) * blockDim.x;
-    for (int64_t i = last_id + 1 + (b - num_blocks) * blockDim.x + threadIdx.x; i < num_rows; i += tail_workers)
-      pad_inverse_mapping[i] = first_row;
-  }
+  (void)pad_tail;   // (the tail's row ids are written after the scatter: NamePaddedRowsKernel)
   char* a0 = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p0) + 15) & ~uintptr_t{15});
   char* a1 = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(p1) & ~uintptr_t{15});
   if (a0 > p1) a0 = p1;

@@ -22,6 +22,7 @@
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
+#include <cstdlib>
 #include <string>
 #include <tuple>
 
@@ -425,7 +426,21 @@ constexpr int64_t kCapacityBytes = int64_t{192} << 20;
 // Up to this much worst-case gradient the "fastest order" kinds do not read the count back AT ALL: the gradient is
 // handed on padded to min(nnz, rows) entries (zero rows that name a row of the batch: an uncoalesced COO tensor of the
 // same value), so the host never waits for the device inside a step -- at B = 1024 the wait was a third of the step.
-constexpr int64_t kPaddedBytes = int64_t{64} << 20;
+// Why not more: with the limit raised (tools/torch_padded_limit_probe.py, profiles/r05_torch_padded_limit_probe.txt) the step
+// alone gains further (4,096 samples, 128 MB: 0.193 -> 0.122 ms; 8,192: 0.187 -> 0.164; slower from 16,384 on), but whoever
+// consumes the gradient pays for min(lookups, rows) entries instead of num_unique (tools/padded_gradient_consumer_probe.py:
+// step + torch.optim.SGD at 4,096 samples 0.236 -> 0.448 ms, at 1,024 samples 0.16 -> 0.22; step + coalesce() 0.29 -> 0.23 at
+// 1,024, 0.32 -> 0.37 at 4,096) -- the entry count of torch's own EmbeddingBag(sparse=True) gradient, but not what
+// "reference" hands on.  CUEMBED_PYT_PADDED_MB moves the limit (0: never pad).
+constexpr int64_t kPaddedBytesDefault = int64_t{64} << 20;
+// (tuning: CUEMBED_PYT_PADDED_MB, read once)
+inline int64_t PaddedBytes() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("CUEMBED_PYT_PADDED_MB");
+    return e != nullptr ? (static_cast<int64_t>(std::atoll(e)) << 20) : kPaddedBytesDefault;
+  }();
+  return v;
+}
 
 enum GradKind : int64_t { kGradDense = 0, kGradSparseAuto = 1, kGradSparseReference = 2, kGradSparseUncoalesced = 3 };
 
@@ -532,7 +547,7 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     const int64_t row_bytes = width * static_cast<int64_t>(out_grad.element_size());
     at::Tensor rows, inv;
     int64_t num_unique = -1;
-    const int64_t room = capacity * row_bytes <= kCapacityBytes ? capacity : 0;   // rows the scatter may write blind
+    const int64_t room = capacity * row_bytes <= (kCapacityBytes > PaddedBytes() ? kCapacityBytes : PaddedBytes()) ? capacity : 0;   // rows the scatter may write blind
     const auto exact_backward = [&]() {
       rows = at::empty({num_unique, width}, out_grad.options());
       inv = at::empty({num_unique}, nw.idx.options());
@@ -541,7 +556,7 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
                                    /*skip_grad_init=*/0, MutPtr(rows), MutPtr(inv), stream);
       if (inv.scalar_type() != at::kLong) inv = inv.to(at::kLong);
     };
-    const bool padded = grad_kind != kGradSparseReference && one_block && room > 0 && room * row_bytes <= kPaddedBytes;
+    const bool padded = grad_kind != kGradSparseReference && one_block && room > 0 && room * row_bytes <= PaddedBytes();
     if (padded) {
       rows = at::empty({room, width}, out_grad.options());
       inv = at::empty({room}, nw.idx.options());
@@ -557,7 +572,7 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     // (from here on the host has to read the row count: not something a HIP graph can hold)
     TORCH_CHECK(c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None,
                 "cuembed_pyt: this sparse gradient needs its row count on the host and cannot be captured into a graph: "
-                "sparse_grad=True is capture-safe while min(lookups, rows) gradient rows fit ", kPaddedBytes >> 20,
+                "sparse_grad=True is capture-safe while min(lookups, rows) gradient rows fit ", PaddedBytes() >> 20,
                 " MiB (here ", (capacity * row_bytes) >> 20, " MiB", grad_kind == kGradSparseReference ? ", and "
                 "sparse_grad=\"reference\" always reads the count" : "", "); sparse_grad=False always is");
     if (room > 0) {

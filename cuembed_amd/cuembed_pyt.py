@@ -381,7 +381,10 @@ def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False, hints
       True           params.grad is a sparse COO tensor holding only the rows that were looked up, computed the fastest
                      way for the shape: where the backward gains from scattering the batch in blocks of samples (C4) a
                      row may appear once per block (is_coalesced=False: the same gradient once scattered or coalesced;
-                     what torch.sparse consumers -- SGD, SparseAdam, .coalesce(), .to_dense() -- take as it is);
+                     what torch.sparse consumers -- SGD, SparseAdam, .coalesce(), .to_dense() -- take as it is); small
+                     batches get it PADDED to min(lookups, rows) entries (zero rows naming rows of the batch in turn) so
+                     that the step never waits for the device -- the entry count of torch's own EmbeddingBag(sparse=True)
+                     gradient; a consumer that pays per entry (torch.optim.SGD) is better served by "reference";
       "reference"    the reference's fully sorted order: always coalesced, ascending rows;
       "blocked"      the same coalesced tensor computed from the sample-blocked order (a faster EmbeddingBackward for
                      more index work; through this op surface the two cancel at C4);

@@ -300,8 +300,8 @@ def embedding_backward(grad_y, num_grad_embedding_rows, transpose_indices, trans
     order's inverse_mapping.
 
     pad_to_capacity=True (with num_grad_embedding_rows=None, one block, skip_grad_init=False): the rows from the
-    device-side count up to the buffers' row count are zeroed and their inverse_mapping entries name the batch's
-    smallest table row -- (inverse_mapping, grad_embedding) as a whole is then a valid uncoalesced COO gradient whose
+    device-side count up to the buffers' row count are zeroed and their inverse_mapping entries name rows of
+    the batch, different ones in turn -- (inverse_mapping, grad_embedding) as a whole is then a valid uncoalesced COO gradient whose
     row count never has to be read back.
 
     Extension: reference_sums=True computes every `grad += grad_y * weight` in the gradient's own type, lookup by

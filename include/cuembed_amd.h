@@ -312,8 +312,8 @@ void cuembed_embedding_backward_blocked(const void* grad_y, int elem_type, int e
  * and *capacity_overflow -- a device word the caller zeroed once; may be NULL -- is OR-ed with 1: a sticky flag to read
  * back whenever convenient instead of a silent overrun.  capacity_rows = 0: unchecked (the other entry points).
  * pad_to_capacity != 0 (needs capacity_rows > 0, num_grad_embedding_rows < 0, skip_grad_init == 0, one block): the
- * rows from the device-side count up to capacity_rows are zeroed and their inverse_mapping entries set to the batch's
- * smallest table row -- (inverse_mapping, grad_embedding) over all capacity_rows entries is then a valid uncoalesced
+ * rows from the device-side count up to capacity_rows are zeroed and their inverse_mapping entries set to rows of
+ * the batch, different ones in turn (entry i names the row of entry (i - count) mod count) -- (inverse_mapping, grad_embedding) over all capacity_rows entries is then a valid uncoalesced
  * COO gradient (coalescing it gives the reference's) that needs no read-back of the count at all. */
 void cuembed_embedding_backward_bounded(const void* grad_y, int elem_type, int embed_width,
                                         int num_grad_embedding_rows, int nnz,

@@ -344,14 +344,14 @@ void OneCallAndBoundedKat(hipStream_t stream) {
     ExpectAll("capacity 4 < 5 rows: nothing written", grad.host(), std::vector<float>(5 * width, 7.0f));
   }
   {
-    // capacity 7 with padding: rows 5 and 6 are zero and name the batch's smallest row (0)
+    // capacity 7 with padding: rows 5 and 6 are zero and name rows of the batch in turn (the first two: 0 and 4)
     DeviceArray<float> grad(std::vector<float>(7 * width, 7.0f));
     DeviceArray<IndexT> inv(std::vector<IndexT>(7, static_cast<IndexT>(-3)));
     cuembed::EmbeddingBackward<float, IndexT>(gy.ptr, width, -1, 8, t_idx.ptr, t_sid.ptr, remap.ptr, no_w, false, grad.ptr,
                                               inv.ptr, stream, 1, nullptr, /*capacity_rows=*/7, overflow.ptr,
                                               /*pad_to_capacity=*/true);
     HIP_OK(hipStreamSynchronize(stream));
-    ExpectInt("padded: inverse mapping", inv.host(), {0, 4, 7, 8, 18, 0, 0});
+    ExpectInt("padded: inverse mapping", inv.host(), {0, 4, 7, 8, 18, 0, 4});
     std::vector<float> want;
     for (float v : {1.f, 2.f, 1.f, 3.f, 1.f, 0.f, 0.f})
       for (int c = 0; c < width; ++c) want.push_back(v);

@@ -696,3 +696,29 @@ def test_sort_regime_knobs_give_the_same_order():
     r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT.format(root=root)], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "knobs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("idx", IDXS, ids=["i32", "i64"])
+def test_padded_gradient_names_different_rows_of_the_batch(ce, oracle, idx):
+    """pad_to_capacity: the zero rows past the device-side count name rows OF THE BATCH, different ones in turn (entry i
+    names the row of entry (i - unique) mod unique) -- one row for the whole tail would make a consumer that adds by row
+    (torch's coalesce(), index_add_) serialise the whole tail on it.  Coalescing gives the reference's gradient."""
+    rng = np.random.default_rng(12)
+    B, H, W, ncat = 600, 20, 48, 5000
+    indices = rng.integers(0, ncat, B * H).astype(idx[0])
+    indices[: B * H // 2] = rng.integers(0, 40, B * H // 2)          # few distinct rows: a long tail to pad
+    gy = rng.integers(-3, 4, (B, W)).astype(np.float32)
+    ti, ts, _, remap = ce.transpose_fixed_hotness(dev(indices), B, H, None, num_categories=ncat, remapped=True)
+    unique = int(remap[-1].item()) + 1
+    capacity = min(B * H, ncat)
+    grad = torch.full((capacity, W), 9.0, device="cuda")
+    inv = torch.full((capacity,), -5, device="cuda", dtype=idx[1])
+    ce.embedding_backward(dev(gy), None, ti, ts, remap, grad_embedding=grad, inverse_mapping=inv, pad_to_capacity=True)
+    want_grad, want_inv = ce.embedding_backward(dev(gy), unique, ti, ts, remap)
+    assert torch.equal(grad[:unique], want_grad) and torch.equal(inv[:unique], want_inv)
+    assert bool((grad[unique:] == 0).all())
+    names = want_inv[torch.arange(capacity - unique, device="cuda") % unique]
+    assert torch.equal(inv[unique:], names)
+    assert int(torch.bincount(inv.long()).max()) <= -(-capacity // unique)       # no row is named more often than that
+    sparse = torch.sparse_coo_tensor(inv.long().unsqueeze(0), grad, (ncat, W)).coalesce()
+    assert torch.equal(sparse._indices()[0], want_inv.long()) and torch.equal(sparse._values(), want_grad)
