@@ -12,7 +12,7 @@ rows, W, H = 10_000_000, 256, 64
 table = torch.empty((rows, W), dtype=torch.float16, device="cuda").uniform_(-1, 1).requires_grad_(True)
 opt = torch.optim.SGD([table], lr=0.01)
 print("CUEMBED_PYT_PADDED_MB=%s" % os.environ.get("CUEMBED_PYT_PADDED_MB", "(default)"))
-for B in (1024, 2048, 4096):
+for B in [int(b) for b in sys.argv[1:]] or (1024, 2048, 4096):
     idx = torch.from_numpy(harness.generate_indices(rows, B, H, alpha=1.15).astype(np.int64)).cuda().view(-1)
     offsets = torch.arange(0, B * H + 1, H, dtype=torch.int64, device="cuda")
     up = torch.randint(-2, 3, (B, W), device="cuda").to(torch.float16)
