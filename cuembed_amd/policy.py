@@ -9,7 +9,9 @@ not have to know them.  Two hints are chosen here, per table and per offsets ten
                 when rows are re-used (alpha = 1.15: 0.136 -> 0.222 ms).  Decided from the distinct fraction of a
                 sample of the batch's indices (one `unique` + one 4-byte read-back), on the first call for a table and
                 again every RECHECK_CALLS calls; conservative: streaming only when >= STREAMING_DISTINCT of the sample
-                is distinct and the table is >= STREAMING_MIN_TABLE_BYTES.
+                is distinct, the table is >= STREAMING_MIN_TABLE_BYTES and the batch has >= STREAMING_MIN_LOOKUPS
+                lookups (smaller ones are latency-bound whatever the loads are, and the decision itself would cost
+                more host time than their launch).
   sample_order  the samples of a ragged CSR batch by descending bag length (cuembed::BagOrderByLength; C3: 0.170 ->
                 0.148 ms).  It depends on the offsets alone and costs about what it saves, so it is computed once per
                 DISTINCT offsets tensor (same storage, same version counter, same length) and kept for the last few:
@@ -27,6 +29,7 @@ RECHECK_CALLS = 256
 SAMPLE = 65536
 STREAMING_DISTINCT = 0.8
 STREAMING_MIN_TABLE_BYTES = 1 << 30
+STREAMING_MIN_LOOKUPS = 1 << 18
 ORDER_MIN_LOOKUPS = 1 << 20
 ORDER_MIN_BATCH = 1 << 14
 _ORDER_KEEP = 4
@@ -68,7 +71,11 @@ def distinct_fraction(indices):
 
 def row_loads(params, indices):
     """-1 (no hint: the process-wide default) / 0 (default loads) / 1 (streaming) for embedding_forward."""
-    if _quiet() or params.numel() * params.element_size() < STREAMING_MIN_TABLE_BYTES:
+    # (the cheap gates first: a small batch is latency-bound whatever the loads are, and at 7 us per launch the 3 us the
+    # capture query of _quiet() costs would be the largest part of this function's caller)
+    if indices.numel() < STREAMING_MIN_LOOKUPS or params.numel() * params.element_size() < STREAMING_MIN_TABLE_BYTES:
+        return -1
+    if _quiet():
         return -1
     key = (params.data_ptr(), tuple(params.shape), params.dtype)
     state = _tables.get(key)
@@ -84,7 +91,7 @@ def row_loads(params, indices):
 
 def sample_order(offsets, nnz, max_length=0):
     """The cached bag order of `offsets` for ForwardOptions::sample_order, or None (small batch, first sight, quiet)."""
-    if _quiet() or offsets is None or nnz < ORDER_MIN_LOOKUPS or offsets.numel() - 1 < ORDER_MIN_BATCH:
+    if offsets is None or nnz < ORDER_MIN_LOOKUPS or offsets.numel() - 1 < ORDER_MIN_BATCH or _quiet():
         return None
     key = (offsets.data_ptr(), offsets._version, offsets.numel(), offsets.dtype)
     entry = _orders.get(key)

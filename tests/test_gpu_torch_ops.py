@@ -429,6 +429,7 @@ def test_policy_hints_never_change_a_result(pyt):
     assert policy.distinct_fraction(uniform) > 0.95 > policy.STREAMING_DISTINCT > policy.distinct_fraction(skewed)
     plain = pyt.cuemb_embedding(table, uniform, offsets, None, hints=None)
     assert policy.row_loads(table, uniform) == 1 and policy.row_loads(table.clone(), skewed) == 0
+    assert policy.row_loads(table, uniform[: policy.STREAMING_MIN_LOOKUPS - 1]) == -1    # small batches: no decision at all
     assert policy.sample_order(offsets, n) is None                  # first sight: nothing is prepared
     order = policy.sample_order(offsets, n)                          # second sight: the order exists and is cached
     assert order is not None and order.dtype == torch.int32 and policy.sample_order(offsets, n) is order
