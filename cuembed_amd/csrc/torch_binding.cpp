@@ -442,7 +442,16 @@ inline int64_t PaddedBytes() {
   return v;
 }
 
-enum GradKind : int64_t { kGradDense = 0, kGradSparseAuto = 1, kGradSparseReference = 2, kGradSparseUncoalesced = 3 };
+// What the caller asked for (cuembed_pyt.py: sparse_grad=).  kGradSparseReference is the CONTRACT of sparse_grad=True: a
+// coalesced tensor of exactly num_unique ascending rows, whatever the backend and whether or not torch.compile traces
+// the call; the other sparse kinds are explicit opt-ins whose entry count differs from that (same dense value).
+enum GradKind : int64_t {
+  kGradDense = 0,
+  kGradSparseFastest = 1,      // sample blocks when the shape gains from them, padded when the step would wait on the count
+  kGradSparseReference = 2,    // fully sorted order: coalesced, num_unique rows
+  kGradSparseUncoalesced = 3,  // sample blocks when the shape gains from them, exactly one entry per (block, row): never padded
+  kGradSparsePadded = 4        // one block, min(lookups, rows) entries at ANY size: never reads the count, capturable
+};
 
 struct NarrowedIndices {
   at::Tensor idx, offsets;
@@ -453,6 +462,10 @@ NarrowedIndices NarrowForIndexWork(const at::Tensor& idx, const at::Tensor& offs
   if (idx.scalar_type() == at::kLong && num_categories < (int64_t{1} << 31) && idx.numel() >= (int64_t{1} << 18) &&
       idx.numel() < (int64_t{1} << 31))
     return {idx.to(at::kInt), offsets.to(at::kInt)};
+  // The forward takes indices and offsets of different integer types (ForwardImpl passes a type code for each); the index
+  // work below has ONE type for lookups and sample ids, the one of the indices: offsets follow (their values are <= nnz,
+  // which fits whatever type holds the lookups' count; int64 -> int32 is checked by the caller against INT32_MAX).
+  if (offsets.scalar_type() != idx.scalar_type()) return {idx, offsets.to(idx.scalar_type())};
   return {idx, offsets};
 }
 
@@ -462,8 +475,21 @@ struct TransposedLookups {
 // Transpose (+ ComputeCompressedGradIndices from the same call) of (sample_ids, indices[, weights]).
 TransposedLookups TransposeWithRemap(const at::Tensor& sample_ids, const at::Tensor& indices, const at::Tensor& weights,
                                      const int64_t num_categories, const int sample_blocks, const bool want_remap) {
+  CheckGpu(sample_ids, "sample_ids");
+  CheckGpu(indices, "indices");
   const int idx = IndexCode(indices, "indices");
-  const int wt = weights.defined() ? ElemCode(weights, "weights") : CUEMBED_F32;
+  // one type code names both arrays below: a pair of different integer types would be read and written past its end
+  TORCH_CHECK(sample_ids.scalar_type() == indices.scalar_type() && sample_ids.numel() == indices.numel(),
+              "cuembed_pyt: sample ids and indices must have the same dtype and length");
+  TORCH_CHECK(indices.numel() <= INT32_MAX, "cuembed_pyt: the number of lookups must fit an int");
+  TORCH_CHECK(sample_ids.is_contiguous() && indices.is_contiguous(), "cuembed_pyt: sample ids and indices must be contiguous");
+  int wt = CUEMBED_F32;
+  if (weights.defined()) {
+    CheckGpu(weights, "weights");
+    wt = ElemCode(weights, "weights");
+    TORCH_CHECK(weights.numel() == indices.numel() && weights.is_contiguous(),
+                "cuembed_pyt: weights must be contiguous with one entry per lookup");
+  }
   const int nnz = static_cast<int>(indices.numel());
   TransposedLookups t;
   t.t_idx = at::empty_like(indices);
@@ -515,7 +541,10 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     out_grad = out_grad.contiguous();
     const int64_t width = out_grad.size(1);
     const int64_t nnz = saved[0].numel();
+    TORCH_CHECK(nnz <= INT32_MAX, "cuembed_pyt: the number of lookups must fit an int");
     const at::Tensor weights = weighted ? saved[2].contiguous() : at::Tensor();
+    // (the forward reads the first nnz weights of a longer tensor; the transpose moves exactly nnz)
+    TORCH_CHECK(!weighted || weights.numel() == nnz, "cuembed_pyt: weights must have one entry per index");
     if (nnz == 0) {
       if (grad_kind == kGradDense) {
         grads[0] = at::zeros({num_categories, width}, out_grad.options());
@@ -538,7 +567,7 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     }
     // ---- compressed gradient as a sparse COO tensor ----
     int blocks = 1;
-    if (grad_kind != kGradSparseReference)   // while a block of samples is scattered every L2 gathers from 1 / blocks of out_grad
+    if (grad_kind == kGradSparseFastest || grad_kind == kGradSparseUncoalesced)   // while a block of samples is scattered every L2 gathers from 1 / blocks of out_grad
       blocks = ::cuembed_recommended_sample_blocks(elem, static_cast<int>(width), static_cast<int>(out_grad.size(0)), nnz);
     const TransposedLookups t = TransposeWithRemap(sample_ids, nw.idx, weights, num_categories, blocks, true);
     const bool one_block = ::cuembed_transpose_sample_block_length(nnz, blocks) >= nnz;
@@ -547,7 +576,9 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     const int64_t row_bytes = width * static_cast<int64_t>(out_grad.element_size());
     at::Tensor rows, inv;
     int64_t num_unique = -1;
-    const int64_t room = capacity * row_bytes <= (kCapacityBytes > PaddedBytes() ? kCapacityBytes : PaddedBytes()) ? capacity : 0;   // rows the scatter may write blind
+    const int64_t room = (grad_kind == kGradSparsePadded ||
+                          capacity * row_bytes <= (kCapacityBytes > PaddedBytes() ? kCapacityBytes : PaddedBytes()))
+                             ? capacity : 0;   // rows the scatter may write blind
     const auto exact_backward = [&]() {
       rows = at::empty({num_unique, width}, out_grad.options());
       inv = at::empty({num_unique}, nw.idx.options());
@@ -556,7 +587,8 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
                                    /*skip_grad_init=*/0, MutPtr(rows), MutPtr(inv), stream);
       if (inv.scalar_type() != at::kLong) inv = inv.to(at::kLong);
     };
-    const bool padded = grad_kind != kGradSparseReference && one_block && room > 0 && room * row_bytes <= PaddedBytes();
+    const bool padded = grad_kind == kGradSparsePadded ||
+                        (grad_kind == kGradSparseFastest && one_block && room > 0 && room * row_bytes <= PaddedBytes());
     if (padded) {
       rows = at::empty({room, width}, out_grad.options());
       inv = at::empty({room}, nw.idx.options());
@@ -572,9 +604,9 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     // (from here on the host has to read the row count: not something a HIP graph can hold)
     TORCH_CHECK(c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None,
                 "cuembed_pyt: this sparse gradient needs its row count on the host and cannot be captured into a graph: "
-                "sparse_grad=True is capture-safe while min(lookups, rows) gradient rows fit ", PaddedBytes() >> 20,
-                " MiB (here ", (capacity * row_bytes) >> 20, " MiB", grad_kind == kGradSparseReference ? ", and "
-                "sparse_grad=\"reference\" always reads the count" : "", "); sparse_grad=False always is");
+                "sparse_grad=\"padded\" never reads it (min(lookups, rows) entries, here ", (capacity * row_bytes) >> 20,
+                " MiB), sparse_grad=\"fastest\" does not while those fit ", PaddedBytes() >> 20,
+                " MiB; sparse_grad=True / \"reference\" / \"uncoalesced\" always read the count; sparse_grad=False never does");
     if (room > 0) {
       // everything is enqueued before the host looks at the device: rows for `room`, narrowed afterwards
       rows = at::empty({room, width}, out_grad.options());
@@ -596,13 +628,11 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
   }
 };
 
-// grad_kind: 0 dense (the reference), 1 sparse / fastest order, 2 sparse / the reference's order (coalesced),
-// 3 sparse / sample-blocked order (uncoalesced when the shape asks for blocks; = 1 today, kept apart for callers that
-// want to pin the behaviour).
+// grad_kind: see GradKind.
 at::Tensor cuemb_embedding_autograd_op(const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
                                     const at::Tensor& weights, const int64_t grad_kind, const int64_t row_loads,
                                     const at::Tensor& sample_order) {
-  TORCH_CHECK(grad_kind >= kGradDense && grad_kind <= kGradSparseUncoalesced, "cuembed_pyt: unknown grad_kind");
+  TORCH_CHECK(grad_kind >= kGradDense && grad_kind <= kGradSparsePadded, "cuembed_pyt: unknown grad_kind");
   return CuEmbEmbeddingNode::apply(params, indices, offsets,
                                    weights.defined() ? c10::optional<at::Tensor>(weights) : c10::nullopt, grad_kind,
                                    row_loads,

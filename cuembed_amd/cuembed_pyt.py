@@ -276,6 +276,10 @@ def _narrow_for_index_work(idx, offsets, num_categories):
     conversion launches cost more than they save -- B = 1024: 0.199 -> 0.228 ms -- hence the size gate)."""
     if idx.dtype == torch.int64 and num_categories < 2 ** 31 and (1 << 18) <= idx.numel() < 2 ** 31:
         return idx.to(torch.int32), (None if offsets is None else offsets.to(torch.int32))
+    if offsets is not None and offsets.dtype != idx.dtype:
+        # the forward takes indices and offsets of different integer types; the index work has ONE type for lookups and
+        # sample ids, the one of the indices (offsets hold values <= nnz, which fits it)
+        offsets = offsets.to(idx.dtype)
     return idx, offsets
 
 
@@ -298,17 +302,31 @@ def cuembed_backward(ctx, out_grad):
 
 
 def _sparse_backward(ctx, out_grad, idx, offsets, weights, nnz):
-    """Compressed gradient as a coalesced sparse COO tensor (like nn.EmbeddingBag(sparse=True)).
-    Reads num_unique back to the host (one sync), exactly like the reference's benchmark does
-    (manual_benchmark.cu:392-394)."""
+    """Compressed gradient as a sparse COO tensor (like nn.EmbeddingBag(sparse=True)); True / "reference" / "blocked":
+    coalesced, exactly num_unique ascending rows.  Reads num_unique back to the host (one sync), exactly like the
+    reference's benchmark does (manual_benchmark.cu:392-394) -- except "padded", which never does."""
     width = out_grad.size(1)
+    if weights is not None and weights.numel() != nnz:
+        raise ValueError("weights must have one entry per index")
     if nnz == 0:
         return (torch.sparse_coo_tensor(torch.empty((1, 0), dtype=torch.int64, device=out_grad.device),
                                         torch.empty((0, width), dtype=out_grad.dtype, device=out_grad.device),
                                         size=(ctx.num_categories, width)), None, None, None)
     sample_ids = torch.ops.cuembed_pyt.cuembed_extract_row_ids_from_offsets(offsets, nnz)
     blocks = 1
-    if ctx.sparse_grad != "reference":
+    if ctx.sparse_grad == "padded":
+        # min(lookups, rows) entries, the tail zero rows naming rows of the batch in turn: no read-back at any size
+        t_idx, t_sid, t_w = cuembed_transpose_sample_ids(sample_ids, idx, weights, ctx.num_categories)
+        remap = torch.ops.cuembed_pyt.cuembed_compute_compressed_grad_indices(t_idx)
+        capacity = min(nnz, ctx.num_categories)
+        rows = torch.empty((capacity, width), dtype=out_grad.dtype, device=out_grad.device)
+        inv = torch.empty((capacity,), dtype=t_idx.dtype, device=out_grad.device)
+        _ops.embedding_backward(out_grad.contiguous(), None, t_idx, t_sid, remap, t_w if t_w.numel() else None,
+                                grad_embedding=rows, inverse_mapping=inv, pad_to_capacity=True)
+        grad = torch.sparse_coo_tensor(inv.to(torch.int64).unsqueeze(0), rows, size=(ctx.num_categories, width),
+                                       is_coalesced=False)
+        return grad, None, None, None
+    if ctx.sparse_grad not in (True, "reference"):
         # while a block of samples is scattered every L2 gathers from 1 / blocks of out_grad only
         blocks = _ops.recommended_sample_blocks(out_grad.dtype, width, out_grad.size(0), nnz)
         if ctx.sparse_grad == "blocked":
@@ -369,7 +387,9 @@ class _CuEmbEmbedding(torch.autograd.Function):
         return tuple(grads) + (None, None)
 
 
-_GRAD_KINDS = {False: 0, True: 1, "reference": 2, "uncoalesced": 3}
+# (native CuEmbEmbeddingNode: GradKind)
+_GRAD_KINDS = {False: 0, True: 2, "reference": 2, "fastest": 1, "uncoalesced": 3, "padded": 4}
+_SPARSE_KINDS = (False, True, "reference", "fastest", "uncoalesced", "padded", "blocked")
 
 
 def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False, hints="auto"):
@@ -377,24 +397,33 @@ def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False, hints
     (examples/pytorch/cuembed_pyt.py:48-51).  Differentiable w.r.t. params and -- an extension over the reference --
     w.r.t. the per-lookup weights.
 
-    sparse_grad (extension; False = the reference's dense, table-sized gradient):
-      True           params.grad is a sparse COO tensor holding only the rows that were looked up, computed the fastest
-                     way for the shape: where the backward gains from scattering the batch in blocks of samples (C4) a
-                     row may appear once per block (is_coalesced=False: the same gradient once scattered or coalesced;
-                     what torch.sparse consumers -- SGD, SparseAdam, .coalesce(), .to_dense() -- take as it is); small
-                     batches get it PADDED to min(lookups, rows) entries (zero rows naming rows of the batch in turn) so
-                     that the step never waits for the device -- the entry count of torch's own EmbeddingBag(sparse=True)
-                     gradient; a consumer that pays per entry (torch.optim.SGD) is better served by "reference";
-      "reference"    the reference's fully sorted order: always coalesced, ascending rows;
+    sparse_grad (extension; False = the reference's dense, table-sized gradient).  Every sparse kind densifies to the
+    same gradient; they differ in which entries the COO tensor holds:
+      True           params.grad is a COALESCED sparse COO tensor holding exactly the rows that were looked up, ascending
+                     (grad._nnz() == number of distinct rows; grad.indices() / .values() work) -- the reference's fully
+                     sorted order, on either backend and under torch.compile alike.  The row count is read back once
+                     per step (after everything is enqueued), so the step cannot be captured into a HIP graph;
+      "reference"    the same, by its older name;
       "blocked"      the same coalesced tensor computed from the sample-blocked order (a faster EmbeddingBackward for
                      more index work; through this op surface the two cancel at C4);
-      "uncoalesced"  today's behaviour of True, pinned.
+      "uncoalesced"  where the backward gains from scattering the batch in blocks of samples (C4: 0.56 -> 0.49 ms per
+                     step) a row may appear once per block (is_coalesced=False; what torch.sparse consumers -- SGD,
+                     SparseAdam, .coalesce(), .to_dense() -- take as it is); exactly one entry per (block, row);
+      "padded"       one block, PADDED to min(lookups, rows) entries (zero rows naming rows of the batch in turn;
+                     is_coalesced=False): the step never waits for the device and can be captured into a HIP graph --
+                     the entry count of torch's own EmbeddingBag(sparse=True) gradient; a consumer that pays per entry
+                     (torch.optim.SGD) is better served by True;
+      "fastest"      whichever of the above is fastest for the shape (native backend: "padded" while the worst case
+                     fits 64 MiB, else "uncoalesced"); the entry count is an implementation detail -- consume it with
+                     .coalesce(), .to_dense() or an optimizer.
     hints="auto" lets cuembed_amd.policy pick the forward's scheduling options for this table and batch (non-temporal
     row loads, bag order); None = the library defaults.  Results never depend on hints.
 
     Outside torch.compile the step runs as ONE native autograd node (forward, and row ids -> transpose + remap ->
     scatter-add in the backward, one dispatcher hop each; libcuembed_pyt.so: CuEmbEmbeddingNode); under torch.compile,
     for the weight gradient and for "blocked" it runs as a Python autograd.Function over the same ops."""
+    if not (isinstance(sparse_grad, bool) or (isinstance(sparse_grad, str) and sparse_grad in _SPARSE_KINDS)):
+        raise ValueError("sparse_grad must be one of %r" % (_SPARSE_KINDS,))
     needs_grad = params.requires_grad or (weights is not None and weights.requires_grad)
     quiet = torch.compiler.is_compiling()
     chosen = _auto_hints(params, idx, offsets) if (hints == "auto" and not quiet) else None

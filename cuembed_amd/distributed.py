@@ -240,3 +240,324 @@ def allreduce_sparse_grad(rows, inverse_mapping, num_categories, group=None, alg
     mine_ids, mine_vals, count = _merge(got_ids, got_vals, num_categories)
     # owners hold disjoint, ascending id ranges in rank order: the concatenation is already sorted
     return _gather_ragged(mine_ids.to(torch.int64), mine_vals, group, count=count)   # read-back 2
+
+
+# ---- fixed-capacity sparse exchange: no host read-back in the steady state ---------------------------------------
+# allreduce_sparse_grad() above sizes every tensor it exchanges and returns exactly, and sizes are host values: two to
+# three read-backs per step, each a stall of the whole pipeline.  A training loop exchanges gradients of (nearly) the
+# same size every step, so the sizes can be fixed ONCE -- from a warm-up step that is allowed to look (calibrate()) --
+# and every later step runs with device-side counts only: fixed slots in the all-to-all, a fixed-capacity merge on the
+# owner (EmbeddingBackward's device-side row count + pad_to_capacity), a fixed-size all-gather that can run behind the
+# next step's forward (async_op), and a sticky overflow word instead of a read-back, like the library's own
+# capacity_overflow.  The result is a valid uncoalesced COO gradient (zero rows fill the slack), identical on every
+# rank; compact() turns it into allreduce_sparse_grad()'s (ids, rows) for whoever wants to pay for the read-back.
+
+XGMI_LINKS_PER_GPU = 7          # MI355X: 7 xGMI links per GPU, fully connected inside a node of 8
+XGMI_LINK_GBPS = 153.0          # ~ 153 GB/s per link and direction
+
+
+def exchange_model_ms(world, rows_per_rank, merged_rows_total, width, elem_size, pair_capacity=None,
+                      owner_capacity=None, link_GBps=XGMI_LINK_GBPS, id_bytes=8):
+    """Link arithmetic of the owner-partitioned sparse exchange on a fully connected xGMI node: every pair of GPUs has
+    its own link, so the all-to-all moves each (source, owner) slot over that pair's link, all pairs at once, and the
+    all-gather of the owners' merged pieces brings (world - 1) pieces into every GPU, one per link.  Bytes that cross
+    ONE link and direction / link rate = the floor of each phase; RCCL's protocol overhead, the merge kernels
+    (Transpose + EmbeddingBackward over the received rows) and launch gaps come on top.  pair_capacity /
+    owner_capacity: the fixed slot sizes of SparseGradExchange (default: the exact averages, i.e. the exact exchange).
+    Returns ms per phase for the peak link rate and for 75 % of it (what large RCCL point-to-point transfers reach)."""
+    if world <= 1:
+        return {"all_to_all_ms": 0.0, "all_gather_ms": 0.0, "total_ms": 0.0, "total_ms_at_75pct_link": 0.0,
+                "bytes_in_per_rank": 0}
+    row = width * elem_size + id_bytes
+    pair = float(pair_capacity) if pair_capacity else rows_per_rank / world
+    piece = float(owner_capacity) if owner_capacity else merged_rows_total / world
+    a2a = pair * row / (link_GBps * 1e9) * 1e3
+    gather = piece * row / (link_GBps * 1e9) * 1e3
+    return {"all_to_all_ms": round(a2a, 4), "all_gather_ms": round(gather, 4), "total_ms": round(a2a + gather, 4),
+            "total_ms_at_75pct_link": round((a2a + gather) / 0.75, 4),
+            "bytes_in_per_rank": int((world - 1) * (pair + piece) * row),
+            "links_used": min(world - 1, XGMI_LINKS_PER_GPU), "link_GBps": link_GBps}
+
+
+def _merge_fixed(ids, vals, num_categories, capacity, pad_lo, pad_len, out_ids=None, out_rows=None):
+    """Sum rows with equal id into buffers of a FIXED capacity, without a host read-back on the GPU.
+
+    ids >= num_categories are padding of the caller's fixed-size input and are dropped.  Returns (uniq[capacity + 1],
+    rows[capacity + 1, W], count[1], overflow[1]): the first `count` entries are the ascending distinct ids and their
+    sums (the same bits as _merge gives), every entry past them a ZERO row whose id names a row of
+    [pad_lo, pad_lo + pad_len) in turn -- harmless to whoever scatter-adds the lot.  overflow != 0: more than
+    `capacity` distinct ids; the buffers then keep what they held (well-formed, but not this step's gradient)."""
+    m = ids.numel()
+    dev = vals.device
+    width = vals.shape[1]
+    if out_rows is None:
+        out_rows = torch.zeros((capacity + 1, width), dtype=vals.dtype, device=dev)
+        out_ids = torch.zeros((capacity + 1,), dtype=torch.int64, device=dev)
+    pad_ids = pad_lo + torch.arange(capacity + 1, dtype=torch.int64, device=dev) % max(pad_len, 1)
+    if m == 0:
+        out_rows.zero_()
+        out_ids.copy_(pad_ids)
+        z = torch.zeros((1,), dtype=torch.int64, device=dev)
+        return out_ids, out_rows, z, z.clone()
+    if vals.is_cuda:
+        from . import ops
+        pos = ops.extract_row_ids_for_concat(m, torch.int64, dev)
+        # (the padding id num_categories sorts behind every real id and becomes ONE extra run at the end)
+        t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories + 1, num_rows=m)
+        remap = ops.compute_compressed_grad_indices(t_ids)
+        has_pad = (t_ids[-1:] >= num_categories).to(torch.int64)
+        count = remap[-1:] + 1 - has_pad
+        overflow = (count > capacity).to(torch.int64)
+        # capacity + 1 rows: the run of the padding ids needs a row too; too many distinct ids -> the kernels write nothing
+        ops.embedding_backward(vals.contiguous(), None, t_ids, t_pos, remap, grad_embedding=out_rows,
+                               inverse_mapping=out_ids, pad_to_capacity=True)
+        # the padding run's "sum" sits right behind the real rows: zero it (when there is none, the spare last row)
+        out_rows.index_fill_(0, torch.where(has_pad > 0, count, torch.full_like(count, capacity)).clamp_(max=capacity), 0)
+        # entries past the count: a valid id each, different ones in turn (one id for the whole tail serialises
+        # whoever coalesces the result)
+        torch.where(torch.arange(capacity + 1, device=dev) < count, out_ids, pad_ids, out=out_ids)
+        return out_ids, out_rows, count, overflow
+    keep = ids < num_categories
+    uniq, inverse = torch.unique(ids[keep], sorted=True, return_inverse=True)
+    k = uniq.numel()
+    count = torch.tensor([k], dtype=torch.int64)
+    if k > capacity:
+        return out_ids, out_rows, count, torch.ones((1,), dtype=torch.int64)
+    summed = torch.zeros((k, width), dtype=torch.float32)
+    summed.index_add_(0, inverse, vals[keep].float())
+    out_rows.zero_()
+    out_rows[:k] = summed.to(vals.dtype)
+    out_ids.copy_(pad_ids)
+    out_ids[:k] = uniq
+    return out_ids, out_rows, count, torch.zeros((1,), dtype=torch.int64)
+
+
+class SparseGradResult:
+    """What SparseGradExchange.start() returns: wait() -> (ids[world * piece], rows[world * piece, W], counts[world]),
+    identical on every rank.  Piece r (entries [r * piece, (r + 1) * piece)) is owner r's merged id range: `counts[r]`
+    ascending distinct ids with their summed rows, then zero rows with valid ids.  The whole is a valid uncoalesced
+    COO gradient of the table (scatter-add it as it is); SparseGradExchange.compact() gives the exact rows."""
+
+    def __init__(self, works, ids, rows, piece, world):
+        self._works, self._ids, self._rows, self._piece, self._world = works, ids, rows, piece, world
+
+    def is_completed(self):
+        return all(w.is_completed() for w in self._works)
+
+    def wait(self):
+        for w in self._works:
+            w.wait()          # (RCCL: the current stream waits for the collective; the host does not)
+        tail = self._ids.view(self._world, self._piece + 2)
+        return (tail[:, : self._piece].reshape(-1), self._rows, tail[:, self._piece])
+
+    def flags(self):
+        """(after wait()) every rank's overflow word of this step, a device tensor [world]."""
+        return self._ids.view(self._world, self._piece + 2)[:, self._piece + 1]
+
+
+class SparseGradExchange:
+    """Owner-partitioned sparse gradient exchange with fixed capacities (see the section comment above).
+
+    pair_capacity : rows one rank may send to one owner per step (a slot of the all-to-all);
+    piece_capacity: distinct rows one owner may hold after merging (a piece of the all-gather);
+    local_capacity: distinct rows of this rank's own gradient after its local merge (coalesced=False only).
+    Sized by hand or by calibrate() from a warm-up step.  A step that does not fit raises the sticky overflow word on
+    EVERY rank (it travels with the all-gather) and delivers a well-formed but incomplete gradient: look at
+    overflowed() whenever a host wait is affordable (every few hundred steps, or at the step where the loss is read
+    anyway) and calibrate again.
+
+        ex = SparseGradExchange.calibrate(rows, ids, num_categories, count=count)      # warm-up: reads sizes back
+        for batch in loader:
+            ... forward / Transpose / EmbeddingBackward into (rows, ids, count) ...
+            pending = ex.start(rows, ids, count)          # all-to-all + merge enqueued, all-gather in flight
+            ... next batch's forward ...
+            ids_all, rows_all, counts = pending.wait()    # stream-side wait
+            table.index_add_(0, ids_all, rows_all, alpha=-lr)
+    """
+
+    def __init__(self, num_categories, width, dtype, device, pair_capacity, piece_capacity, local_capacity=0,
+                 group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.num_categories, self.width, self.dtype, self.device = int(num_categories), int(width), dtype, device
+        self.pair_capacity, self.piece_capacity = int(pair_capacity), int(piece_capacity)
+        self.local_capacity = int(local_capacity)
+        if self.pair_capacity < 1 or self.piece_capacity < 1:
+            raise ValueError("capacities must be at least one row")
+        bounds = owner_bounds(self.num_categories, self.world)
+        self._cuts = torch.tensor([b[0] for b in bounds] + [self.num_categories], dtype=torch.int64, device=device)
+        self._lo, hi = bounds[self.rank]
+        self._range = max(hi - self._lo, 1)
+        w, s, p = self.world, self.pair_capacity, self.piece_capacity
+        self._slot = torch.arange(s, dtype=torch.int64, device=device)
+        self._send_ids = torch.empty((w * s,), dtype=torch.int64, device=device)
+        self._recv_ids = torch.empty((w * s,), dtype=torch.int64, device=device)
+        self._recv_rows = torch.empty((w * s, self.width), dtype=dtype, device=device)
+        # (zero-initialised ONCE: a step that overflows leaves them as they were -- finite rows, valid ids)
+        self._piece_rows = torch.zeros((p + 1, self.width), dtype=dtype, device=device)
+        self._piece_ids = torch.zeros((p + 1,), dtype=torch.int64, device=device)
+        self._piece_tail = torch.zeros((p + 2,), dtype=torch.int64, device=device)    # ids, count, overflow word
+        self._local_rows = self._local_ids = None
+        if self.local_capacity:
+            self._local_rows = torch.zeros((self.local_capacity + 1, self.width), dtype=dtype, device=device)
+            self._local_ids = torch.zeros((self.local_capacity + 1,), dtype=torch.int64, device=device)
+        # two sets of result buffers: the all-gather of step i may still be read while step i + 1 gathers
+        self._out = [(torch.zeros((w * (p + 2),), dtype=torch.int64, device=device),
+                      torch.zeros((w * p, self.width), dtype=dtype, device=device)) for _ in range(2)]
+        self._turn = 0
+        self._overflow = torch.zeros((1,), dtype=torch.int64, device=device)      # sticky, all ranks' words OR-ed
+
+    # -- sizes ----------------------------------------------------------------------------------------------------
+    @classmethod
+    def calibrate(cls, rows, inverse_mapping, num_categories, count=None, coalesced=True, group=None, headroom=1.25):
+        """Warm-up: looks at THIS step's sizes on the host (read-backs, an exchange of the ids alone) and returns an
+        exchange whose capacities are `headroom` x the largest slot / piece / local gradient any rank needs for it."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        ids = inverse_mapping.to(torch.int64)
+        k = ids.numel() if count is None else int(count.reshape(-1)[0].item())
+        ids = ids[:k]
+        local = 0
+        if not coalesced:
+            ids = torch.unique(ids)          # (what the rank's own merge will leave: ascending distinct ids)
+            local = ids.numel()
+        bounds = owner_bounds(num_categories, world)
+        cuts = torch.tensor([b[0] for b in bounds] + [num_categories], dtype=torch.int64, device=ids.device)
+        pos = torch.searchsorted(ids, cuts)
+        pair = int((pos[1:] - pos[:-1]).max().item()) if ids.numel() else 0
+        merged = torch.unique(torch.cat(_all_gather_ragged_ids(ids, group)))      # the owners' merged rows, all ranges
+        got = torch.searchsorted(merged, cuts)
+        piece = int((got[1:] - got[:-1]).max().item()) if merged.numel() else 0
+        need = torch.tensor([pair, piece, local], dtype=torch.int64,
+                            device=rows.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+        pair, piece, local = (int(x) for x in need.tolist())
+
+        def grow(n):
+            return max(int(n * headroom) + 16, 16)
+        return cls(num_categories, rows.shape[1], rows.dtype, rows.device, grow(pair), grow(piece),
+                   0 if coalesced else grow(local), group=group)
+
+    def overflowed(self, reset=False):
+        """True when a step since the last reset did not fit the capacities on SOME rank (one host read-back)."""
+        flag = bool(self._overflow.item())
+        if reset:
+            self._overflow.zero_()
+        return flag
+
+    def wire_bytes_per_step(self):
+        """Bytes that enter this rank per step: (world - 1) slots of the all-to-all + (world - 1) pieces."""
+        row = self.width * torch.empty((), dtype=self.dtype).element_size() + 8
+        return (self.world - 1) * (self.pair_capacity * row + self.piece_capacity * row + 16)
+
+    # -- the step -------------------------------------------------------------------------------------------------
+    def start(self, rows, inverse_mapping, count=None, coalesced=True, async_op=True):
+        """Enqueues the whole exchange of this rank's compressed gradient -- rows[n, W], inverse_mapping[n], of which
+        the first `count` (1-element device tensor; None = all) are valid and, for coalesced=True, ascending -- and
+        returns a SparseGradResult.  Nothing in here waits for the device."""
+        import torch.distributed as dist
+        dev, w, s, p = self.device, self.world, self.pair_capacity, self.piece_capacity
+        ids = inverse_mapping if inverse_mapping.dtype == torch.int64 else inverse_mapping.to(torch.int64)
+        n = ids.numel()
+        flag = torch.zeros((1,), dtype=torch.int64, device=dev)
+        if n and count is not None:      # rows past the count hold nothing: give them the padding id
+            ids = torch.where(torch.arange(n, device=dev) < count.reshape(1).to(dev), ids,
+                              torch.full_like(ids, self.num_categories))
+        if n and not coalesced:
+            if not self.local_capacity:
+                raise ValueError("coalesced=False needs local_capacity (the rank's own rows are merged first)")
+            ids, rows, mine, over = _merge_fixed(ids, rows, self.num_categories, self.local_capacity, 0, 1,
+                                                 self._local_ids, self._local_rows)
+            # (behind the count the merged buffer holds zero rows named 0: give them the padding id again)
+            ids = torch.where(torch.arange(ids.numel(), device=dev) < mine, ids, torch.full_like(ids, self.num_categories))
+            flag = flag | over
+            n = ids.numel()
+        # ---- pack: owner r's rows into slot r of the send buffers (device-side counts, fixed slot size)
+        if n:
+            pos = torch.searchsorted(ids, self._cuts)                       # padding ids sort behind the last cut
+            have = pos[1:] - pos[:-1]
+            flag = flag | (have > s).any().reshape(1).to(torch.int64)
+            valid = self._slot.unsqueeze(0) < have.unsqueeze(1)             # [world, slot]
+            src = torch.where(valid, pos[:-1].unsqueeze(1) + self._slot.unsqueeze(0), torch.zeros_like(valid, dtype=torch.int64))
+            src = src.reshape(-1)
+            torch.where(valid.reshape(-1), ids[src], torch.full_like(src, self.num_categories), out=self._send_ids)
+            send_rows = rows.index_select(0, src)       # (rows of unused slot entries: row 0 again and again -- their id drops them)
+        else:
+            self._send_ids.fill_(self.num_categories)
+            send_rows = torch.zeros((w * s, self.width), dtype=self.dtype, device=dev)
+        # ---- all-to-all with equal splits: no sizes to agree on
+        _all_to_all_equal(self._recv_ids, self._send_ids, self.group)
+        _all_to_all_equal(self._recv_rows, send_rows, self.group)
+        # ---- merge my range into the piece (fixed capacity, device-side count)
+        _, _, cnt, over = _merge_fixed(self._recv_ids, self._recv_rows, self.num_categories, p, self._lo, self._range,
+                                       self._piece_ids, self._piece_rows)
+        flag = flag | over
+        self._piece_tail[:p] = self._piece_ids[:p]
+        self._piece_tail[p: p + 1] = torch.clamp(cnt, max=p)
+        self._piece_tail[p + 1:] = flag
+        # ---- all-gather of the fixed-size pieces (ids carry count and overflow word in-band)
+        out_tail, out_rows = self._out[self._turn]
+        self._turn ^= 1
+        works = [_all_gather_into(out_tail, self._piece_tail, self.group, async_op),
+                 _all_gather_into(out_rows, self._piece_rows[:p], self.group, async_op)]
+        result = SparseGradResult([x for x in works if x is not None], out_tail, out_rows, p, w)
+        if not async_op:
+            self.note_flags(result)
+        return result
+
+    def note_flags(self, result):
+        """(after result.wait()) folds the step's overflow words of all ranks into the sticky one; device-side."""
+        self._overflow |= result.flags().max().reshape(1)
+
+    @staticmethod
+    def compact(ids, rows, counts):
+        """The exact (ascending unique ids, summed rows) of a waited result -- allreduce_sparse_grad()'s return value.
+        Reads the owners' counts back (one host wait)."""
+        world = counts.numel()
+        piece = ids.numel() // world
+        ks = counts.tolist()
+        return (torch.cat([ids[r * piece: r * piece + ks[r]] for r in range(world)]),
+                torch.cat([rows[r * piece: r * piece + ks[r]] for r in range(world)]))
+
+
+def _all_gather_ragged_ids(ids, group):
+    """(calibration only) every rank's id list, through a padded all-gather; reads the lengths back."""
+    import torch.distributed as dist
+    n = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+    counts = torch.cat(_all_gather(n, group)).tolist()
+    cap = max(max(counts), 1)
+    pad = torch.full((cap,), -1, dtype=torch.int64, device=ids.device)
+    pad[: ids.numel()] = ids
+    got = _all_gather(pad, group)
+    return [got[r][: counts[r]] for r in range(dist.get_world_size(group))]
+
+
+def _all_to_all_equal(out, src, group):
+    """all_to_all_single with equal splits (no split sizes: nothing to read back or agree on)."""
+    import torch.distributed as dist
+    if not _stage_on_host(src, group):
+        dist.all_to_all_single(out, src.contiguous(), group=group)
+        return
+    h_out = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_to_all_single(h_out, src.cpu(), group=group)
+    out.copy_(h_out)
+
+
+def _all_gather_into(out, piece, group, async_op):
+    """out[world * n, ...] = every rank's piece[n, ...]; a work handle when async_op (None when it ran blocking)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if _stage_on_host(piece, group):
+        h = piece.cpu()
+        got = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(got, h, group=group)
+        out.copy_(torch.cat(got))
+        return None
+    if dist.get_backend(group) == "nccl":
+        return dist.all_gather_into_tensor(out, piece.contiguous(), group=group, async_op=async_op) if async_op \
+            else dist.all_gather_into_tensor(out, piece.contiguous(), group=group)
+    got = list(out.chunk(world))
+    return dist.all_gather(got, piece.contiguous(), group=group, async_op=async_op) if async_op \
+        else dist.all_gather(got, piece.contiguous(), group=group)

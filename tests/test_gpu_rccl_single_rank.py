@@ -51,5 +51,31 @@ def test_fwd_bwd_allreduce_world1(oracle):
             rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device="cuda")
             rebuilt[ids] = summed
             assert np.array_equal(rebuilt.cpu().numpy().view(np.uint16), o_grad.view(np.uint16)), algorithm
+        # the fixed-capacity exchange over RCCL: after the warm-up (calibrate + one step: communicator set-up, allocator)
+        # a step must not wait for the device ANYWHERE -- torch's sync debug mode raises on every synchronising call
+        want_ids, want_rows = D.allreduce_sparse_grad(rows, inv, ncat, algorithm="owner")
+        cap = min(t_idx.numel(), ncat)
+        rows_cap = torch.zeros((cap, W), dtype=torch.float16, device="cuda")
+        inv_cap = torch.zeros((cap,), dtype=torch.int32, device="cuda")
+        count = remap[-1:] + 1
+        ex = D.SparseGradExchange.calibrate(rows, inv, ncat)
+        ex.start(rows, inv).wait()
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(3):
+                ce.embedding_backward(gy, None, t_idx, t_sid, remap, grad_embedding=rows_cap, inverse_mapping=inv_cap)
+                pending = ex.start(rows_cap, inv_cap, count=count)          # all-gather in flight (async_op)
+                out2 = ce.embedding_forward(table, idx.contiguous(), batch_size=b_loc, num_hots=H)   # ... behind the next forward
+                ids_all, rows_all, counts = pending.wait()
+                ex.note_flags(pending)
+                rebuilt = torch.zeros((ncat, W), dtype=torch.float32, device="cuda").index_add_(0, ids_all, rows_all.float())
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert not ex.overflowed()
+        assert np.array_equal(rebuilt.half().cpu().numpy().view(np.uint16), o_grad.view(np.uint16))
+        got_ids, got_rows = ex.compact(ids_all, rows_all, counts)
+        assert torch.equal(got_ids, want_ids.long()) and torch.equal(got_rows, want_rows)
+        assert torch.equal(out2, out)
     finally:
         dist.destroy_process_group()

@@ -167,8 +167,9 @@ def test_op_schemas_and_dtypes(pyt):
 
 @pytest.mark.parametrize("weighted", [False, True])
 def test_sparse_gradient_extension(pyt, weighted):
-    """sparse_grad=True returns the compressed gradient as a sparse COO tensor (coalesced at this size: one block) that
-    densifies to the dense-path gradient (and to nn.EmbeddingBag's)."""
+    """sparse_grad=True returns the compressed gradient as a COALESCED sparse COO tensor of exactly the looked-up rows
+    (on either backend; "reference" is its older name) that densifies to the dense-path gradient (and to
+    nn.EmbeddingBag's); "padded" / "fastest" are the opt-ins that never read the row count back."""
     k, d, B = 20000, 64, 2048
     bag = make_bag(k, d)
     lens = torch.randint(1, 20, (B,), device="cuda")
@@ -179,20 +180,36 @@ def test_sparse_gradient_extension(pyt, weighted):
     up = torch.randn(B, d, device="cuda")
     weight = bag.weight
     weight.grad = None
-    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad="reference") * up).sum().backward()
+    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=True) * up).sum().backward()
     g_sparse = weight.grad
     assert g_sparse.is_sparse
     assert g_sparse._nnz() == torch.unique(indices).numel()        # one entry per looked-up row
     ids = g_sparse._indices()[0]
     assert (ids[1:] > ids[:-1]).all()                                # ascending, no duplicates
-    # sparse_grad=True = the fastest form for the shape: at this size the row count is never read back and the tensor is
-    # padded to min(nnz, rows) entries (zero rows naming a row of the batch) -- the same gradient once coalesced
     weight.grad = None
-    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=True) * up).sum().backward()
-    g_fast = weight.grad
-    assert g_fast.is_sparse and not g_fast.is_coalesced() and g_fast._nnz() == min(n, k)
-    merged = g_fast.coalesce()
+    (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad="reference") * up).sum().backward()
+    assert torch.equal(weight.grad._indices(), g_sparse._indices()) and torch.equal(weight.grad._values(), g_sparse._values())
+    # the same contract from the Python autograd.Function (what torch.compile traces)
+    t2 = weight.detach().clone().requires_grad_(True)
+    (pyt._CuEmbEmbedding.apply(t2, indices, offsets, w, True, None) * up).sum().backward()
+    assert t2.grad._nnz() == g_sparse._nnz() and torch.equal(t2.grad._indices(), g_sparse._indices())
+    assert torch.equal(t2.grad._values(), g_sparse._values())
+    # "padded" (and "fastest" at this size): the row count is never read back and the tensor is padded to min(nnz, rows)
+    # entries (zero rows naming a row of the batch) -- the same gradient once coalesced; both backends
+    for kind in ("padded", "fastest"):
+        weight.grad = None
+        (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=kind) * up).sum().backward()
+        g_fast = weight.grad
+        assert g_fast.is_sparse and not g_fast.is_coalesced() and g_fast._nnz() == min(n, k), kind
+        merged = g_fast.coalesce()
+        assert torch.equal(merged._indices(), g_sparse._indices()) and torch.equal(merged._values(), g_sparse._values())
+    t2.grad = None
+    (pyt._CuEmbEmbedding.apply(t2, indices, offsets, w, "padded", None) * up).sum().backward()
+    assert t2.grad._nnz() == min(n, k)
+    merged = t2.grad.coalesce()
     assert torch.equal(merged._indices(), g_sparse._indices()) and torch.equal(merged._values(), g_sparse._values())
+    with pytest.raises(ValueError):
+        pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad="sorted")
     weight.grad = None
     (pyt.cuemb_embedding(weight, indices, offsets, w) * up).sum().backward()
     g_dense = weight.grad.clone()
@@ -227,7 +244,7 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     indices = (k * torch.rand(n, device="cuda") ** (2 if ragged else 3)).long()
     up = torch.randint(-1, 2, (B, d), device="cuda").half()
     grads = {}
-    for kind in ("reference", True, "uncoalesced", "blocked"):
+    for kind in ("reference", True, "fastest", "uncoalesced", "blocked"):
         weight.grad = None
         (pyt.cuemb_embedding(weight, indices, offsets, w, sparse_grad=kind) * up).sum().backward()
         grads[kind] = weight.grad
@@ -239,7 +256,9 @@ def test_uncoalesced_sparse_gradient_in_sample_blocks(pyt, ragged):
     n_unique = grads["reference"]._nnz()
     # exact in fp16: integers below 2048, or -- with weights 0.5 / 0.25 -- multiples of 0.25 below 512
     assert float(grads["reference"].to_dense().abs().max()) < (512 if ragged else 2048)
-    for kind in (True, "uncoalesced"):     # True = the fastest order for the shape: the sample-blocked one here
+    assert grads[True].is_sparse and torch.equal(grads[True]._indices(), grads["reference"]._indices())
+    assert torch.equal(grads[True]._values(), grads["reference"]._values())       # True = the coalesced tensor, always
+    for kind in ("fastest", "uncoalesced"):     # the fastest order for this shape is the sample-blocked one
         assert not grads[kind].is_coalesced()
         assert n_unique < grads[kind]._nnz() <= 2 * n_unique
         assert torch.equal(grads[kind].to_dense(), grads["reference"].to_dense())
@@ -301,7 +320,7 @@ def test_per_sample_weights_gradient_extension(pyt, d):
 
 
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
-@pytest.mark.parametrize("kind", [False, True, "reference"])
+@pytest.mark.parametrize("kind", [False, True, "fastest", "padded", "uncoalesced"])
 def test_native_autograd_node_equals_the_python_function(pyt, kind, idx_dtype):
     """Outside torch.compile cuemb_embedding runs as ONE native autograd node (CuEmbEmbeddingNode: forward, and row ids ->
     transpose + remap -> scatter-add in the backward, the row count read back after everything is enqueued); the
@@ -330,15 +349,18 @@ def test_native_autograd_node_equals_the_python_function(pyt, kind, idx_dtype):
             if kind is False:
                 assert torch.equal(t1.grad, t2.grad)
             else:
-                g1 = t1.grad
-                if kind is True:      # small batches: padded instead of read back (see test_sparse_gradient_extension)
+                g1, g2 = t1.grad, t2.grad
+                if kind in ("fastest", "padded"):  # small batches: padded instead of read back (see test_sparse_gradient_extension)
                     assert g1.is_sparse and g1._nnz() == min(n, k)
                     g1 = g1.coalesce()
-                assert g1.is_sparse and g1._nnz() == torch.unique(indices).numel()
+                    if kind == "padded":
+                        assert g2._nnz() == min(n, k)
+                    g2 = g2.coalesce()
+                assert g1.is_sparse and g1._nnz() == torch.unique(indices).numel()      # (True: as delivered)
                 ids = g1._indices()[0]
                 assert bool((ids[1:] > ids[:-1]).all())                       # one block: ascending, no duplicates
-                assert torch.equal(g1._indices(), t2.grad._indices())
-                assert torch.equal(g1._values(), t2.grad._values())
+                assert torch.equal(g1._indices(), g2._indices())
+                assert torch.equal(g1._values(), g2._values())
     # frozen table: no node, no gradient
     y = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad=kind)
     assert y.grad_fn is None
@@ -346,12 +368,12 @@ def test_native_autograd_node_equals_the_python_function(pyt, kind, idx_dtype):
 
 def test_native_node_large_and_small_gradients_in_turn(pyt):
     """The native node reads the row count back first above 192 MB of worst-case gradient, enqueues everything and
-    narrows afterwards below that ("reference") or pads and never reads it back below 64 MB (True): batches with few and
+    narrows afterwards below that (True) or pads and never reads it back below 64 MB ("fastest"): batches with few and
     with many distinct rows in turn, on all three paths."""
     torch.manual_seed(9)
     k, d, H = 300_000, 256, 50                               # 1 KiB rows
     table = torch.randn(k, d, device="cuda")
-    for B, kind in ((4096, True), (2048, "reference"), (1024, True)):   # 200 MB / 100 MB / 50 MB worst case
+    for B, kind in ((4096, "fastest"), (2048, True), (1024, "fastest")):   # 200 MB / 100 MB / 50 MB worst case
         offsets = torch.arange(0, B * H + 1, H, device="cuda")
         up = torch.randint(-3, 4, (B, d), device="cuda").float()     # integers: sums are exact in any order of the atomics
         narrow = torch.randint(0, 1000, (B * H,), device="cuda")
@@ -381,7 +403,7 @@ def test_native_step_replays_from_a_hip_graph(pyt):
     second = torch.randint(0, 2000, (B * H,), device="cuda")
     indices = first.clone()
     side = torch.cuda.Stream()
-    for kind in (False, True):
+    for kind in (False, "padded", "fastest"):
         def step():
             out = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad=kind, hints=None)
             (g,) = torch.autograd.grad(out, table, up)
@@ -407,7 +429,7 @@ def test_native_step_replays_from_a_hip_graph(pyt):
         graph = torch.cuda.CUDAGraph()
         with pytest.raises(RuntimeError, match="cannot be captured"):
             with torch.cuda.graph(graph, stream=side):
-                out = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad="reference", hints=None)
+                out = pyt.cuemb_embedding(table, indices, offsets, None, sparse_grad=True, hints=None)
                 torch.autograd.grad(out, table, up)
     torch.cuda.synchronize()
 
@@ -540,3 +562,49 @@ def test_opcheck_schemas_and_fake_kernels(pyt):
             (ops.cuembed_embedding_forward_fixed, (table, idx.view(B, H), None, "concat")),
             (ops.cuembed_embedding_weight_grad, (table, idx, off, gy))]:
         torch.library.opcheck(op, args, test_utils=checks)
+
+
+@pytest.mark.parametrize("kind", [False, True, "fastest"])
+@pytest.mark.parametrize("dtypes", [(torch.int64, torch.int32), (torch.int32, torch.int64)], ids=["idx64_off32", "idx32_off64"])
+def test_backward_with_indices_and_offsets_of_different_integer_types(pyt, dtypes, kind):
+    """The forward takes indices and offsets of different integer types (a type code each); the backward's index work
+    has one type for lookups and sample ids and follows the indices -- it used to build the sample ids in the type of the
+    offsets and hand both arrays on under ONE type code (out-of-bounds accesses for int64 indices + int32 offsets, a wrong
+    gradient the other way round).  Native node and Python function, against same-type inputs."""
+    idx_t, off_t = dtypes
+    torch.manual_seed(11)
+    k, d, B = 3000, 32, 700
+    lens = torch.randint(0, 12, (B,), device="cuda")
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens.cumsum(0)])
+    n = int(offsets[-1])
+    indices = torch.randint(0, k, (n,), device="cuda")
+    table = torch.randn(k, d, device="cuda")
+    up = torch.randint(-3, 4, (B, d), device="cuda").float()
+    w = torch.randint(1, 4, (n,), device="cuda").float() * 0.5
+    for weights in (None, w):
+        want_t = table.clone().requires_grad_(True)
+        want = pyt.cuemb_embedding(want_t, indices, offsets, weights, sparse_grad=kind, hints=None)
+        want.backward(up)
+        for apply in (lambda t: pyt.cuemb_embedding(t, indices.to(idx_t), offsets.to(off_t), weights, sparse_grad=kind, hints=None),
+                      lambda t: pyt._CuEmbEmbedding.apply(t, indices.to(idx_t), offsets.to(off_t), weights, kind, None)):
+            t = table.clone().requires_grad_(True)
+            got = apply(t)
+            got.backward(up)
+            assert torch.equal(got, want)
+            g, gw = t.grad, want_t.grad
+            if kind is not False:
+                g, gw = g.to_dense(), gw.to_dense()
+            assert torch.equal(g, gw)
+
+
+def test_backward_rejects_weights_of_the_wrong_length(pyt):
+    """The forward reads the first nnz weights of a longer tensor; the backward moves exactly nnz of them with the
+    lookups, so a different length is an error there (it used to be unchecked in the native node)."""
+    k, d, B, H = 100, 16, 10, 4
+    table = torch.randn(k, d, device="cuda", requires_grad=True)
+    offsets = torch.arange(0, B * H + 1, H, device="cuda")
+    indices = torch.randint(0, k, (B * H,), device="cuda")
+    w = torch.rand(B * H + 3, device="cuda")
+    out = pyt.cuemb_embedding(table, indices, offsets, w, hints=None)
+    with pytest.raises((RuntimeError, ValueError)):
+        out.sum().backward()

@@ -122,6 +122,39 @@ def main():
             rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device=dev)
             rebuilt[ids.long()] = summed
             check(algorithm + ": sparse exchange == dense all-reduce", torch.equal(rebuilt, dense))
+        # ---- the fixed-capacity exchange (SparseGradExchange): sizes from a warm-up step, then device-side counts only
+        want_ids, want_rows = D.allreduce_sparse_grad(rows, inv, ncat, algorithm="owner")
+        ex = D.SparseGradExchange.calibrate(rows_cap, inv_cap, ncat, count=remap[-1:] + 1)
+        for step in range(3):
+            pending = ex.start(rows_cap, inv_cap, count=remap[-1:] + 1)
+            ids_all, rows_all, counts = pending.wait()
+            ex.note_flags(pending)
+            # the result as it comes is a valid uncoalesced COO gradient: zero rows with valid ids fill the slack
+            rebuilt = torch.zeros((ncat, W), dtype=torch.float32, device=dev).index_add_(0, ids_all, rows_all.float())
+            check("fixed-capacity exchange, scatter-added as it comes == dense all-reduce", torch.equal(rebuilt.half(), dense))
+            got_ids, got_rows = ex.compact(ids_all, rows_all, counts)
+            check("fixed-capacity exchange == exact exchange (ids)", torch.equal(got_ids, want_ids.long()))
+            check("fixed-capacity exchange == exact exchange (rows, same bits)", torch.equal(got_rows, want_rows))
+        check("fixed-capacity exchange: no overflow", not ex.overflowed())
+        ex_u = D.SparseGradExchange.calibrate(b_rows, b_inv, ncat, coalesced=False)
+        pending = ex_u.start(b_rows, b_inv, coalesced=False, async_op=False)
+        got_ids, got_rows = ex_u.compact(*pending.wait())
+        rebuilt = torch.zeros((ncat, W), dtype=torch.float16, device=dev)
+        rebuilt[got_ids] = got_rows
+        check("fixed-capacity exchange of an uncoalesced gradient == dense all-reduce",
+              torch.equal(rebuilt, dense) and bool((got_ids[1:] > got_ids[:-1]).all()) and not ex_u.overflowed())
+        tight = D.SparseGradExchange(ncat, W, torch.float16, dev, pair_capacity=max((ex.pair_capacity - 16) // 3, 1),
+                                     piece_capacity=ex.piece_capacity)
+        pending = tight.start(rows, inv)
+        ids_all, rows_all, counts = pending.wait()
+        tight.note_flags(pending)
+        check("slots too small: sticky flag on every rank, well-formed result",
+              tight.overflowed(reset=True) and not tight.overflowed() and int(ids_all.min()) >= 0
+              and int(ids_all.max()) < ncat and bool(torch.isfinite(rows_all.float()).all()))
+        tight = D.SparseGradExchange(ncat, W, torch.float16, dev, pair_capacity=ex.pair_capacity, piece_capacity=3)
+        pending = tight.start(rows, inv, async_op=False)
+        ids_all, rows_all, counts = pending.wait()
+        check("piece too small: flag, ids still valid", tight.overflowed() and int(ids_all.min()) >= 0 and int(ids_all.max()) < ncat)
         # every rank ended with the same gradient
         digest = torch.tensor([float(dense.float().abs().sum().item())], dtype=torch.float64)
         both = [torch.zeros_like(digest) for _ in range(world)]

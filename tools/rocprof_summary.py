@@ -14,6 +14,7 @@ from collections import defaultdict
 def main():
     d = sys.argv[1]
     match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else None
+    groups = int(sys.argv[sys.argv.index("--groups") + 1]) if "--groups" in sys.argv else 0   # dispatch-order groups
     files = sorted(glob.glob(os.path.join(d, "**", "*.csv"), recursive=True))
     for f in files:
         base = os.path.basename(f)
@@ -43,6 +44,8 @@ def main():
                          m.get("VGPR_Count"), m.get("SGPR_Count"), m.get("Scratch_Size")))
         elif base.endswith("counter_collection.csv"):
             agg = defaultdict(lambda: defaultdict(list))
+            if rows and "Dispatch_Id" in rows[0]:
+                rows.sort(key=lambda r: int(r["Dispatch_Id"]))
             for r in rows:
                 name = r.get("Kernel_Name", "?")
                 if match and match not in name:
@@ -53,6 +56,10 @@ def main():
                 print("  %s" % name[:160])
                 for c, v in sorted(cs.items()):
                     print("     %-28s dispatches=%d avg=%.4g min=%.4g max=%.4g" % (c, len(v), sum(v) / len(v), min(v), max(v)))
+                    if groups and len(v) % groups == 0 and len(v) > groups:
+                        n = len(v) // groups
+                        print("     %-28s   by dispatch order, %d groups of %d: %s"
+                              % ("", groups, n, "  ".join("%.5g" % (sum(v[g * n:(g + 1) * n]) / n) for g in range(groups))))
 
 
 if __name__ == "__main__":

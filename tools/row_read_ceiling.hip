@@ -378,7 +378,45 @@ double Run(const char* table, int row_bytes, const int* lookups, int64_t n, unsi
   return ms / iters;
 }
 
+// Address translation (`--span`): the headline's launch shape, loads only, K = 8, with the SAME index streams spread
+// over more and more address space -- row id * stride, the table grown to match -- so that reuse, L2 / MALL hit rates and
+// DRAM bytes stay what they are and only the number of distinct pages behind them grows (alpha 1.15: 570 k distinct
+// rows per batch; alpha 0: 4.1 M).  If translation mattered for random 512-byte gathers, the time would grow with the
+// span; TCP_UTCL1_TRANSLATION_MISS of the same runs is in profiles/r06_translation_counters.txt.
+int TranslationSpan() {
+  const int64_t base_rows = 10000000;
+  const int batch = 65536, hotness = 64, batches = 4;
+  const int strides[] = {1, 2, 4, 8, 16, 32};
+  const int64_t max_rows = base_rows * 32;
+  char* table = nullptr;
+  int* lookups = nullptr;
+  unsigned* sink = nullptr;
+  HIP_OK(hipMalloc(&table, max_rows * 512));          // 164 GB of the 288
+  HIP_OK(hipMemset(table, 1, max_rows * 512));
+  HIP_OK(hipMalloc(&sink, 64));
+  std::vector<int> h(static_cast<size_t>(batches) * batch * hotness), scaled(h.size());
+  HIP_OK(hipMalloc(&lookups, h.size() * sizeof(int)));
+  std::printf("pattern,alpha,row_id_stride,span_GB,policy,ms_per_batch,row_GBps\n");
+  for (const double alpha : {1.15, 0.0}) {
+    cuembed_harness_generate_indices(base_rows, batches * batch, hotness, alpha, 1, 1, 0, nullptr, h.data());
+    for (const int stride : strides) {
+      for (size_t i = 0; i < h.size(); ++i) scaled[i] = h[i] * stride;
+      HIP_OK(hipMemcpy(lookups, scaled.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+      const double row_bytes = static_cast<double>(batch) * hotness * 512;
+      const double ms = RunSamples<8, false>(table, lookups, batches, batch, hotness, sink);
+      const double ms_nt = RunSamples<8, true>(table, lookups, batches, batch, hotness, sink);
+      std::printf("c2_samples_span,%.2f,%d,%.1f,default,%.4f,%.0f\n", alpha, stride, base_rows * 512.0 * stride / 1e9, ms,
+                  row_bytes / ms / 1e6);
+      std::printf("c2_samples_span,%.2f,%d,%.1f,nt,%.4f,%.0f\n", alpha, stride, base_rows * 512.0 * stride / 1e9, ms_nt,
+                  row_bytes / ms_nt / 1e6);
+      std::fflush(stdout);
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "--span") return TranslationSpan();
   if (argc > 1 && std::string(argv[1]) == "--c2-parts") return HeadlineParts(argc > 2 ? std::atof(argv[2]) : 0.0);
   if (argc > 1 && std::string(argv[1]) == "--c2") return HeadlinePattern(argc > 2 ? std::atof(argv[2]) : 1.15);
   const int64_t table_bytes = int64_t{5} << 30;       // 5 GiB: far beyond L2 (32 MiB) and the Infinity Cache (256 MiB)

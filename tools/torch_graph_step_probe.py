@@ -23,7 +23,7 @@ for B in (1024, 2048):   # (padded, read-back-free gradients: up to 64 MiB of wo
     up = torch.randint(-2, 3, (B, W), device=dev).to(torch.float16)
 
     def step():
-        out = P.cuemb_embedding(table, idx, offsets, None, sparse_grad=True, hints=None)
+        out = P.cuemb_embedding(table, idx, offsets, None, sparse_grad="padded", hints=None)
         (g,) = torch.autograd.grad(out, table, up)
         return out, g
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end time of one training step through the torch op surface (cuemb_embedding forward +
 autograd backward), int64 indices as the reference's binding requires; dense gradient (the
-reference's behaviour) and sparse_grad=True (extension: compressed rows as a sparse COO tensor).
+reference's behaviour) and sparse_grad="fastest" (extension: compressed rows as a sparse COO tensor, the fastest order for the shape).
 
     python tools/torch_op_step_probe.py                       # native binding (libcuembed_pyt.so)
     CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py   # same ops registered from Python (ctypes)
@@ -33,7 +33,7 @@ for dtype in (torch.float16, torch.float32):
                 if kind == "fixed_layout_dense":
                     out = P.cuemb_embedding_fixed(table, idx.view(B, H))
                 else:
-                    out = P.cuemb_embedding(table, idx, offsets, None, sparse_grad=(kind == "sparse"))
+                    out = P.cuemb_embedding(table, idx, offsets, None, sparse_grad=("fastest" if kind == "sparse" else False))
                 out.backward(up)
             for _ in range(3):
                 step()
