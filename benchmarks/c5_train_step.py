@@ -95,6 +95,17 @@ class TrainStep:
                                 coalesced=self.order != "blocked_uncoalesced")
         return None   # (the row count lives on the device; see exchanged_bytes())
 
+    def exchange_fixed(self, D, plan):
+        """The same sum through the fixed-capacity exchange (cuembed_amd.distributed.SparseGradExchange): no host
+        read-back; returns the pending result (its all-gather may still be in flight)."""
+        return plan.start(self.comp_rows, self.comp_inv, count=self.count,
+                          coalesced=self.order != "blocked_uncoalesced")
+
+    def calibrate_exchange(self, D, headroom=1.25):
+        """(warm-up, after a compute()) capacities for exchange_fixed from this step's sizes; reads them back."""
+        return D.SparseGradExchange.calibrate(self.comp_rows, self.comp_inv, self.rows, count=self.count,
+                                              coalesced=self.order != "blocked_uncoalesced", headroom=headroom)
+
     def exchanged_bytes(self):
         """(after a step) gradient bytes this rank puts on the wire: rows x (W x elem + 8-byte id) -- one read-back"""
         if self.dense is not None:

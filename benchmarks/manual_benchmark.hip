@@ -16,6 +16,8 @@
 #include <dlfcn.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <unistd.h>
 
 #include <cstdint>
@@ -333,11 +335,22 @@ struct Timer {
   void ClearCache() {
     if (clear) FlushKernel<<<2048, 256>>>(flush.ptr, static_cast<int64_t>(flush.n), sink.ptr);
   }
+  //! per-iteration times of the last Run in the flushed protocol (every iteration is timed alone there): the sweep
+  //! reports their minimum and median next to the reference's mean, so that one slow iteration is seen for what it is
+  std::vector<float> samples;
+  float Min() const { return samples.empty() ? 0.f : *std::min_element(samples.begin(), samples.end()); }
+  float Median() const {
+    if (samples.empty()) return 0.f;
+    std::vector<float> v(samples);
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    return v[v.size() / 2];
+  }
   template <typename Fn>
   float Run(int iterations, Fn fn) {
     fn();  // warm-up
     ClearCache();
     float total = 0.f;
+    samples.clear();
     for (int it = 0; it < iterations; ++it) {
       if (clear || it == 0) HIP_OK(hipEventRecord(start));
       fn();
@@ -347,6 +360,7 @@ struct Timer {
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, start, stop));
         total += ms;
+        if (clear) samples.push_back(ms);
       }
       ClearCache();
     }
@@ -355,18 +369,20 @@ struct Timer {
   }
 };
 
-void CsvLine(const Flags& f, const char* name, double ms, double bw_l2, double bw_dram) {
+void CsvLine(const Flags& f, const char* name, double ms, double bw_l2, double bw_dram, const Timer& timer) {
   if (!f.enable_csv) return;
   const char* fname = "manual_benchmark_out.csv";
   bool existed = std::ifstream(fname).good();
   std::ofstream out(fname, std::ios::app);
   if (!existed)
     out << "num_categories,batch_size,hotness,alpha,embed_width,combine_mode,is_csr,is_weighted,"
-           "compressed_grad,skip_grad_init,name,iterations,elapsed_time_ms,avg_time_ms,algo_bw_l2,algo_bw_dram\n";
+           "compressed_grad,skip_grad_init,name,iterations,elapsed_time_ms,avg_time_ms,algo_bw_l2,algo_bw_dram,"
+           "min_time_ms,median_time_ms\n";      // (the reference's columns, then this benchmark's two)
   char buf[512];
-  std::snprintf(buf, sizeof buf, "%d,%d,%d,%g,%d,kSum,%d,%d,%d,%d,%s,%d ,%.2f ,%.4f ,%.2f,%.2f\n",
+  std::snprintf(buf, sizeof buf, "%d,%d,%d,%g,%d,kSum,%d,%d,%d,%d,%s,%d ,%.2f ,%.4f ,%.2f,%.2f,%.5f,%.5f\n",
                 f.num_categories, f.batch_size, f.hotness, f.alpha, f.embed_width, f.csr_input, f.weighted_sum,
-                f.compressed_grad, f.skip_grad_init, name, f.iterations, ms, ms / f.iterations, bw_l2, bw_dram);
+                f.compressed_grad, f.skip_grad_init, name, f.iterations, ms, ms / f.iterations, bw_l2, bw_dram,
+                timer.Min(), timer.Median());
   out << buf;
 }
 
@@ -428,7 +444,7 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
                        "Application BW [GB/s]: %.2f (algorithmic bytes / time: cache hits count, NOT an HBM "
                        "rate -- bench.py's roofline block has the measured fabric traffic)\n",
                f.iterations, ms, ms / it, bw);
-  CsvLine(f, "forward", ms, bw, 0.0);
+  CsvLine(f, "forward", ms, bw, 0.0, timer);
   if (f.check_result) {   // (manual_benchmark.cu:278-285)
     const std::vector<ElemT> table = device_fill ? Download(w.table.ptr, static_cast<size_t>(cells)) : h_table;
     std::vector<ElemT> want(static_cast<size_t>(f.batch_size) * f.embed_width);
@@ -474,7 +490,7 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
   bw = tb * it / 1e6 / ms;
   std::fprintf(stderr, "Transpose. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
                        "Application BW [GB/s]: %.2f\n", f.iterations, ms, ms / it, bw);
-  CsvLine(f, "transpose", ms, 0.0, bw);
+  CsvLine(f, "transpose", ms, 0.0, bw, timer);
   std::vector<IndexT> c_idx, c_sid, c_remap;
   std::vector<ElemT> c_w;
   if (f.check_result) {   // (manual_benchmark.cu:373-386; the device contract: a STABLE sort by index)
@@ -535,7 +551,7 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
   std::fprintf(stderr, "Backward. Iterations: %d , Total time [ms]: %.2f , Avg [ms]: %.4f , "
                        "Application DRAM BW [GB/s]: %.2f , Application L2 BW [GB/s]: %.2f\n",
                f.iterations, ms, ms / it, dram * it / 1e6 / ms, l2 * it / 1e6 / ms);
-  CsvLine(f, "backward", ms, l2 * it / 1e6 / ms, dram * it / 1e6 / ms);
+  CsvLine(f, "backward", ms, l2 * it / 1e6 / ms, dram * it / 1e6 / ms, timer);
   if (f.check_result) {   // (manual_benchmark.cu:495-507)
     // the timed iterations may have run with skip_grad_init onto a buffer that earlier iterations had written
     // (only their time means anything): one more call into a zeroed buffer is what is compared

@@ -29,6 +29,11 @@ def _declare(L):
     L.cuembed_embedding_forward_ordered.restype = None
     L.cuembed_embedding_forward_ordered.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I, _VP,
                                                     _VP]
+    L.cuembed_embedding_forward_device_hints.restype = None
+    L.cuembed_embedding_forward_device_hints.argtypes = [_VP, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I,
+                                                         _VP, _VP, _VP]
+    L.cuembed_decide_row_loads.restype = None
+    L.cuembed_decide_row_loads.argtypes = [_VP, _I, ctypes.c_int64, ctypes.c_int64, _VP, ctypes.c_uint, _VP]
     L.cuembed_bag_order_by_length.restype = None
     L.cuembed_bag_order_by_length.argtypes = [_VP, _I, _I, _I, _VP, _VP, ctypes.POINTER(ctypes.c_size_t), _VP]
     L.cuembed_set_forward_row_load_policy.restype = None

@@ -13,10 +13,11 @@ template <typename ElemT, typename IndexT, typename OffsetT>
 void Forward(const void* params, int embed_width, const IndexT* indices, const OffsetT* offsets,
              const void* weights, int batch_size, int num_hots, int mode, int fp16_math,
              void* ret, cuembed_stream_t stream, int reduction_order = -1, int row_load_policy = -1,
-             const int32_t* sample_order = nullptr) {
+             const int32_t* sample_order = nullptr, const uint32_t* row_loads_device = nullptr) {
   // per-call options (cuembed_embedding_forward_with_options); < 0 = the process-wide default
   cuembed::ForwardOptions options = cuembed::DefaultForwardOptions();
   options.sample_order = sample_order;
+  options.row_loads_device = row_loads_device;
   CUEMBED_ASSERT(reduction_order <= 1 && row_load_policy <= 1);
   if (reduction_order >= 0) options.reduction_order = static_cast<cuembed::ReductionOrder>(reduction_order);
   if (row_load_policy >= 0) options.row_loads = static_cast<cuembed::RowLoadPolicy>(row_load_policy);
@@ -86,10 +87,33 @@ void cuembed_embedding_forward_ordered(const void* params, int elem_type, int em
                                        int num_hots, int mode, int fp16_math, void* ret,
                                        int reduction_order, int row_load_policy,
                                        const int32_t* sample_order, cuembed_stream_t stream) {
+  cuembed_embedding_forward_device_hints(params, elem_type, embed_width, indices, index_type, offsets, offset_type,
+                                         weights, batch_size, num_hots, mode, fp16_math, ret, reduction_order,
+                                         row_load_policy, sample_order, nullptr, stream);
+}
+
+void cuembed_decide_row_loads(const void* indices, int index_type, int64_t nnz, int64_t table_bytes,
+                              uint32_t* decision, unsigned distinct_per_1024, cuembed_stream_t stream) {
+  const unsigned th = distinct_per_1024 != 0u ? distinct_per_1024 : cuembed::kStreamingDistinctPer1024;
+  if (index_type == CUEMBED_I32)
+    cuembed::DecideRowLoads<int32_t>(static_cast<const int32_t*>(indices), nnz, table_bytes, decision, Stream(stream), th);
+  else if (index_type == CUEMBED_I64)
+    cuembed::DecideRowLoads<int64_t>(static_cast<const int64_t*>(indices), nnz, table_bytes, decision, Stream(stream), th);
+  else
+    CUEMBED_C_API_BAD_TYPE();
+}
+
+void cuembed_embedding_forward_device_hints(const void* params, int elem_type, int embed_width,
+                                            const void* indices, int index_type, const void* offsets,
+                                            int offset_type, const void* weights, int batch_size,
+                                            int num_hots, int mode, int fp16_math, void* ret,
+                                            int reduction_order, int row_load_policy,
+                                            const int32_t* sample_order, const uint32_t* row_loads_device,
+                                            cuembed_stream_t stream) {
 #define FWD(E, I, O)                                                                          \
   Forward<E, I, O>(params, embed_width, static_cast<const I*>(indices),                       \
                    static_cast<const O*>(offsets), weights, batch_size, num_hots, mode,       \
-                   fp16_math, ret, stream, reduction_order, row_load_policy, sample_order)
+                   fp16_math, ret, stream, reduction_order, row_load_policy, sample_order, row_loads_device)
   const int key = (elem_type << 2) | (index_type << 1) | (offsets ? offset_type : 0);
   switch (key) {
     case 0: FWD(float, int32_t, int32_t); break;

@@ -24,6 +24,7 @@
 #include "cuembed/include/cuembed_assert.hpp"
 #include "cuembed/include/embedding_types.hpp"
 #include "cuembed/include/gather_reduce_kernels.hpp"
+#include "cuembed/include/hint_kernels.hpp"
 #include "cuembed/include/scatter_add_kernels.hpp"
 
 namespace cuembed {
@@ -59,6 +60,10 @@ struct ForwardOptions {
   //! unequal bags end at different times.  With the bags in descending order of length (BagOrderByLength,
   //! index_transforms.hpp; it only depends on the offsets) C3 takes 0.156 instead of 0.169 ms.
   const int32_t* sample_order = nullptr;
+  //! (extension) the row-load decision left in device memory by DecideRowLoads (below): when non-null the kernels read
+  //! word 0 of it (0: ordinary loads, 1: non-temporal) INSTEAD of `row_loads` -- the host never learns the answer, so
+  //! the decision can be taken from the batch's own indices inside a stream-ordered step or a HIP graph.
+  const uint32_t* row_loads_device = nullptr;
 };
 
 namespace detail {
@@ -285,10 +290,10 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
     const size_t lds = samples * (chunk * lanes * sizeof(Pack<ElemT, N>) + (weighted ? chunk * sizeof(ElemT) : 0));
     if (weighted)
       GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, true><<<wgrid, wblock, lds, stream>>>(
-          table, width, batch, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
+          table, width, batch, indices, offsets, num_hots, weights, is_mean, out, stream_rows, options.row_loads_device);
     else
       GatherReduceWideLoadKernel<ElemT, AccT, IndexT, OffsetT, N, false><<<wgrid, wblock, lds, stream>>>(
-          table, width, batch, indices, offsets, num_hots, weights, is_mean, out, stream_rows);
+          table, width, batch, indices, offsets, num_hots, weights, is_mean, out, stream_rows, options.row_loads_device);
     return;
   }
   const dim3 block(f.split.lanes_per_row, f.split.rows_per_block, 1);
@@ -297,7 +302,8 @@ inline void LaunchGatherReduce(const ElemT* table, int width, const IndexT* indi
   GatherReduceKernel<ElemT, AccT, IndexT, OffsetT, N, W, SRC>                             \
       <<<grid, block, f.stage_bytes, stream>>>(table, width, batch, indices, offsets,     \
                                                num_hots, weights, is_mean, out, 1, stream_rows, \
-                                               offsets != nullptr ? options.sample_order : nullptr)
+                                               offsets != nullptr ? options.sample_order : nullptr, \
+                                               options.row_loads_device)
   if (f.staged) {
     if (weighted) CUEMBED_LAUNCH_GR(true, IndexSource::kLdsStaged);
     else CUEMBED_LAUNCH_GR(false, IndexSource::kLdsStaged);
@@ -433,6 +439,42 @@ void EmbeddingForward(const InputT* params,
   EmbeddingForward<InputT, OutputT, IndexT, OffsetT, fp16_math>(params, embed_width, indices, offsets, weights,
                                                                 batch_size, num_hots, mode, ret, stream,
                                                                 DefaultForwardOptions());
+}
+
+//! Tables below this size, and batches of fewer lookups, are never streamed (the batch is latency-bound or the table
+//! lives in the caches whatever the loads are): DecideRowLoads answers "default" for them without looking.
+constexpr int64_t kStreamingMinTableBytes = int64_t{1} << 30;
+constexpr int64_t kStreamingMinLookups = int64_t{1} << 18;
+//! ... and at least this share of a strided sample's rows must be distinct (x / 1024; measured crossover: see
+//! tools/row_loads_crossover_probe.py -- streaming loses as soon as rows repeat inside the caches' reach).
+constexpr unsigned kStreamingDistinctPer1024 = 973;    // 0.95
+
+/**
+ * @brief RowLoadPolicy decided ON THE DEVICE from the batch's own indices (extension): an evenly strided sample of up
+ * to 65,536 lookups is cut into groups of 4,096, every group's DISTINCT rows are counted exactly (one workgroup and
+ * one LDS hash set per group), and `decision[0]` becomes 1 (kStreaming) when at least `distinct_per_1024` / 1024 of
+ * the sample is distinct, the table has `table_bytes` >= 1 GiB and the batch >= 2^18 lookups -- else 0.  One launch,
+ * no read-back: pass `decision` as ForwardOptions::row_loads_device to the EmbeddingForward calls that follow (this
+ * batch and, for a stationary index distribution, the next few hundred).
+ * `decision`: FOUR 32-bit words of device memory, zeroed once by the caller (word 0 = the decision, the others are the
+ * kernel's arrival counters and are left at zero); calls that share them must be stream-ordered.
+ */
+template <typename IndexT>
+void DecideRowLoads(const IndexT* indices,
+                    const int64_t nnz,
+                    const int64_t table_bytes,
+                    uint32_t* decision,
+                    const hipStream_t stream = 0,
+                    const unsigned distinct_per_1024 = kStreamingDistinctPer1024) {
+  CUEMBED_ASSERT(decision != nullptr);
+  if (nnz < kStreamingMinLookups || table_bytes < kStreamingMinTableBytes || indices == nullptr) {
+    detail::ClearRowLoadsDecisionKernel<0><<<1, 64, 0, stream>>>(decision);
+    return;
+  }
+  int64_t groups = nnz / detail::kDecideGroupSample;
+  groups = groups > detail::kDecideMaxGroups ? detail::kDecideMaxGroups : groups;
+  detail::DecideRowLoadsKernel<IndexT><<<static_cast<unsigned>(groups), detail::kDecideThreads, 0, stream>>>(
+      indices, nnz, detail::kDecideGroupSample, distinct_per_1024, decision);
 }
 
 /**

@@ -339,9 +339,12 @@ GatherReduceKernel(const ElemT* __restrict__ table,
                    const bool is_mean,
                    ElemT* __restrict__ out,
                    const int column_slices,    // 1, 2, 4 or 8 (see ColumnSlice)
-                   const bool stream_rows,     // RowLoadPolicy::kStreaming: table rows are not kept in L2
-                   const int32_t* __restrict__ sample_order = nullptr) {   // ForwardOptions::sample_order (CSR only)
+                   const bool stream_rows_host, // RowLoadPolicy::kStreaming: table rows are not kept in L2
+                   const int32_t* __restrict__ sample_order = nullptr,    // ForwardOptions::sample_order (CSR only)
+                   const uint32_t* __restrict__ row_loads_device = nullptr) {   // ForwardOptions::row_loads_device
   using A = Arith<AccT>;
+  // (the decision taken on the device, DecideRowLoads: one scalar load, the same value for every wavefront)
+  const bool stream_rows = row_loads_device != nullptr ? (*row_loads_device != 0u) : stream_rows_host;
   const int lane_x = threadIdx.x;
   const int slot = threadIdx.y;
   const int samples_per_block = blockDim.y;
@@ -570,8 +573,10 @@ __global__ void __launch_bounds__(kWideLoadThreads)
 GatherReduceWideLoadKernel(const ElemT* __restrict__ table, const int width, const int batch,
                            const IndexT* __restrict__ indices, const OffsetT* __restrict__ offsets,  // null => fixed hotness
                            const int num_hots, const ElemT* __restrict__ weights, const bool is_mean,
-                           ElemT* __restrict__ out, const bool stream_rows) {
+                           ElemT* __restrict__ out, const bool stream_rows_host,
+                           const uint32_t* __restrict__ row_loads_device = nullptr) {
   using A = Arith<AccT>;
+  const bool stream_rows = row_loads_device != nullptr ? (*row_loads_device != 0u) : stream_rows_host;
   constexpr int kWordElems = 4 / static_cast<int>(sizeof(ElemT));   // elements in a 32-bit word: 1 (fp32) or 2
   extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds_raw[];
   __shared__ int longest_bag;

@@ -1,0 +1,174 @@
+// Device-side decisions for EmbeddingForward's scheduling hints (extensions; a hint never changes a result).
+//
+// The reference picks its launch parameters from the shape alone (embedding_lookup.cuh:186-208: one rule for every
+// index distribution).  Two of this library's options depend on the DATA -- non-temporal row loads pay only when the
+// rows of a batch are (nearly) all distinct, the bag order only for ragged bags -- and a caller of the C++ / C API
+// cannot be asked to read index statistics back to the host in the middle of a step.  Both decisions are taken on the
+// device here, in ONE launch each, without a read-back, so they can sit inside a stream-ordered step and a HIP graph:
+//   DecideRowLoadsKernel    counts the distinct rows of an evenly strided sample of the batch exactly (LDS hash
+//                           sets) and leaves a flag word in device memory that the forward kernels read;
+//   BagOrderCountingKernel  the samples of a CSR batch by descending bag length -- a stable counting sort on lengths
+//                           clamped to 255 -- for ForwardOptions::sample_order.
+#ifndef CUEMBED_INCLUDE_HINT_KERNELS_HPP_
+#define CUEMBED_INCLUDE_HINT_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cuembed/include/sort_common.hpp"
+
+namespace cuembed {
+namespace detail {
+
+// ---------------------------------------------------------------------------
+// Row-load decision.  `groups` workgroups; workgroup g takes the sample elements j * groups + g (j < per_group) of an
+// evenly strided sample of the lookups and counts how many DIFFERENT rows they name: every key goes into an
+// open-addressing hash set in LDS (2 x per_group slots, full keys compared: the count is exact, not an estimate).  The
+// last workgroup to arrive adds the counts up and writes the decision -- nobody waits for anybody, so residency does
+// not matter.  words[0] = decision (1: streaming), words[1] = arrivals, words[2] = distinct rows (both left at zero).
+// ---------------------------------------------------------------------------
+constexpr int kDecideThreads = 1024;
+constexpr int kDecideGroupSample = 4096;   // lookups per workgroup
+constexpr int kDecideSlots = 8192;         // hash slots per workgroup (load factor <= 0.5)
+constexpr int kDecideMaxGroups = 16;       // 65,536 sampled lookups at most
+
+template <typename IndexT>
+__global__ void __launch_bounds__(kDecideThreads)
+DecideRowLoadsKernel(const IndexT* __restrict__ indices, const int64_t nnz, const int per_group,
+                     const unsigned threshold_per_1024, uint32_t* __restrict__ words) {
+  using Key = typename std::conditional<sizeof(IndexT) == 8, unsigned long long, unsigned>::type;
+  __shared__ Key slots[kDecideSlots];
+  __shared__ unsigned distinct;
+  constexpr Key kEmpty = ~Key(0);
+  for (int i = threadIdx.x; i < kDecideSlots; i += kDecideThreads) slots[i] = kEmpty;
+  if (threadIdx.x == 0) distinct = 0u;
+  __syncthreads();
+  const int groups = static_cast<int>(gridDim.x);
+  const int64_t sampled = static_cast<int64_t>(per_group) * groups;
+  const int64_t stride = nnz / sampled > 0 ? nnz / sampled : 1;
+  unsigned mine = 0;
+  for (int j = threadIdx.x; j < per_group; j += kDecideThreads) {
+    const int64_t at = (static_cast<int64_t>(j) * groups + blockIdx.x) * stride;
+    if (at >= nnz) break;
+    const Key key = static_cast<Key>(indices[at]);
+    if (key == kEmpty) continue;                                   // (-1 is not a row)
+    unsigned h = (static_cast<unsigned>(key) ^ static_cast<unsigned>(static_cast<unsigned long long>(key) >> 32)) * 0x9E3779B1u;
+    h >>= 32 - 13;                                                  // kDecideSlots = 2^13
+    for (;;) {
+      const Key seen = atomicCAS(&slots[h], kEmpty, key);
+      if (seen == kEmpty) {
+        ++mine;
+        break;
+      }
+      if (seen == key) break;
+      h = (h + 1) & (kDecideSlots - 1);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine != 0) atomicAdd(&distinct, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(words + 2, distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (release: my count is out before my arrival; acquire: the last one sees every count)
+    const unsigned before = __hip_atomic_fetch_add(words + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == static_cast<unsigned>(groups)) {
+      const unsigned total = __hip_atomic_load(words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int64_t taken = sampled < nnz ? sampled : nnz;
+      const bool streaming = static_cast<uint64_t>(total) * 1024u >= static_cast<uint64_t>(threshold_per_1024) * static_cast<uint64_t>(taken);
+      __hip_atomic_store(words + 0, streaming ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(words + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next call
+      __hip_atomic_store(words + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+//! (small batches and small tables: the decision is "default" without looking)
+template <int kUnused = 0>   // (a template so that the header can be included from several translation units)
+__global__ void ClearRowLoadsDecisionKernel(uint32_t* __restrict__ words) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) words[0] = 0u;
+}
+
+// ---------------------------------------------------------------------------
+// Bag order in one launch: sample_order = the samples by DESCENDING min(bag length, 255), ties in input order (a stable
+// counting sort over 256 keys).  Workgroup w owns samples [1024 w, 1024 w + 1024).  No workgroup waits for another:
+// every one counts the keys of the WHOLE batch itself (the offsets are a few hundred KB and come from L2) -- the
+// counts of the samples before its own range and the totals -- then ranks its own 1,024 samples with the sort's
+// wave-synchronous match (MatchDigit) and writes their positions.  Worth it up to ~2^17 samples; BagOrderByLength
+// falls back to the general sort above that and for length bounds beyond 255.
+// ---------------------------------------------------------------------------
+constexpr int kBagOrderThreads = 1024;
+constexpr int kBagOrderWaves = kBagOrderThreads / 64;
+constexpr int kBagOrderMaxBatch = 1 << 17;
+
+template <typename OffsetT>
+__device__ __forceinline__ unsigned BagKey(const OffsetT* __restrict__ offsets, const int s, const int bound) {
+  int64_t len = static_cast<int64_t>(offsets[s + 1]) - static_cast<int64_t>(offsets[s]);
+  len = len < 0 ? 0 : (len > bound ? bound : len);
+  return static_cast<unsigned>(bound - static_cast<int>(len));     // ascending keys = descending lengths
+}
+
+template <typename OffsetT>
+__global__ void __launch_bounds__(kBagOrderThreads)
+BagOrderCountingKernel(const OffsetT* __restrict__ offsets, const int batch, const int bound /* 1..255 */,
+                       int32_t* __restrict__ sample_order) {
+  __shared__ unsigned total[256];                 // keys of the whole batch
+  __shared__ unsigned before[256];                // ... of the samples before this workgroup's
+  __shared__ unsigned wave_count[kBagOrderWaves][256];
+  __shared__ unsigned scan_carry[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int first = static_cast<int>(blockIdx.x) * kBagOrderThreads;
+  if (tid < 256) total[tid] = 0u;
+  for (int i = tid; i < kBagOrderWaves * 256; i += kBagOrderThreads) (&wave_count[0][0])[i] = 0u;
+  __syncthreads();
+  // One LDS atomic per group of equal keys in a wavefront (all bags alike would otherwise be 1,024 atomics on one word).
+  auto count_range = [&](const int lo, const int hi) {
+    for (int base = lo; base < hi; base += kBagOrderThreads) {
+      const int s = base + tid;
+      const bool valid = s < hi;
+      const unsigned key = valid ? BagKey(offsets, s, bound) : 0u;
+      const unsigned long long peers = MatchDigit(key, valid);
+      if (valid && CountBelow(peers) == 0u) atomicAdd(&total[key], static_cast<unsigned>(__popcll(peers)));
+    }
+  };
+  count_range(0, first < batch ? first : batch);
+  __syncthreads();
+  if (tid < 256) before[tid] = total[tid];
+  __syncthreads();
+  count_range(first, batch);
+  __syncthreads();
+  // base of key k = samples with a smaller key (whole batch) + samples with key k before this workgroup
+  unsigned mine = 0u, incl = 0u;
+  if (tid < 256) {
+    mine = total[tid];
+    incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) scan_carry[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    unsigned carry = 0u;
+    for (int w = 0; w < wave; ++w) carry += scan_carry[w];
+    total[tid] = carry + incl - mine + before[tid];          // (total now holds the bases)
+  }
+  // rank of my sample among the workgroup's samples with the same key: lanes below me in my wavefront + earlier wavefronts
+  const int s = first + tid;
+  const bool valid = s < batch;
+  const unsigned key = valid ? BagKey(offsets, s, bound) : 0u;
+  const unsigned long long peers = MatchDigit(key, valid);
+  const unsigned below = CountBelow(peers);
+  if (valid && below == 0u) wave_count[wave][key] = static_cast<unsigned>(__popcll(peers));
+  __syncthreads();
+  if (!valid) return;
+  unsigned pos = total[key] + below;
+  for (int w = 0; w < wave; ++w) pos += wave_count[w][key];
+  sample_order[pos] = s;
+}
+
+}  // namespace detail
+}  // namespace cuembed
+
+#endif  // CUEMBED_INCLUDE_HINT_KERNELS_HPP_

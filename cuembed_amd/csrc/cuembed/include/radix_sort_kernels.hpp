@@ -85,10 +85,10 @@ enum SortBuffer : int { kBufIn = 0, kBufOut = 1, kBufTmp0 = 2, kBufTmp1 = 3 };
 enum NarrowKeys : int { kNarrowNever = 0, kNarrowAlways = 1, kNarrowIfConstantHigh = 2 };
 enum : int { kStateVarying = 0, kStateAllBits = 1, kStatePayloadBits = 2, kStateWords = 3 };
 
-//! Arrival counters of the grid barrier: a top counter and one per group of workgroups (blockIdx % groups), 256 bytes
-//! apart (an arrival costs ~10 ns on ONE address, tools/ticket_probe.hip; eight groups arrive side by side).  They
-//! sit behind the three state words and are zeroed by whoever writes those.
-constexpr int kBarrierGroups = 8;
+//! Counters of the high-word kernels' ticket queue (SortWorkQueue): the next ticket and the number of finished items,
+//! 256 bytes apart (an atomic costs ~10 ns on ONE address, tools/ticket_probe.hip).  They sit behind the three state
+//! words and are zeroed by whoever writes those.
+constexpr int kBarrierGroups = 1;
 constexpr int kBarrierStride = 64;     // in counters (unsigned)
 constexpr int kBarrierWords = (kBarrierGroups + 1) * kBarrierStride / 2;   // in state words (unsigned long long)
 __device__ __forceinline__ unsigned* SortBarrierCounters(unsigned long long* state) {
@@ -836,36 +836,72 @@ inline int ChainedSortTiles(const size_t n) {
 // The HIGH WORD of 64-bit keys in one launch.  Lookup indices are below 2^31 (the API's row counts are `int`), so
 // passes 4..7 of an int64 sort through the reference signature (all 64 bits: index_transforms.cuh:108-136) are
 // skipped on the device practically always -- but the host cannot know, and twelve launches that return at once cost
-// ~45 us (C4, int64: 0.187 ms against 0.129 with a key bound).  This kernel is ALL of them: one workgroup per four
-// compute units (resident together: HighWordWorkgroups below), which returns at once when no high digit varies and otherwise runs the
-// working passes itself -- histogram, scan and scatter of every tile in turn, separated by a grid-wide barrier
-// (arrival counters + agent-scope release / acquire, docs: cdna_hip_programming.md G16).  The same result, but SLOW
-// when it has work (a generic COO transpose whose keys go beyond 2^32; tools/persistent_sort_probe.hip, 4.2 M keys
-// using all 64 bits: 0.529 ms with one workgroup per compute unit, 1.07 ms with the quarter grid, against 0.285 as
-// 24 launches): a barrier with its fences costs 5 us at 256 workgroups
-// and 12 us at 768 -- more than the launch boundary it replaces (every workgroup's release walks its XCD's L2) -- and
-// a phase at one workgroup per compute unit runs at a third of the launched kernels' rate.  That measurement is also
-// why the WHOLE sort is not one persistent launch.  CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 brings the launches back.
+// ~45 us (C4, int64: 0.187 ms against 0.129 with a key bound).  This kernel is ALL of them: one workgroup per
+// compute unit, which returns at once when no high digit varies and otherwise runs the working passes itself --
+// histogram, scan and scatter of every tile, handed out in execution order from a ticket queue (SortWorkQueue below:
+// agent-scope release / acquire, NO grid barrier and no assumption about which workgroups are resident).  The same
+// result, but SLOW when it has work (a generic COO transpose whose keys go beyond 2^32; round 5 measured the grid-barrier
+// form of this kernel, tools/persistent_sort_probe.hip, 4.2 M keys using all 64 bits: 0.529 ms with one workgroup per
+// compute unit against 0.285 as 24 launches: every phase boundary costs a release that walks the XCD's L2, and a phase
+// at one workgroup per compute unit runs at a third of the launched kernels' rate).  That measurement is also why the
+// WHOLE sort is not one persistent launch.  CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 brings the launches back.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void SortGridBarrier(unsigned* counters, unsigned* epoch) {
-  __syncthreads();                                   // every thread's stores of the phase are issued
-  *epoch += 1u;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // write this XCD's dirty lines back
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned grid = gridDim.x;
-    const unsigned groups = grid < static_cast<unsigned>(kBarrierGroups) ? grid : static_cast<unsigned>(kBarrierGroups);
-    const unsigned g = blockIdx.x % groups;
-    const unsigned members = (grid - g + groups - 1) / groups;    // workgroups with blockIdx % groups == g
-    const unsigned before =
-        __hip_atomic_fetch_add(counters + (1 + g) * kBarrierStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (before + 1u == members * *epoch)                          // the group's last arrival tells the top counter
-      __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * *epoch)
-      __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // drop what other XCDs have rewritten
+// Phases inside the launch are ordered WITHOUT a grid barrier and without assuming that the workgroups are resident
+// together (an ordinary launch guarantees nothing of the kind: under RCCL's persistent kernels, other streams or other
+// processes some of them may not get a slot for as long as the others spin -- a barrier would then hang).  The work is a
+// single ordered list of items -- (pass, phase, tile) in execution order -- and a workgroup CLAIMS the next item with a
+// ticket (one atomic), waits until every item of the earlier phases is done (a counter of finished items) and runs it.
+// Whoever holds a ticket is running, and waits only for lower tickets, which by induction are held by running
+// workgroups or finished: the launch completes with ANY number of resident workgroups, one included.  Workgroups that
+// get their slot late find the tickets gone and leave.  (tests: a grid many times what the device can hold, and sorts
+// racing CU-filling kernels on other streams.)
+struct SortWorkQueue {
+  unsigned* ticket;   //!< next item to hand out
+  unsigned* done;     //!< items finished (their stores released at agent scope)
+  unsigned* slot;     //!< one LDS word: the claimed ticket, for the whole workgroup
+  __device__ __forceinline__ unsigned Claim() const {
+    __syncthreads();                                 // (the previous item is through with LDS, `slot` included)
+    if (threadIdx.x == 0) *slot = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return *slot;
   }
-  __syncthreads();
+  __device__ __forceinline__ void WaitFor(const unsigned finished_items) const {
+    if (threadIdx.x == 0) {
+      while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < finished_items)
+        __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // drop what other XCDs have rewritten
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void Finish() const {
+    __syncthreads();                                 // every thread's stores of the item are issued
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // write this XCD's dirty lines back
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+};
+
+//! The working passes among [first_pass, passes): at most four (the high word of a 64-bit key).
+struct ActivePasses {
+  int pass[4];
+  int count;
+};
+__device__ __forceinline__ ActivePasses FindActivePasses(const unsigned long long* state, const int first_pass,
+                                                         const int passes, const SortMode mode) {
+  ActivePasses a;
+  a.count = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a.pass[k] = 0;
+  for (int p = first_pass; p < passes && a.count < 4; ++p)
+    if (PlanPass(state, p, passes, mode).active) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k == a.count) a.pass[k] = p;
+      ++a.count;
+    }
+  return a;
 }
 
 template <typename KeyT, typename V1, typename V2>
@@ -874,32 +910,58 @@ RadixHighPassesKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const 
                       const int first_pass, const int passes, const SortMode mode, unsigned* tile_hist,
                       unsigned* bin_total, const int num_tiles, unsigned long long* state, const int segment_tiles,
                       const int segments, const int xcds) {
-  bool any = false;
-  for (int p = first_pass; p < passes; ++p) any = any || PlanPass(state, p, passes, mode).active;
-  if (!any) return;                                  // (the same three words for every workgroup)
+  __shared__ unsigned claimed;
+  const ActivePasses act = FindActivePasses(state, first_pass, passes, mode);
+  if (act.count == 0) return;                        // (the same three words for every workgroup)
   unsigned* counter = SortBarrierCounters(state);
-  unsigned epoch = 0;
-  const int grid = static_cast<int>(gridDim.x);
-  const int scan_blocks = kSortBins * segments;
-  for (int p = first_pass; p < passes; ++p) {
-    if (!PlanPass(state, p, passes, mode).active) continue;
-    for (int b = static_cast<int>(blockIdx.x); b < num_tiles; b += grid) {
-      RadixTileHistogramBody<KeyT, kSortItems, false>(keys, n, p, passes, mode, tile_hist, num_tiles, nullptr, state,
-                                                      nullptr, xcds, b);
-      __syncthreads();
+  const SortWorkQueue queue{counter, counter + kBarrierStride, &claimed};
+  const unsigned scan_blocks = static_cast<unsigned>(kSortBins * segments);
+  const unsigned tiles = static_cast<unsigned>(num_tiles);
+  // A ticket is a CHUNK of consecutive tiles (as many as give every workgroup of the grid one ticket per phase): the
+  // release behind an item walks the XCD's L2, and one per tile made the kernel twice as slow as one per chunk.
+  const unsigned tile_chunk = (tiles + gridDim.x - 1) / gridDim.x;
+  const unsigned tile_tickets = (tiles + tile_chunk - 1) / tile_chunk;
+  const unsigned scan_chunk = (scan_blocks + gridDim.x - 1) / gridDim.x;
+  const unsigned scan_tickets = (scan_blocks + scan_chunk - 1) / scan_chunk;
+  const unsigned per_pass = 2u * tile_tickets + scan_tickets;    // histogram of every tile, scan, scatter of every tile
+  const unsigned total = per_pass * static_cast<unsigned>(act.count);
+  for (;;) {
+    const unsigned t = queue.Claim();
+    if (t >= total) return;
+    const unsigned a = t / per_pass, r = t - a * per_pass;
+    int p = act.pass[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (static_cast<unsigned>(k) == a) p = act.pass[k];
+    if (r < tile_tickets) {
+      queue.WaitFor(a * per_pass);                               // the previous pass has scattered everything
+      const unsigned end = (r + 1u) * tile_chunk < tiles ? (r + 1u) * tile_chunk : tiles;
+      for (unsigned b = r * tile_chunk; b < end; ++b) {
+        RadixTileHistogramBody<KeyT, kSortItems, false>(keys, n, p, passes, mode, tile_hist, num_tiles, nullptr, state,
+                                                        nullptr, xcds, static_cast<int>(b));
+        __syncthreads();
+      }
+    } else if (r < tile_tickets + scan_tickets) {
+      queue.WaitFor(a * per_pass + tile_tickets);                // every tile is counted
+      const unsigned q = r - tile_tickets;
+      const unsigned end = (q + 1u) * scan_chunk < scan_blocks ? (q + 1u) * scan_chunk : scan_blocks;
+      for (unsigned b = q * scan_chunk; b < end; ++b) {
+        RadixScanTilesBody(tile_hist, num_tiles, bin_total, p, passes, mode, nullptr, state, segment_tiles,
+                           static_cast<int>(b), static_cast<int>(scan_blocks));
+        __syncthreads();
+      }
+    } else {
+      queue.WaitFor(a * per_pass + tile_tickets + scan_tickets); // every bin is scanned
+      const unsigned q = r - tile_tickets - scan_tickets;
+      const unsigned end = (q + 1u) * tile_chunk < tiles ? (q + 1u) * tile_chunk : tiles;
+      for (unsigned b = q * tile_chunk; b < end; ++b) {
+        RadixScatterBody<KeyT, V1, V2, kSortItems, false>(keys, v1, v2, n, p, passes, mode, tile_hist, bin_total, num_tiles,
+                                                          state, segment_tiles, xcds, nullptr, nullptr, nullptr,
+                                                          static_cast<int>(b));
+        __syncthreads();
+      }
     }
-    SortGridBarrier(counter, &epoch);
-    for (int b = static_cast<int>(blockIdx.x); b < scan_blocks; b += grid) {
-      RadixScanTilesBody(tile_hist, num_tiles, bin_total, p, passes, mode, nullptr, state, segment_tiles, b, scan_blocks);
-      __syncthreads();
-    }
-    SortGridBarrier(counter, &epoch);
-    for (int b = static_cast<int>(blockIdx.x); b < num_tiles; b += grid) {
-      RadixScatterBody<KeyT, V1, V2, kSortItems, false>(keys, v1, v2, n, p, passes, mode, tile_hist, bin_total, num_tiles,
-                                                        state, segment_tiles, xcds, nullptr, nullptr, nullptr, b);
-      __syncthreads();
-    }
-    SortGridBarrier(counter, &epoch);
+    queue.Finish();
   }
 }
 
@@ -909,31 +971,52 @@ __global__ void __launch_bounds__(kSortThreads)
 RadixHighPassesChainedKernel(const SortArray<KeyT> keys, const SortArray<V1> v1, const SortArray<V2> v2, const int64_t n,
                              const int first_pass, const int passes, const SortMode mode, unsigned* tile_hist,
                              const int num_tiles, unsigned long long* state, const int xcds) {
-  bool any = false;
-  for (int p = first_pass; p < passes; ++p) any = any || PlanPass(state, p, passes, mode).active;
-  if (!any) return;
+  __shared__ unsigned claimed;
+  const ActivePasses act = FindActivePasses(state, first_pass, passes, mode);
+  if (act.count == 0) return;
   unsigned* counter = SortBarrierCounters(state);
-  unsigned epoch = 0;
-  const int grid = static_cast<int>(gridDim.x);
-  for (int p = first_pass; p < passes; ++p) {
-    if (!PlanPass(state, p, passes, mode).active) continue;
-    for (int b = static_cast<int>(blockIdx.x); b < num_tiles; b += grid) {
+  const SortWorkQueue queue{counter, counter + kBarrierStride, &claimed};
+  const unsigned tiles = static_cast<unsigned>(num_tiles);
+  const unsigned chunk = (tiles + gridDim.x - 1) / gridDim.x;     // tiles per ticket (see RadixHighPassesKernel)
+  const unsigned tickets = (tiles + chunk - 1) / chunk;
+  const unsigned total = tickets * static_cast<unsigned>(act.count);
+  for (;;) {
+    const unsigned t = queue.Claim();
+    if (t >= total) return;
+    const unsigned a = t / tickets, r = t - a * tickets;
+    int p = act.pass[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (static_cast<unsigned>(k) == a) p = act.pass[k];
+    queue.WaitFor(a * tickets);          // the pass adds up the counts the previous one left with atomics
+    const unsigned end = (r + 1u) * chunk < tiles ? (r + 1u) * chunk : tiles;
+    for (unsigned b = r * chunk; b < end; ++b) {
       RadixScatterBody<KeyT, V1, V2, kChainedSortItems, true>(keys, v1, v2, n, p, passes, mode, tile_hist, nullptr, num_tiles,
-                                                              state, num_tiles, xcds, tile_hist, nullptr, nullptr, b);
+                                                              state, num_tiles, xcds, tile_hist, nullptr, nullptr,
+                                                              static_cast<int>(b));
       __syncthreads();
     }
-    SortGridBarrier(counter, &epoch);   // the next pass adds up the counts this one left with atomics
+    queue.Finish();
   }
 }
 
-//! Grid of the high-word kernels: a QUARTER of the compute units.  Their workgroups wait for each other at the grid
-//! barriers, so all of them have to be resident together -- alone they always are, and with 3 such workgroups fitting
-//! a compute unit (160 VGPRs, 43 KB LDS) it would take MORE THAN TWELVE of these kernels executing at the same time,
-//! each with keys beyond 2^32, to leave one of them waiting for slots the others hold (a process has 4 hardware queues
-//! by default, GPU_MAX_HW_QUEUES).  Kernels that find no work (every lookup index) return at once and wait for nobody.
+//! Grid of the high-word kernels: one workgroup per compute unit (a grid for throughput -- the kernels are correct with
+//! any number of resident workgroups, see SortWorkQueue).  Kernels that find no work (every lookup index) return at once.
+//! CUEMBED_SORT_HIGH_WORD_WORKGROUPS (read once) overrides it: tests run grids far beyond what the device holds.
 inline int HighWordWorkgroups() {
-  const int units = CurrentDeviceShape().compute_units / 4;
+  static const int forced = [] {
+    const char* e = std::getenv("CUEMBED_SORT_HIGH_WORD_WORKGROUPS");
+    return e != nullptr ? std::atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  const int units = CurrentDeviceShape().compute_units;
   return units < 1 ? 1 : units;
+}
+
+//! (no more workgroups than tiles -- unless a test forces the grid)
+inline int HighWordGrid(const int tiles, const int units) {
+  static const bool forced = std::getenv("CUEMBED_SORT_HIGH_WORD_WORKGROUPS") != nullptr;
+  return (forced || tiles > units) ? units : tiles;
 }
 
 //! CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 (read once): the passes over the high word of 64-bit keys as launches of their own
@@ -1073,7 +1156,7 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
     if constexpr (sizeof(KeyT) == 8) {
       if (launched_passes < plan.passes) {
         const int units = HighWordWorkgroups();
-        RadixHighPassesChainedKernel<KeyT, V1, V2><<<tiles < units ? tiles : units, kSortThreads, 0, stream>>>(
+        RadixHighPassesChainedKernel<KeyT, V1, V2><<<HighWordGrid(tiles, units), kSortThreads, 0, stream>>>(
             keys, v1, v2, count, launched_passes, plan.passes, mode, tile_hist, tiles, state, xcds);
       }
     }
@@ -1100,7 +1183,7 @@ inline void RadixSortPairs(const KeyT* keys_in, KeyT* keys_out, const V1* v1_in,
   if constexpr (sizeof(KeyT) == 8) {
     if (tiled_passes < plan.passes) {
       const int units = HighWordWorkgroups();
-      RadixHighPassesKernel<KeyT, V1, V2><<<plan.num_tiles < units ? plan.num_tiles : units, kSortThreads, 0, stream>>>(
+      RadixHighPassesKernel<KeyT, V1, V2><<<HighWordGrid(plan.num_tiles, units), kSortThreads, 0, stream>>>(
           keys, v1, v2, count, tiled_passes, plan.passes, mode, tile_hist, bin_total, plan.num_tiles, state, segment_tiles,
           segments, xcds);
     }

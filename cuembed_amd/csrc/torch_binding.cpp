@@ -84,7 +84,7 @@ int IndexBits(const int64_t num_categories) {
 // (a permutation of the samples; undefined = none): scheduling hints, never a different result.
 at::Tensor ForwardImpl(const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
                        const at::Tensor& weights, const std::string& mode, const int row_loads,
-                       const at::Tensor& sample_order) {
+                       const at::Tensor& sample_order, const at::Tensor& row_loads_device = at::Tensor()) {
   CheckGpu(params, "params");
   CheckGpu(indices, "indices");
   CheckGpu(offsets, "offsets");
@@ -108,10 +108,15 @@ at::Tensor ForwardImpl(const at::Tensor& params, const at::Tensor& indices, cons
     TORCH_CHECK(sample_order.is_cuda() && sample_order.scalar_type() == at::kInt && sample_order.numel() == batch &&
                     sample_order.is_contiguous(),
                 "cuembed_pyt: sample_order must be a contiguous int32 permutation of the samples on the GPU");
+  if (row_loads_device.defined())      // the words cuembed_decide_row_loads works on: the kernels read the decision themselves
+    TORCH_CHECK(row_loads_device.is_cuda() && row_loads_device.scalar_type() == at::kInt && row_loads_device.numel() >= 4 &&
+                    row_loads_device.is_contiguous(),
+                "cuembed_pyt: row_loads_device must be the contiguous 4-word int32 tensor of cuembed_decide_row_loads");
   if (batch > 0)
-    ::cuembed_embedding_forward_ordered(Ptr(p), elem, static_cast<int>(p.size(1)), Ptr(i), idx, Ptr(o), off, Ptr(w),
-                                        static_cast<int>(batch), 0, m, 0, MutPtr(out), /*reduction_order=*/-1, row_loads,
-                                        static_cast<const int32_t*>(Ptr(sample_order)), CurrentStream(p));
+    ::cuembed_embedding_forward_device_hints(Ptr(p), elem, static_cast<int>(p.size(1)), Ptr(i), idx, Ptr(o), off, Ptr(w),
+                                             static_cast<int>(batch), 0, m, 0, MutPtr(out), /*reduction_order=*/-1, row_loads,
+                                             static_cast<const int32_t*>(Ptr(sample_order)),
+                                             static_cast<const uint32_t*>(Ptr(row_loads_device)), CurrentStream(p));
   return out;
 }
 
@@ -125,9 +130,25 @@ at::Tensor cuembed_embedding_forward_op(const at::Tensor& params, const at::Tens
 at::Tensor cuembed_embedding_forward_hinted_op(const at::Tensor& params, const at::Tensor& indices,
                                             const at::Tensor& offsets, const c10::optional<at::Tensor>& weights,
                                             const std::string& mode, const int64_t row_loads,
-                                            const c10::optional<at::Tensor>& sample_order) {
+                                            const c10::optional<at::Tensor>& sample_order,
+                                            const c10::optional<at::Tensor>& row_loads_device) {
   return ForwardImpl(params, indices, offsets, weights.has_value() ? *weights : at::Tensor(), mode,
-                     static_cast<int>(row_loads), sample_order.has_value() ? *sample_order : at::Tensor());
+                     static_cast<int>(row_loads), sample_order.has_value() ? *sample_order : at::Tensor(),
+                     row_loads_device.has_value() ? *row_loads_device : at::Tensor());
+}
+
+// Extension (cuembed::DecideRowLoads): the row-load policy decided on the device from the batch's indices; `decision` is
+// four int32 words zeroed once by the caller, handed to the forward as row_loads_device.  One launch, no read-back.
+void cuembed_decide_row_loads_op(const at::Tensor& indices, const int64_t table_bytes, at::Tensor decision) {
+  CheckGpu(indices, "indices");
+  CheckGpu(decision, "decision");
+  const int idx = IndexCode(indices, "indices");
+  TORCH_CHECK(decision.scalar_type() == at::kInt && decision.numel() >= 4 && decision.is_contiguous(),
+              "cuembed_pyt: decision must be a contiguous int32 tensor of 4 words");
+  const at::DeviceGuard guard(indices.device());
+  const at::Tensor i = indices.contiguous();
+  ::cuembed_decide_row_loads(Ptr(i), idx, i.numel(), table_bytes, static_cast<uint32_t*>(decision.data_ptr()), 0u,
+                             CurrentStream(i));
 }
 
 // Extension (cuembed::BagOrderByLength): the samples of a CSR batch by descending bag length, for sample_order.
@@ -514,7 +535,8 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
   static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& params, const at::Tensor& indices,
                             const at::Tensor& offsets, const c10::optional<at::Tensor>& optional_weights,
                             const int64_t grad_kind, const int64_t row_loads,
-                            const c10::optional<at::Tensor>& optional_sample_order) {
+                            const c10::optional<at::Tensor>& optional_sample_order,
+                            const c10::optional<at::Tensor>& optional_row_loads_device) {
     at::AutoDispatchBelowADInplaceOrView below;
     const at::Tensor weights = optional_weights.has_value() ? *optional_weights : at::Tensor();
     const at::Tensor sample_order = optional_sample_order.has_value() ? *optional_sample_order : at::Tensor();
@@ -523,7 +545,8 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     ctx->saved_data["weighted"] = weights.defined();
     if (weights.defined()) ctx->save_for_backward({indices, offsets, weights});
     else ctx->save_for_backward({indices, offsets});
-    return ForwardImpl(params, indices, offsets, weights, "sum", static_cast<int>(row_loads), sample_order);
+    return ForwardImpl(params, indices, offsets, weights, "sum", static_cast<int>(row_loads), sample_order,
+                       optional_row_loads_device.has_value() ? *optional_row_loads_device : at::Tensor());
   }
 
   static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
@@ -534,7 +557,7 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
     const int64_t num_categories = ctx->saved_data["num_categories"].toInt();
     const int64_t grad_kind = ctx->saved_data["grad_kind"].toInt();
     at::Tensor out_grad = grad_outputs[0];
-    torch::autograd::variable_list grads(7);   // (params, indices, offsets, weights, grad_kind, row_loads, sample_order)
+    torch::autograd::variable_list grads(8);   // (params, indices, offsets, weights, grad_kind, row_loads, sample_order, row_loads_device)
     if (!ctx->needs_input_grad(0)) return grads;
     CheckGpu(out_grad, "the incoming gradient");
     const at::DeviceGuard guard(out_grad.device());
@@ -631,12 +654,13 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
 // grad_kind: see GradKind.
 at::Tensor cuemb_embedding_autograd_op(const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
                                     const at::Tensor& weights, const int64_t grad_kind, const int64_t row_loads,
-                                    const at::Tensor& sample_order) {
+                                    const at::Tensor& sample_order, const at::Tensor& row_loads_device) {
   TORCH_CHECK(grad_kind >= kGradDense && grad_kind <= kGradSparsePadded, "cuembed_pyt: unknown grad_kind");
   return CuEmbEmbeddingNode::apply(params, indices, offsets,
                                    weights.defined() ? c10::optional<at::Tensor>(weights) : c10::nullopt, grad_kind,
                                    row_loads,
-                                   sample_order.defined() ? c10::optional<at::Tensor>(sample_order) : c10::nullopt);
+                                   sample_order.defined() ? c10::optional<at::Tensor>(sample_order) : c10::nullopt,
+                                   row_loads_device.defined() ? c10::optional<at::Tensor>(row_loads_device) : c10::nullopt);
 }
 
 }  // namespace
@@ -670,19 +694,22 @@ TORCH_LIBRARY(cuembed_pyt, m) {
   // forward + backward of cuemb_embedding as one native autograd node (see CuEmbEmbeddingNode)
   m.def(
       "cuemb_embedding_step(Tensor params, Tensor indices, Tensor offsets, Tensor? weights, int grad_kind, int row_loads, "
-      "Tensor? sample_order) -> Tensor");
+      "Tensor? sample_order, Tensor? row_loads_device) -> Tensor");
   m.def(
       "cuembed_embedding_forward_hinted(Tensor params, Tensor indices, Tensor offsets, Tensor? weights, str mode, int "
-      "row_loads, Tensor? sample_order) -> Tensor");
+      "row_loads, Tensor? sample_order, Tensor? row_loads_device) -> Tensor");
+  m.def("cuembed_decide_row_loads(Tensor indices, int table_bytes, Tensor(a!) decision) -> ()");
   m.def("cuembed_bag_order_by_length(Tensor offsets, int max_length) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(cuembed_pyt, Autograd, m) {
   m.impl("cuemb_embedding_step", [](const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
                                     const c10::optional<at::Tensor>& weights, int64_t grad_kind, int64_t row_loads,
-                                    const c10::optional<at::Tensor>& sample_order) {
+                                    const c10::optional<at::Tensor>& sample_order,
+                                    const c10::optional<at::Tensor>& row_loads_device) {
     return cuemb_embedding_autograd_op(params, indices, offsets, weights.has_value() ? *weights : at::Tensor(), grad_kind,
-                                       row_loads, sample_order.has_value() ? *sample_order : at::Tensor());
+                                       row_loads, sample_order.has_value() ? *sample_order : at::Tensor(),
+                                       row_loads_device.has_value() ? *row_loads_device : at::Tensor());
   });
 }
 
@@ -702,4 +729,5 @@ TORCH_LIBRARY_IMPL(cuembed_pyt, CUDA, m) {  // HIP tensors use the CUDA dispatch
   m.impl("cuembed_embedding_weight_grad", cuembed_embedding_weight_grad_op);
   m.impl("cuembed_embedding_forward_hinted", cuembed_embedding_forward_hinted_op);
   m.impl("cuembed_bag_order_by_length", cuembed_bag_order_by_length_op);
+  m.impl("cuembed_decide_row_loads", cuembed_decide_row_loads_op);
 }

@@ -66,8 +66,10 @@ def _define_python_ops():
     _lib.define("cuembed_embedding_backward(Tensor y_grad, int num_categories, Tensor transpose_indices,"
                 " Tensor transpose_sample_ids, Tensor transpose_weights) -> Tensor")
     _lib.define("cuembed_embedding_forward_hinted(Tensor params, Tensor indices, Tensor offsets, Tensor? weights,"
-                " str mode, int row_loads, Tensor? sample_order) -> Tensor")
+                " str mode, int row_loads, Tensor? sample_order, Tensor? row_loads_device) -> Tensor")
     _lib.define("cuembed_bag_order_by_length(Tensor offsets, int max_length) -> Tensor")
+    _lib.define("cuembed_decide_row_loads(Tensor indices, int table_bytes, Tensor(a!) decision) -> ()")
+    _lib.impl("cuembed_decide_row_loads", _decide_row_loads_impl, "CUDA")
     _lib.impl("cuembed_embedding_forward_hinted", _forward_hinted_impl, "CUDA")
     _lib.impl("cuembed_bag_order_by_length", _bag_order_impl, "CUDA")
     _lib.impl("cuembed_extract_row_ids_from_offsets", _extract_closed_impl, "CUDA")
@@ -109,15 +111,19 @@ def _require(cond, msg):
         raise RuntimeError("cuembed_pyt: " + msg)
 
 
-def _forward_hinted_impl(params, indices, offsets, weights, mode, row_loads, sample_order):
-    return _forward_impl(params, indices, offsets, weights, mode, row_loads, sample_order)
+def _forward_hinted_impl(params, indices, offsets, weights, mode, row_loads, sample_order, row_loads_device=None):
+    return _forward_impl(params, indices, offsets, weights, mode, row_loads, sample_order, row_loads_device)
+
+
+def _decide_row_loads_impl(indices, table_bytes, decision):
+    _ops.decide_row_loads(indices, int(table_bytes), decision)
 
 
 def _bag_order_impl(offsets, max_length):
     return _ops.bag_order_by_length(offsets.contiguous(), max_length=int(max_length))
 
 
-def _forward_impl(params, indices, offsets, weights, mode, row_loads=-1, sample_order=None):
+def _forward_impl(params, indices, offsets, weights, mode, row_loads=-1, sample_order=None, row_loads_device=None):
     _require(params.is_cuda and indices.is_cuda and offsets.is_cuda, "tensors must be on the GPU")
     _require(params.dtype in _FLOATS, "params must be float32 or float16")
     _require(indices.dtype in _INTS and offsets.dtype in _INTS, "indices/offsets must be int64 or int32")
@@ -129,7 +135,7 @@ def _forward_impl(params, indices, offsets, weights, mode, row_loads=-1, sample_
     return _ops.embedding_forward(params.contiguous(), indices.contiguous(), offsets.contiguous(), weights,
                                   batch_size=batch_size, num_hots=0, mode=mode,
                                   row_loads={-1: None, 0: "default", 1: "streaming"}[int(row_loads)],
-                                  sample_order=sample_order)
+                                  sample_order=sample_order, row_loads_device=row_loads_device)
 
 
 def _extract_impl(offsets, nnz):
@@ -260,12 +266,14 @@ cuembed_embedding_backward = torch.ops.cuembed_pyt.cuembed_embedding_backward
 def cuembed_forward(params, idx, offsets, weights, hints=None):
     if hints is None:
         return cuembed_embedding_forward(params, idx, offsets, weights, mode="sum")
-    return torch.ops.cuembed_pyt.cuembed_embedding_forward_hinted(params, idx, offsets, weights, "sum", hints[0], hints[1])
+    return torch.ops.cuembed_pyt.cuembed_embedding_forward_hinted(params, idx, offsets, weights, "sum", hints[0], hints[1],
+                                                                  hints[2] if len(hints) > 2 else None)
 
 
 def _auto_hints(params, idx, offsets):
-    """(row_loads, sample_order) chosen by cuembed_amd.policy for this table and this batch; never changes a result."""
-    return _policy.row_loads(params, idx), _policy.sample_order(offsets, idx.numel())
+    """(row_loads, sample_order, row_loads_device) chosen by cuembed_amd.policy for this table and this batch -- both
+    decided on the device, no read-back; never changes a result."""
+    return -1, _policy.sample_order(offsets, idx.numel()), _policy.row_loads_device(params, idx)
 
 
 def _narrow_for_index_work(idx, offsets, num_categories):
@@ -427,16 +435,16 @@ def cuemb_embedding(params, idx, offsets, weights=None, sparse_grad=False, hints
     needs_grad = params.requires_grad or (weights is not None and weights.requires_grad)
     quiet = torch.compiler.is_compiling()
     chosen = _auto_hints(params, idx, offsets) if (hints == "auto" and not quiet) else None
-    if chosen is not None and chosen[0] < 0 and chosen[1] is None:
+    if chosen is not None and chosen[0] < 0 and chosen[1] is None and chosen[2] is None:
         chosen = None
     if not torch.is_grad_enabled() or not needs_grad:
         return cuembed_forward(params, idx, offsets, weights, chosen)
     native = (BACKEND == "native" and not quiet and sparse_grad in _GRAD_KINDS and
               not (weights is not None and weights.requires_grad))
     if native:
-        row_loads, order = chosen if chosen is not None else (-1, None)
+        row_loads, order, decision = chosen if chosen is not None else (-1, None, None)
         return torch.ops.cuembed_pyt.cuemb_embedding_step(params, idx, offsets, weights, _GRAD_KINDS[sparse_grad],
-                                                          row_loads, order)
+                                                          row_loads, order, decision)
     return _CuEmbEmbedding.apply(params, idx, offsets, weights, sparse_grad, chosen)
 
 
@@ -556,8 +564,13 @@ def _(params, idx, offsets, weights=None, mode="sum"):
     return torch.empty((offsets.shape[0] - 1, params.shape[1]), device=params.device, dtype=params.dtype)
 
 
+@torch.library.register_fake("cuembed_pyt::cuembed_decide_row_loads")
+def _(indices, table_bytes, decision):
+    return None
+
+
 @torch.library.register_fake("cuembed_pyt::cuembed_embedding_forward_hinted")
-def _(params, idx, offsets, weights=None, mode="sum", row_loads=-1, sample_order=None):
+def _(params, idx, offsets, weights=None, mode="sum", row_loads=-1, sample_order=None, row_loads_device=None):
     return torch.empty((offsets.shape[0] - 1, params.shape[1]), device=params.device, dtype=params.dtype)
 
 

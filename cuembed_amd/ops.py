@@ -123,7 +123,8 @@ def backward_launch_shape(elem_dtype, index_dtype, embed_width, nnz, is_weighted
 
 
 def embedding_forward(params, indices, offsets=None, weights=None, batch_size=None, num_hots=0,
-                      mode="sum", fp16_math=False, out=None, reduction_order=None, row_loads=None, sample_order=None):
+                      mode="sum", fp16_math=False, out=None, reduction_order=None, row_loads=None, sample_order=None,
+                      row_loads_device=None):
     """out[s] = combine_j weights[s,j] * params[indices[s,j]].
 
     Fixed hotness: offsets=None, num_hots>0 (indices holds batch_size*num_hots ids).
@@ -132,7 +133,9 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
     Per-call options (extension; None = the process-wide default): reduction_order "sequential" | "split"
     (set_forward_reduction_order), row_loads "default" | "streaming" (set_forward_row_load_policy);
     sample_order (CSR only): an int32 permutation of range(batch_size) on the device, the order in which the samples
-    are handed to the wavefronts -- a scheduling hint that never changes a result (bag_order_by_length())."""
+    are handed to the wavefronts -- a scheduling hint that never changes a result (bag_order_by_length());
+    row_loads_device: the 4-word int32 device tensor decide_row_loads() filled -- the kernels read the decision from it
+    instead of row_loads (the host never sees it)."""
     if mode not in _MODES:
         raise ValueError("mode must be 'sum', 'mean' or 'concat'")
     if reduction_order not in _ORDERS or row_loads not in _ROW_LOADS:
@@ -183,6 +186,10 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
             raise ValueError("sample_order is a hint for CSR batches (bags of different lengths)")
         if sample_order.dtype != torch.int32 or sample_order.numel() != batch_size or not sample_order.is_contiguous():
             raise ValueError("sample_order must be a contiguous int32 permutation of range(batch_size)")
+    if row_loads_device is not None:
+        _check_dev("row_loads_device", row_loads_device, dev)
+        if row_loads_device.dtype != torch.int32 or row_loads_device.numel() < 4 or not row_loads_device.is_contiguous():
+            raise ValueError("row_loads_device must be the contiguous 4-word int32 tensor decide_row_loads() fills")
     shape = (batch_size, num_hots, width) if m == CONCAT else (batch_size, width)
     if out is None:
         out = torch.empty(shape, dtype=params.dtype, device=dev)
@@ -192,29 +199,54 @@ def embedding_forward(params, indices, offsets=None, weights=None, batch_size=No
             raise ValueError("out has the wrong dtype or size")
     if batch_size > 0:
         with torch.cuda.device(params.device):   # the launch must happen on the tensors' device
-            _lib.lib().cuembed_embedding_forward_ordered(
+            _lib.lib().cuembed_embedding_forward_device_hints(
                 _ptr(params), et, width, _ptr(indices), it, _ptr(offsets), ot, _ptr(weights),
                 batch_size, num_hots, m, int(bool(fp16_math)), _ptr(out), _ORDERS[reduction_order],
-                _ROW_LOADS[row_loads], _ptr(sample_order), _stream(params))
+                _ROW_LOADS[row_loads], _ptr(sample_order), _ptr(row_loads_device), _stream(params))
     return out
+
+
+def decide_row_loads(indices, table_bytes, decision=None, distinct_fraction=None):
+    """The row-load policy of embedding_forward decided ON THE DEVICE from the batch's own indices
+    (cuembed::DecideRowLoads): one launch, no read-back, capturable.  Returns `decision`, a 4-word int32 device tensor
+    (word 0: 1 = non-temporal row loads, 0 = ordinary; allocate it once with new_row_loads_decision() and re-use it) to
+    pass as embedding_forward(..., row_loads_device=).  Streaming is chosen when at least `distinct_fraction` (default
+    0.95) of an evenly strided sample of up to 65,536 lookups names distinct rows, the table has >= 1 GiB and the batch
+    >= 2^18 lookups.  Never changes a result."""
+    _check_dev("indices", indices)
+    it = _index_code("indices", indices)
+    if decision is None:
+        decision = new_row_loads_decision(indices.device)
+    _check_dev("decision", decision, indices.device)
+    if decision.dtype != torch.int32 or decision.numel() < 4 or not decision.is_contiguous():
+        raise ValueError("decision must be a contiguous int32 tensor of 4 words (new_row_loads_decision())")
+    th = 0 if distinct_fraction is None else max(1, min(1024, int(round(float(distinct_fraction) * 1024))))
+    with torch.cuda.device(indices.device):
+        _lib.lib().cuembed_decide_row_loads(_ptr(indices.contiguous()), it, indices.numel(), int(table_bytes),
+                                            _ptr(decision), th, _stream(indices))
+    return decision
+
+
+def new_row_loads_decision(device="cuda"):
+    """The four zeroed device words decide_row_loads() works on (word 0 is the decision: "default" until decided)."""
+    return torch.zeros((4,), dtype=torch.int32, device=device)
 
 
 def bag_order_by_length(offsets, batch_size=None, max_length=None, workspace=None):
     """int32 permutation of range(batch_size): the samples of a CSR batch by DESCENDING bag length (ties in input
     order) -- what embedding_forward(..., sample_order=) wants for ragged bags: the two bags of a wavefront are alike,
-    neighbouring wavefronts are alike, and the longest bags start first (cuembed::BagOrderByLength: a key kernel +
-    the library's own stable sort).  max_length, when the caller knows a bound on the bag length, keeps the sort to
-    the key bits that exist (one radix pass for bags of up to 255 lookups; longer bags rank as max_length).  It
-    only depends on the offsets: prepare it once per batch where they are made."""
+    neighbouring wavefronts are alike, and the longest bags start first (cuembed::BagOrderByLength).  max_length, when
+    the caller knows a bound on the bag length (longer bags rank as max_length), keeps the sort short: with a bound
+    of at most 255 -- or max_length=-1, "bags of 255 lookups and more rank alike" -- and up to 131,072 samples it is
+    ONE launch (a stable counting sort, ~5 us for 65,536 bags); None = unknown: a key kernel + the library's stable
+    sort.  It only depends on the offsets."""
     _check_dev("offsets", offsets)
     ot = _index_code("offsets", offsets)
     if batch_size is None:
         batch_size = offsets.numel() - 1
     if batch_size < 0 or offsets.numel() < batch_size + 1:
         raise ValueError("offsets must hold batch_size + 1 entries")
-    bound = 0 if max_length is None else int(max_length)
-    if bound < 0:
-        raise ValueError("max_length must be positive (or None)")
+    bound = 0 if max_length is None else int(max_length)     # (< 0: bags of 255 lookups and more rank alike)
     order = torch.empty((batch_size,), dtype=torch.int32, device=offsets.device)
     need = ctypes.c_size_t(0)
     _lib.lib().cuembed_bag_order_by_length(None, ot, batch_size, bound, None, None, ctypes.byref(need), None)

@@ -2,48 +2,44 @@
 
 The library's fast paths are options that never change a result (include/cuembed_amd.h: RowLoadPolicy,
 ForwardOptions::sample_order); a caller of the reference's Python surface (examples/pytorch/cuembed_pyt.py:48-51) should
-not have to know them.  Two hints are chosen here, per table and per offsets tensor:
+not have to know them.  Two hints are chosen here, and since round 6 BOTH ARE DECIDED ON THE DEVICE: no `torch.unique`,
+no read-back, nothing that a HIP graph capture or a stream-ordered pipeline would have to stop for (C++ / C-ABI callers
+have the same two calls: cuembed_decide_row_loads, cuembed_bag_order_by_length).
 
   row_loads     "streaming" (non-temporal table-row loads) pays when nearly every lookup of a batch hits a different row
                 of a table far larger than the caches (C2 shape, uniform indices: 0.380 -> 0.358 ms) and costs a lot
-                when rows are re-used (alpha = 1.15: 0.136 -> 0.222 ms).  Decided from the distinct fraction of a
-                sample of the batch's indices (one `unique` + one 4-byte read-back), on the first call for a table and
-                again every RECHECK_CALLS calls; conservative: streaming only when >= STREAMING_DISTINCT of the sample
-                is distinct, the table is >= STREAMING_MIN_TABLE_BYTES and the batch has >= STREAMING_MIN_LOOKUPS
-                lookups (smaller ones are latency-bound whatever the loads are, and the decision itself would cost
-                more host time than their launch).
+                when rows are re-used (alpha = 1.15: 0.136 -> 0.222 ms).  cuembed::DecideRowLoads counts the distinct
+                rows of an evenly strided sample of the batch exactly (one launch, ~5 us) and leaves the decision in
+                four device words that the forward kernels read (ForwardOptions::row_loads_device); run for the first
+                batch of a table and again every RECHECK_CALLS calls; in between the forward re-reads the last decision.
+                Conservative: streaming only when >= 95 % of the sample is distinct, the table is >= 1 GiB and the
+                batch has >= 2^18 lookups (the gates are the library's: kStreamingMinTableBytes / kStreamingMinLookups).
   sample_order  the samples of a ragged CSR batch by descending bag length (cuembed::BagOrderByLength; C3: 0.170 ->
-                0.148 ms).  It depends on the offsets alone and costs about what it saves, so it is computed once per
-                DISTINCT offsets tensor (same storage, same version counter, same length) and kept for the last few:
-                a pipeline that re-uses its offsets (fixed bag layout, evaluation over a cached batch) gains, one that
-                builds new offsets every step pays nothing -- the order is only prepared on the SECOND sight of a tensor.
+                0.148 ms).  With bag lengths clamped at 255 it is ONE launch of ~5 us (a stable counting sort), cheap
+                enough to be computed for EVERY batch from its own offsets -- no cache, nothing to go stale (round 5
+                kept an order per offsets tensor, keyed by address and version; a pipeline that builds fresh offsets
+                in a recycled allocation would have been handed another batch's order: still a valid permutation,
+                but not the one it paid for).
 
-Nothing here runs under torch.compile tracing or stream capture (both need a read-back-free path): the hints are then
-"no hint".  `set_enabled(False)` turns the whole module into "no hint" (the tests that pin kernels do).
+Nothing here runs under torch.compile tracing: the hints are then "no hint".  `set_enabled(False)` turns the whole
+module into "no hint" (the tests that pin kernels do).
 """
-import collections
-
 import torch
 
 RECHECK_CALLS = 256
-SAMPLE = 65536
-STREAMING_DISTINCT = 0.8
-STREAMING_MIN_TABLE_BYTES = 1 << 30
-STREAMING_MIN_LOOKUPS = 1 << 18
+STREAMING_MIN_TABLE_BYTES = 1 << 30          # = cuembed::kStreamingMinTableBytes (the kernel-side gate)
+STREAMING_MIN_LOOKUPS = 1 << 18              # = cuembed::kStreamingMinLookups
 ORDER_MIN_LOOKUPS = 1 << 20
 ORDER_MIN_BATCH = 1 << 14
-_ORDER_KEEP = 4
 
 _enabled = True
-_tables = {}                                  # (ptr, shape, dtype) -> [calls, streaming]
-_orders = collections.OrderedDict()           # (ptr, version, numel, dtype) -> [sightings, order tensor or None]
+_tables = {}                                  # (ptr, shape, dtype, device) -> [calls, decision words]
 
 
 def set_enabled(flag):
     global _enabled
     _enabled = bool(flag)
     _tables.clear()
-    _orders.clear()
 
 
 def enabled():
@@ -51,57 +47,40 @@ def enabled():
 
 
 def _quiet():
-    """True where a decision would need a read-back that the context forbids."""
-    if not _enabled:
-        return True
-    if torch.compiler.is_compiling():
-        return True
-    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    return not _enabled or torch.compiler.is_compiling()
 
 
-def distinct_fraction(indices):
-    """Distinct fraction of an evenly strided sample of up to SAMPLE indices (one device -> host read-back)."""
-    flat = indices.reshape(-1)
-    n = flat.numel()
-    if n == 0:
-        return 0.0
-    sample = flat[:: max(1, n // SAMPLE)][:SAMPLE]
-    return float(torch.unique(sample).numel()) / float(sample.numel())
-
-
-def row_loads(params, indices):
-    """-1 (no hint: the process-wide default) / 0 (default loads) / 1 (streaming) for embedding_forward."""
-    # (the cheap gates first: a small batch is latency-bound whatever the loads are, and at 7 us per launch the 3 us the
-    # capture query of _quiet() costs would be the largest part of this function's caller)
+def row_loads_device(params, indices):
+    """The table's row-load decision words (int32[4] on the device, word 0: 1 = streaming) for
+    embedding_forward(..., row_loads_device=), or None (no hint: the process-wide default).  Decided on the device from
+    `indices` on the first call for a table and every RECHECK_CALLS calls; never read back."""
+    # (the cheap gates first: a small batch is latency-bound whatever the loads are, and at 7 us per launch even a
+    # dictionary lookup shows)
     if indices.numel() < STREAMING_MIN_LOOKUPS or params.numel() * params.element_size() < STREAMING_MIN_TABLE_BYTES:
-        return -1
+        return None
     if _quiet():
-        return -1
-    key = (params.data_ptr(), tuple(params.shape), params.dtype)
+        return None
+    key = (params.data_ptr(), tuple(params.shape), params.dtype, params.device)
     state = _tables.get(key)
     if state is None:
         if len(_tables) > 64:
             _tables.clear()
-        state = _tables[key] = [0, False]
+        state = _tables[key] = [0, torch.zeros((4,), dtype=torch.int32, device=params.device)]
     if state[0] % RECHECK_CALLS == 0:
-        state[1] = distinct_fraction(indices) >= STREAMING_DISTINCT
+        torch.ops.cuembed_pyt.cuembed_decide_row_loads(indices, params.numel() * params.element_size(), state[1])
     state[0] += 1
-    return 1 if state[1] else 0
+    return state[1]
 
 
-def sample_order(offsets, nnz, max_length=0):
-    """The cached bag order of `offsets` for ForwardOptions::sample_order, or None (small batch, first sight, quiet)."""
+def row_loads_decision(params):
+    """(tests, diagnostics) the last decision for `params` read back: 1 streaming, 0 default, -1 none taken."""
+    state = _tables.get((params.data_ptr(), tuple(params.shape), params.dtype, params.device))
+    return -1 if state is None else int(state[1][0].item())
+
+
+def sample_order(offsets, nnz):
+    """The bag order of `offsets` for ForwardOptions::sample_order (lengths clamped at 255: one launch up to 131,072
+    samples, a one-pass sort above), or None (small batch, quiet)."""
     if offsets is None or nnz < ORDER_MIN_LOOKUPS or offsets.numel() - 1 < ORDER_MIN_BATCH or _quiet():
         return None
-    key = (offsets.data_ptr(), offsets._version, offsets.numel(), offsets.dtype)
-    entry = _orders.get(key)
-    if entry is None:
-        _orders[key] = [1, None]
-        while len(_orders) > _ORDER_KEEP:
-            _orders.popitem(last=False)
-        return None
-    _orders.move_to_end(key)
-    entry[0] += 1
-    if entry[1] is None:
-        entry[1] = torch.ops.cuembed_pyt.cuembed_bag_order_by_length(offsets, int(max_length))
-    return entry[1]
+    return torch.ops.cuembed_pyt.cuembed_bag_order_by_length(offsets, -1)

@@ -395,10 +395,29 @@ void cuembed_embedding_forward_ordered(const void* params, int elem_type, int em
                                        int num_hots, int mode, int fp16_math, void* ret,
                                        int reduction_order, int row_load_policy,
                                        const int32_t* sample_order, cuembed_stream_t stream);
+/* ... and with cuembed::ForwardOptions::row_loads_device (extension; NULL = none): the row-load decision that
+ * cuembed_decide_row_loads left in device memory is read by the kernels instead of row_load_policy. */
+void cuembed_embedding_forward_device_hints(const void* params, int elem_type, int embed_width,
+                                            const void* indices, int index_type, const void* offsets,
+                                            int offset_type, const void* weights, int batch_size,
+                                            int num_hots, int mode, int fp16_math, void* ret,
+                                            int reduction_order, int row_load_policy,
+                                            const int32_t* sample_order, const uint32_t* row_loads_device,
+                                            cuembed_stream_t stream);
+/* cuembed::DecideRowLoads (extension; the reference has one launch rule for every index distribution,
+ * embedding_lookup.cuh:186-208): the row-load policy decided ON THE DEVICE from the batch's own indices, no read-back,
+ * one launch, capturable.  decision[0] = 1 (non-temporal row loads) when at least distinct_per_1024 / 1024 of an
+ * evenly strided sample of up to 65,536 lookups names distinct rows (counted exactly, in groups of 4,096), the table
+ * has table_bytes >= 1 GiB and the batch nnz >= 2^18 lookups; else 0.  distinct_per_1024 = 0: the built-in 0.95.
+ * `decision` = FOUR 32-bit device words zeroed once by the caller (words 1..3 are the kernel's own and stay zero);
+ * calls sharing them must be stream-ordered.  Never changes a result. */
+void cuembed_decide_row_loads(const void* indices, int index_type, int64_t nnz, int64_t table_bytes,
+                              uint32_t* decision, unsigned distinct_per_1024, cuembed_stream_t stream);
 /* cuembed::BagOrderByLength (extension): sample_order[batch_size] = the samples of a CSR batch by descending bag
- * length, ties in input order (a key kernel + the library's stable sort).  max_length > 0: a bound on the bag
- * length (fewer radix passes; longer bags rank as max_length), 0 = unknown.  Two-phase workspace query: work == NULL
- * writes the bytes needed to *lwork. */
+ * length, ties in input order.  max_length > 0: a bound on the bag length (longer bags rank as max_length), 0 =
+ * unknown, < 0 = bags of 255 lookups and more rank alike.  With a bound <= 255 and batch_size <= 131,072 it is ONE
+ * launch (a stable counting sort; ~5 us for 65,536 bags -- cheap enough for every fresh offsets array); otherwise a
+ * key kernel + the library's stable sort.  Two-phase workspace query: work == NULL writes the bytes needed to *lwork. */
 void cuembed_bag_order_by_length(const void* offsets, int offset_type, int batch_size, int max_length,
                                  int32_t* sample_order, char* work, size_t* lwork, cuembed_stream_t stream);
 /* cuembed::SetBackwardTuning / GetBackwardTuning (tuning and tests; 0 = built-in heuristic):

@@ -436,8 +436,9 @@ def test_native_step_replays_from_a_hip_graph(pyt):
 
 def test_policy_hints_never_change_a_result(pyt):
     """cuembed_amd.policy picks non-temporal row loads for a table whose batches are (nearly) all distinct rows and the
-    bag order for an offsets tensor it sees again; both are scheduling hints: same bits, and the decisions are the
-    expected ones (uniform indices over a > 1 GiB table: streaming; a power-law batch: not)."""
+    bag order for ragged CSR batches -- both decided ON THE DEVICE (no torch.unique, no read-back: torch's sync debug
+    mode is on while the hinted calls run); both are scheduling hints: same bits, and the decisions are the expected
+    ones (uniform indices over a > 1 GiB table: streaming; a skewed batch: not)."""
     from cuembed_amd import policy
     policy.set_enabled(True)
     k, d, B = 2_200_000, 128, 20000          # 1.05 GiB of fp32
@@ -448,22 +449,37 @@ def test_policy_hints_never_change_a_result(pyt):
     assert n >= policy.ORDER_MIN_LOOKUPS
     uniform = torch.randint(0, k, (n,), device="cuda")
     skewed = (k * torch.rand(n, device="cuda") ** 8).long()
-    assert policy.distinct_fraction(uniform) > 0.95 > policy.STREAMING_DISTINCT > policy.distinct_fraction(skewed)
     plain = pyt.cuemb_embedding(table, uniform, offsets, None, hints=None)
-    assert policy.row_loads(table, uniform) == 1 and policy.row_loads(table.clone(), skewed) == 0
-    assert policy.row_loads(table, uniform[: policy.STREAMING_MIN_LOOKUPS - 1]) == -1    # small batches: no decision at all
-    assert policy.sample_order(offsets, n) is None                  # first sight: nothing is prepared
-    order = policy.sample_order(offsets, n)                          # second sight: the order exists and is cached
-    assert order is not None and order.dtype == torch.int32 and policy.sample_order(offsets, n) is order
+    plain_skewed = pyt.cuemb_embedding(table, skewed, offsets, None, hints=None)
+    pyt.cuemb_embedding(table, uniform, offsets, None)               # warm-up: allocations, the table's decision words
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        hinted = pyt.cuemb_embedding(table, uniform, offsets, None)      # hints="auto": decision + order, device-side
+        t = table.clone().requires_grad_(True)
+        y = pyt.cuemb_embedding(t, uniform, offsets, None, sparse_grad="padded")
+        order = policy.sample_order(offsets, n)
+        words = policy.row_loads_device(table, uniform)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.equal(plain, hinted) and torch.equal(y, plain)
+    assert policy.row_loads_decision(table) == 1
+    assert words is not None and words.dtype == torch.int32 and words.tolist()[1:] == [0, 0, 0]
+    assert order is not None and order.dtype == torch.int32
     assert torch.equal(torch.sort(order.long()).values, torch.arange(B, device="cuda"))
     assert bool((lens[order.long()][1:] <= lens[order.long()][:-1]).all())         # descending bag length
-    hinted = pyt.cuemb_embedding(table, uniform, offsets, None)      # hints="auto": streaming + the cached order
-    assert torch.equal(plain, hinted)
-    t = table.clone().requires_grad_(True)
-    y = pyt.cuemb_embedding(t, uniform, offsets, None, sparse_grad=True)
-    assert torch.equal(y, plain)
+    # a fresh offsets tensor gets ITS order (nothing is cached: nothing can go stale)
+    lens2 = torch.flip(lens, [0])
+    offsets2 = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens2.cumsum(0)])
+    order2 = policy.sample_order(offsets2, n)
+    assert bool((lens2[order2.long()][1:] <= lens2[order2.long()][:-1]).all()) and not torch.equal(order, order2)
+    # another table, a skewed batch: default loads; same bits
+    table2 = table.clone()
+    assert torch.equal(pyt.cuemb_embedding(table2, skewed, offsets, None), plain_skewed)
+    assert policy.row_loads_decision(table2) == 0
+    assert policy.row_loads_device(table, uniform[: policy.STREAMING_MIN_LOOKUPS - 1]) is None   # small batches: no decision at all
     policy.set_enabled(False)
-    assert policy.row_loads(table, uniform) == -1 and policy.sample_order(offsets, n) is None
+    assert policy.row_loads_device(table, uniform) is None and policy.sample_order(offsets, n) is None
     policy.set_enabled(True)
 
 
