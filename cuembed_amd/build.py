@@ -213,6 +213,30 @@ def build_sort_unit_test(force=False):
     return exe
 
 
+def build_device_blocks_test(force=False):
+    """Compiles tests/cpp/device_blocks_unit.hip: unit tests of the gather / scatter building blocks (addressing, column
+    slices, Pack / Arith / RowPool, FinishPooledRow, AccumulateRow) instantiated in small kernels and compared with host
+    recomputation, bit for bit.  Needs a GPU to RUN (tests/test_gpu_device_blocks.py)."""
+    src = os.path.join(ROOT, "tests", "cpp", "device_blocks_unit.hip")
+    exe = os.path.join(ROOT, "tests", "cpp", "device_blocks_unit")
+    stamp = exe + ".stamp"
+    deps = [src]
+    for dirpath, _, files in os.walk(os.path.join(CSRC, "cuembed", "include")):
+        deps += [os.path.join(dirpath, f) for f in files]
+    digest = _digest_files(deps)
+    if not force and os.path.exists(exe) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return exe
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I" + CSRC, src, "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for tests/cpp/device_blocks_unit.hip:\n" + r.stdout)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return exe
+
+
 def build_manual_benchmark(force=False):
     """Compiles benchmarks/manual_benchmark.hip (C++ harness on the header-only API)."""
     src = os.path.join(ROOT, "benchmarks", "manual_benchmark.hip")

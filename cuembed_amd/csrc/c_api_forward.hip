@@ -93,8 +93,8 @@ void cuembed_embedding_forward_ordered(const void* params, int elem_type, int em
 }
 
 void cuembed_decide_row_loads(const void* indices, int index_type, int64_t nnz, int64_t table_bytes,
-                              uint32_t* decision, unsigned distinct_per_1024, cuembed_stream_t stream) {
-  const unsigned th = distinct_per_1024 != 0u ? distinct_per_1024 : cuembed::kStreamingDistinctPer1024;
+                              uint32_t* decision, unsigned distinct_per_65536, cuembed_stream_t stream) {
+  const unsigned th = distinct_per_65536 != 0u ? distinct_per_65536 : cuembed::kStreamingDistinctPer65536;
   if (index_type == CUEMBED_I32)
     cuembed::DecideRowLoads<int32_t>(static_cast<const int32_t*>(indices), nnz, table_bytes, decision, Stream(stream), th);
   else if (index_type == CUEMBED_I64)

@@ -445,14 +445,17 @@ void EmbeddingForward(const InputT* params,
 //! lives in the caches whatever the loads are): DecideRowLoads answers "default" for them without looking.
 constexpr int64_t kStreamingMinTableBytes = int64_t{1} << 30;
 constexpr int64_t kStreamingMinLookups = int64_t{1} << 18;
-//! ... and at least this share of a strided sample's rows must be distinct (x / 1024; measured crossover: see
-//! tools/row_loads_crossover_probe.py -- streaming loses as soon as rows repeat inside the caches' reach).
-constexpr unsigned kStreamingDistinctPer1024 = 973;    // 0.95
+//! ... and at least this share of a strided sample's rows must be distinct INSIDE their group of 4,096 (x / 65,536).
+//! Measured crossover at the C2 shape (tools/row_loads_crossover_probe.py, profiles/r06_row_loads_crossover.jsonl):
+//! power-law exponent 0.5 -- 99.93 % distinct inside a group, 3 repeats per 4,096 -- is where streaming stops
+//! paying (- 1 %); at exponent 0.75 (96.9 %) it already costs 20 %.  A few repeats per group are what separates the two:
+//! the threshold sits at 8 repeats per 4,096.
+constexpr unsigned kStreamingDistinctPer65536 = 65408;    // 0.998
 
 /**
  * @brief RowLoadPolicy decided ON THE DEVICE from the batch's own indices (extension): an evenly strided sample of up
  * to 65,536 lookups is cut into groups of 4,096, every group's DISTINCT rows are counted exactly (one workgroup and
- * one LDS hash set per group), and `decision[0]` becomes 1 (kStreaming) when at least `distinct_per_1024` / 1024 of
+ * one LDS hash set per group), and `decision[0]` becomes 1 (kStreaming) when at least `distinct_per_65536` / 65536 of
  * the sample is distinct, the table has `table_bytes` >= 1 GiB and the batch >= 2^18 lookups -- else 0.  One launch,
  * no read-back: pass `decision` as ForwardOptions::row_loads_device to the EmbeddingForward calls that follow (this
  * batch and, for a stationary index distribution, the next few hundred).
@@ -465,7 +468,7 @@ void DecideRowLoads(const IndexT* indices,
                     const int64_t table_bytes,
                     uint32_t* decision,
                     const hipStream_t stream = 0,
-                    const unsigned distinct_per_1024 = kStreamingDistinctPer1024) {
+                    const unsigned distinct_per_65536 = kStreamingDistinctPer65536) {
   CUEMBED_ASSERT(decision != nullptr);
   if (nnz < kStreamingMinLookups || table_bytes < kStreamingMinTableBytes || indices == nullptr) {
     detail::ClearRowLoadsDecisionKernel<0><<<1, 64, 0, stream>>>(decision);
@@ -474,7 +477,7 @@ void DecideRowLoads(const IndexT* indices,
   int64_t groups = nnz / detail::kDecideGroupSample;
   groups = groups > detail::kDecideMaxGroups ? detail::kDecideMaxGroups : groups;
   detail::DecideRowLoadsKernel<IndexT><<<static_cast<unsigned>(groups), detail::kDecideThreads, 0, stream>>>(
-      indices, nnz, detail::kDecideGroupSample, distinct_per_1024, decision);
+      indices, nnz, detail::kDecideGroupSample, distinct_per_65536, decision);
 }
 
 /**

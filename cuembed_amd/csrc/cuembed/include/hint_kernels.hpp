@@ -36,7 +36,7 @@ constexpr int kDecideMaxGroups = 16;       // 65,536 sampled lookups at most
 template <typename IndexT>
 __global__ void __launch_bounds__(kDecideThreads)
 DecideRowLoadsKernel(const IndexT* __restrict__ indices, const int64_t nnz, const int per_group,
-                     const unsigned threshold_per_1024, uint32_t* __restrict__ words) {
+                     const unsigned threshold_per_65536, uint32_t* __restrict__ words) {
   using Key = typename std::conditional<sizeof(IndexT) == 8, unsigned long long, unsigned>::type;
   __shared__ Key slots[kDecideSlots];
   __shared__ unsigned distinct;
@@ -75,7 +75,7 @@ DecideRowLoadsKernel(const IndexT* __restrict__ indices, const int64_t nnz, cons
     if (before + 1u == static_cast<unsigned>(groups)) {
       const unsigned total = __hip_atomic_load(words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int64_t taken = sampled < nnz ? sampled : nnz;
-      const bool streaming = static_cast<uint64_t>(total) * 1024u >= static_cast<uint64_t>(threshold_per_1024) * static_cast<uint64_t>(taken);
+      const bool streaming = static_cast<uint64_t>(total) * 65536u >= static_cast<uint64_t>(threshold_per_65536) * static_cast<uint64_t>(taken);
       __hip_atomic_store(words + 0, streaming ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(words + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next call
       __hip_atomic_store(words + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -31,9 +31,19 @@ def _p(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
+def _check_alpha(alpha, hotness):
+    """alpha = 1 is the one exponent the reference's inverse-CDF recipe cannot do (datagen.cpp:39-50: x = (u * span +
+    1) ^ (1 / (1 - alpha)) with span = 0: every draw is id 1, and a sample of more than one DISTINCT id never fills --
+    the reference's generator does not return either).  Say so instead of hanging."""
+    if float(alpha) == 1.0 and hotness > 1:
+        raise ValueError("alpha = 1 is singular in the reference's power-law recipe (every draw is the same id); "
+                         "use e.g. 0.99 or 1.01")
+
+
 def generate_indices(num_categories, batch_size, hotness, alpha=0.0, index=np.int32, shuffle=True,
                      permute=True, offsets=None):
     """batch_size samples x hotness distinct ids in [0, num_categories), power-law(alpha)."""
+    _check_alpha(alpha, hotness)
     out = np.empty((batch_size * hotness,), dtype=index)
     off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int32)
     n = _lib().cuembed_harness_generate_indices(
@@ -51,6 +61,7 @@ def allocate_forward(num_categories, embed_width, batch_size, hotness, alpha=0.0
     are the reference's; use it when the table is filled on the GPU.  consume_table_draws=False
     additionally skips those draws (fast for 10M-row tables; offsets/weights then differ from the
     reference stream but have the same distribution)."""
+    _check_alpha(alpha, hotness)
     table = np.empty((num_categories, embed_width), dtype=elem) if with_table else None
     offsets = np.empty((batch_size + 1,), dtype=np.int32)
     indices = np.empty((batch_size * hotness,), dtype=index)

@@ -211,7 +211,7 @@ def decide_row_loads(indices, table_bytes, decision=None, distinct_fraction=None
     (cuembed::DecideRowLoads): one launch, no read-back, capturable.  Returns `decision`, a 4-word int32 device tensor
     (word 0: 1 = non-temporal row loads, 0 = ordinary; allocate it once with new_row_loads_decision() and re-use it) to
     pass as embedding_forward(..., row_loads_device=).  Streaming is chosen when at least `distinct_fraction` (default
-    0.95) of an evenly strided sample of up to 65,536 lookups names distinct rows, the table has >= 1 GiB and the batch
+    0.998, i.e. at most 8 repeats per group of 4,096: the measured crossover) of an evenly strided sample of up to 65,536 lookups names distinct rows, the table has >= 1 GiB and the batch
     >= 2^18 lookups.  Never changes a result."""
     _check_dev("indices", indices)
     it = _index_code("indices", indices)
@@ -220,7 +220,7 @@ def decide_row_loads(indices, table_bytes, decision=None, distinct_fraction=None
     _check_dev("decision", decision, indices.device)
     if decision.dtype != torch.int32 or decision.numel() < 4 or not decision.is_contiguous():
         raise ValueError("decision must be a contiguous int32 tensor of 4 words (new_row_loads_decision())")
-    th = 0 if distinct_fraction is None else max(1, min(1024, int(round(float(distinct_fraction) * 1024))))
+    th = 0 if distinct_fraction is None else max(1, min(65536, int(round(float(distinct_fraction) * 65536))))
     with torch.cuda.device(indices.device):
         _lib.lib().cuembed_decide_row_loads(_ptr(indices.contiguous()), it, indices.numel(), int(table_bytes),
                                             _ptr(decision), th, _stream(indices))

@@ -12,7 +12,9 @@ have the same two calls: cuembed_decide_row_loads, cuembed_bag_order_by_length).
                 rows of an evenly strided sample of the batch exactly (one launch, ~5 us) and leaves the decision in
                 four device words that the forward kernels read (ForwardOptions::row_loads_device); run for the first
                 batch of a table and again every RECHECK_CALLS calls; in between the forward re-reads the last decision.
-                Conservative: streaming only when >= 95 % of the sample is distinct, the table is >= 1 GiB and the
+                Conservative: streaming only when >= 99.8 % of the sample is distinct inside its group of 4,096 (the
+                measured crossover: at 96.9 % -- power-law exponent 0.75 -- streaming already costs 20 %; round 5's
+                host-side rule, >= 80 % of a 65,536 sample, chose it there), the table is >= 1 GiB and the
                 batch has >= 2^18 lookups (the gates are the library's: kStreamingMinTableBytes / kStreamingMinLookups).
   sample_order  the samples of a ragged CSR batch by descending bag length (cuembed::BagOrderByLength; C3: 0.170 ->
                 0.148 ms).  With bag lengths clamped at 255 it is ONE launch of ~5 us (a stable counting sort), cheap

@@ -406,13 +406,14 @@ void cuembed_embedding_forward_device_hints(const void* params, int elem_type, i
                                             cuembed_stream_t stream);
 /* cuembed::DecideRowLoads (extension; the reference has one launch rule for every index distribution,
  * embedding_lookup.cuh:186-208): the row-load policy decided ON THE DEVICE from the batch's own indices, no read-back,
- * one launch, capturable.  decision[0] = 1 (non-temporal row loads) when at least distinct_per_1024 / 1024 of an
+ * one launch, capturable.  decision[0] = 1 (non-temporal row loads) when at least distinct_per_65536 / 65536 of an
  * evenly strided sample of up to 65,536 lookups names distinct rows (counted exactly, in groups of 4,096), the table
- * has table_bytes >= 1 GiB and the batch nnz >= 2^18 lookups; else 0.  distinct_per_1024 = 0: the built-in 0.95.
+ * has table_bytes >= 1 GiB and the batch nnz >= 2^18 lookups; else 0.  distinct_per_65536 = 0: the built-in 0.998
+ * (8 repeats per group of 4,096: the measured crossover -- streaming costs 20 % as soon as 3 % of a group repeats).
  * `decision` = FOUR 32-bit device words zeroed once by the caller (words 1..3 are the kernel's own and stay zero);
  * calls sharing them must be stream-ordered.  Never changes a result. */
 void cuembed_decide_row_loads(const void* indices, int index_type, int64_t nnz, int64_t table_bytes,
-                              uint32_t* decision, unsigned distinct_per_1024, cuembed_stream_t stream);
+                              uint32_t* decision, unsigned distinct_per_65536, cuembed_stream_t stream);
 /* cuembed::BagOrderByLength (extension): sample_order[batch_size] = the samples of a CSR batch by descending bag
  * length, ties in input order.  max_length > 0: a bound on the bag length (longer bags rank as max_length), 0 =
  * unknown, < 0 = bags of 255 lookups and more rank alike.  With a bound <= 255 and batch_size <= 131,072 it is ONE

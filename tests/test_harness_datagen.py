@@ -72,3 +72,13 @@ def test_multi_hot_no_repeats_in_range(harness):
     idx = harness.generate_indices(1001, 40000, 64, alpha=1.15, shuffle=False, permute=False).reshape(40000, 64)
     assert idx.min() >= 1 and idx.max() <= 1000
     assert (np.diff(np.sort(idx, axis=1), axis=1) > 0).all()
+
+
+def test_alpha_one_is_refused_instead_of_hanging(harness):
+    """alpha = 1 makes the reference's inverse-CDF recipe draw the same id forever (span = 0, datagen.cpp:39-50), and a
+    sample of several DISTINCT ids then never fills: the Python layer refuses it."""
+    with pytest.raises(ValueError):
+        harness.generate_indices(1000, 4, 8, alpha=1.0)
+    with pytest.raises(ValueError):
+        harness.allocate_forward(1000, 8, 4, 8, alpha=1.0)
+    assert harness.generate_indices(1000, 4, 1, alpha=1.0).shape == (4,)      # one id per sample: the recipe terminates

@@ -45,6 +45,13 @@ tools/row_read_ceiling --c2-parts 1.15 > "$O/forward_parts_probe.csv" 2>> "$O/ro
 tools/row_read_ceiling --c2-parts 0 >> "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
 python tools/narrow_row_probe.py > "$O/narrow_row_probe.jsonl" 2>> "$O/row_read_ceiling.err"
 python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
+# the same grid through the C++ benchmark binary (host launch cost of a C++ program, like the reference's sweep): mean / min /
+# median over 3 independent processes per point and every kernel's share of the step
+python benchmarks/sweep_parameters.py --binary --repetitions 3 --iterations 30 --csv "$O/sweep_parameters_cpp_binary.csv" > "$O/sweep_binary.log" 2>&1
+python tools/high_word_timing.py > "$O/high_word_timing.jsonl" 2>> "$O/torch_probe.err"
+CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 python tools/high_word_timing.py >> "$O/high_word_timing.jsonl" 2>> "$O/torch_probe.err"
+python tools/high_word_stress.py 120 > "$O/high_word_stress.json" 2>> "$O/torch_probe.err"
+python tools/row_loads_crossover_probe.py > "$O/row_loads_crossover.jsonl" 2>> "$O/torch_probe.err"
 # profiler passes last (they clock lower); the program goes directly after `--`
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-c5 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
@@ -107,4 +114,5 @@ cp "$O/traffic_c3.json" "$R/profiles/traffic_c3.json"
 python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2>> "$O/bench.err"
 python bench.py --steps 200 --warmup 20 > "$O/bench_c2_line_200_steps.json" 2>> "$O/bench.err"
 python bench.py --gpus 2 --steps 20 --warmup 5 > "$O/bench_c2_two_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
+python bench.py --gpus 8 --steps 20 --warmup 5 > "$O/bench_c2_eight_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
 ls -la "$O"

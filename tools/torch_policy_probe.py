@@ -3,7 +3,7 @@
 offsets, weights) with hints="auto" (cuembed_amd.policy) against hints=None, forward only, HIP events, back to back.
   * C3 (fp32 weighted sum, CSR bags U[0, 128], 10M x 128, batch 65,536): the bag order is computed for EVERY call from
     the offsets (one launch, device-side; the hints_auto time includes it);
-  * C2 shape with uniform indices (the HBM-bound case): non-temporal row loads once a sample of the batch is >= 95 %
+  * C2 shape with uniform indices (the HBM-bound case): non-temporal row loads once a sample of the batch is >= 99.8 %
     distinct rows (decided on the device, read by the kernels);
   * C2 itself (alpha = 1.15): the policy must NOT pick streaming.
 One JSON line."""
