@@ -436,6 +436,13 @@ int EmbeddingLookupBenchmark(const Flags& f, const char* argv0) {
     order_work.Resize(lw_o);
     cuembed::BagOrderByLength<OffsetT>(w.offsets.ptr, f.batch_size, f.hotness, w.sample_order.ptr, order_work.ptr, &lw_o);
     HIP_OK(hipDeviceSynchronize());
+    // ... and what it costs to prepare: the same protocol as the kernels below (one launch up to 131,072 bags of <= 255 lookups)
+    const float oms = timer.Run(f.iterations, [&] {
+      cuembed::BagOrderByLength<OffsetT>(w.offsets.ptr, f.batch_size, f.hotness, w.sample_order.ptr, order_work.ptr, &lw_o);
+    });
+    std::fprintf(stderr, "Bag order. Iterations: %d , Total time [ms]: %.3f , Avg [ms]: %.5f\n", f.iterations, oms,
+                 oms / f.iterations);
+    CsvLine(f, "bag_order", oms, 0.0, 0.0, timer);
   }
   float ms = timer.Run(f.iterations, [&] { RunForward<ElemT, IndexT, OffsetT, fp16_math>(w); });
   double bytes = f.csr_input ? es * (nnz - 1 + B) * W : es * B * (H + 1) * W;

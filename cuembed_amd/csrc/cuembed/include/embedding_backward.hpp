@@ -333,8 +333,9 @@ void EmbeddingBackward(const GradT* grad_y,
  * (utils/include/embedding_lookup_cpu.hpp:131-143).  Bit-identical to it for ANY data: fp16 / bf16 gradients that
  * are not exactly representable, runs of any length.  (EmbeddingBackward keeps fp32 partial sums and rounds once per
  * flush: identical on exactly representable data, closer to the true sum otherwise.)  A rounding chain cannot be cut
- * into partial sums, so one run is walked by ONE lane group: slow where a row is looked up very often (the hottest row
- * of the C4 batch: 65,528 sequential lookups).  skip_grad_init = true ADDS to what grad_embedding holds, like the
+ * into partial sums, so one run is ONE chain of dependent additions (the hottest row of the C4 batch: 65,528 of them);
+ * short runs are walked by one lane group each, runs of 256 lookups and more by a whole workgroup that gathers 64 rows at
+ * a time into LDS and chains every element of the row on a thread of its own.  C4: ~8 x the default path's time in fp16.  skip_grad_init = true ADDS to what grad_embedding holds, like the
  * reference's loop on a buffer the caller did not zero.
  */
 template <typename GradT, typename IndexT>
@@ -371,14 +372,18 @@ void EmbeddingBackwardReferenceSums(const GradT* grad_y,
   const int64_t spans = (static_cast<int64_t>(nnz) + detail::kReferenceSpan - 1) / detail::kReferenceSpan;
   const dim3 grid(static_cast<unsigned>((spans + groups - 1) / groups), 1, 1);
   constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
+  // runs of 256 lookups and more are walked by the whole workgroup out of LDS (see the kernel); 0: shape without that path
+  const size_t row_bytes = static_cast<size_t>(embed_width) * sizeof(ElemT);
+  const int chunk = detail::ReferenceChunkRows(row_bytes, lanes * groups, groups, embed_width);
+  const size_t lds = chunk > 0 ? 2 * static_cast<size_t>(chunk) * (row_bytes + sizeof(ElemT)) : 0;
 #define CUEMBED_LAUNCH_REFERENCE(NN)                                                                               \
   do {                                                                                                             \
     if (w != nullptr)                                                                                              \
-      detail::ReferenceSumsScatterKernel<ElemT, IndexT, NN, true><<<grid, block, 0, stream>>>(                      \
-          gy, embed_width, rows, transpose_sample_ids, w, nnz, out, skip_grad_init, run_ids, inverse_mapping);      \
+      detail::ReferenceSumsScatterKernel<ElemT, IndexT, NN, true><<<grid, block, lds, stream>>>(                    \
+          gy, embed_width, rows, transpose_sample_ids, w, nnz, out, skip_grad_init, run_ids, inverse_mapping, chunk); \
     else                                                                                                           \
-      detail::ReferenceSumsScatterKernel<ElemT, IndexT, NN, false><<<grid, block, 0, stream>>>(                     \
-          gy, embed_width, rows, transpose_sample_ids, w, nnz, out, skip_grad_init, run_ids, inverse_mapping);      \
+      detail::ReferenceSumsScatterKernel<ElemT, IndexT, NN, false><<<grid, block, lds, stream>>>(                   \
+          gy, embed_width, rows, transpose_sample_ids, w, nnz, out, skip_grad_init, run_ids, inverse_mapping, chunk); \
   } while (0)
   if (split.elems_per_lane == kMaxN) CUEMBED_LAUNCH_REFERENCE(kMaxN);
   else if (split.elems_per_lane == kMaxN / 2) CUEMBED_LAUNCH_REFERENCE(kMaxN / 2);

@@ -4,11 +4,12 @@
 // index distribution).  Two of this library's options depend on the DATA -- non-temporal row loads pay only when the
 // rows of a batch are (nearly) all distinct, the bag order only for ragged bags -- and a caller of the C++ / C API
 // cannot be asked to read index statistics back to the host in the middle of a step.  Both decisions are taken on the
-// device here, in ONE launch each, without a read-back, so they can sit inside a stream-ordered step and a HIP graph:
+// device here, in one or two small launches each, without a read-back, so they can sit inside a stream-ordered step and a HIP graph:
 //   DecideRowLoadsKernel    counts the distinct rows of an evenly strided sample of the batch exactly (LDS hash
 //                           sets) and leaves a flag word in device memory that the forward kernels read;
-//   BagOrderCountingKernel  the samples of a CSR batch by descending bag length -- a stable counting sort on lengths
-//                           clamped to 255 -- for ForwardOptions::sample_order.
+//   BagChunkHistogramKernel + BagOrderScatterKernel
+//                           the samples of a CSR batch by descending bag length -- a stable counting sort on lengths
+//                           clamped to 255, two small launches -- for ForwardOptions::sample_order.
 #ifndef CUEMBED_INCLUDE_HINT_KERNELS_HPP_
 #define CUEMBED_INCLUDE_HINT_KERNELS_HPP_
 
@@ -90,57 +91,82 @@ __global__ void ClearRowLoadsDecisionKernel(uint32_t* __restrict__ words) {
 }
 
 // ---------------------------------------------------------------------------
-// Bag order in one launch: sample_order = the samples by DESCENDING min(bag length, 255), ties in input order (a stable
-// counting sort over 256 keys).  Workgroup w owns samples [1024 w, 1024 w + 1024).  No workgroup waits for another:
-// every one counts the keys of the WHOLE batch itself (the offsets are a few hundred KB and come from L2) -- the
-// counts of the samples before its own range and the totals -- then ranks its own 1,024 samples with the sort's
-// wave-synchronous match (MatchDigit) and writes their positions.  Worth it up to ~2^17 samples; BagOrderByLength
-// falls back to the general sort above that and for length bounds beyond 255.
+// Bag order: sample_order = the samples by DESCENDING min(bag length, 255), ties in input order -- a stable counting sort
+// over 256 keys in TWO small launches, chunks of 1,024 samples:
+//   BagChunkHistogramKernel  workgroup w counts the keys of ITS chunk (one LDS atomic per group of equal keys in a
+//                            wavefront: the sort's MatchDigit) and stores the 256 counts;
+//   BagOrderScatterKernel    workgroup w adds up the chunks' counts -- all of them for the key totals, the chunks before
+//                            its own for its bases -- and ranks its samples with the wave-synchronous match.
+// (A ONE-launch form in which every workgroup counts the whole batch itself, so that nobody depends on anybody, was built
+// first: 64 rounds of 1,024 LDS atomics per workgroup at 65,536 samples -- 34 us with one round's offsets in flight, 17 us
+// with eight and a 32-fold replicated histogram against same-word queues: LDS atomics retire ~2 lanes per clock.  Two
+// dependent launches of a few microseconds each beat it.)  Up to 2^17 samples; BagOrderByLength falls back to the general
+// sort above that and for length bounds beyond 255.
 // ---------------------------------------------------------------------------
 constexpr int kBagOrderThreads = 1024;
 constexpr int kBagOrderWaves = kBagOrderThreads / 64;
 constexpr int kBagOrderMaxBatch = 1 << 17;
 
 template <typename OffsetT>
-__device__ __forceinline__ unsigned BagKey(const OffsetT* __restrict__ offsets, const int s, const int bound) {
-  int64_t len = static_cast<int64_t>(offsets[s + 1]) - static_cast<int64_t>(offsets[s]);
+__device__ __forceinline__ unsigned BagKeyOf(const OffsetT lo, const OffsetT hi, const int bound) {
+  int64_t len = static_cast<int64_t>(hi) - static_cast<int64_t>(lo);
   len = len < 0 ? 0 : (len > bound ? bound : len);
   return static_cast<unsigned>(bound - static_cast<int>(len));     // ascending keys = descending lengths
 }
 
 template <typename OffsetT>
 __global__ void __launch_bounds__(kBagOrderThreads)
-BagOrderCountingKernel(const OffsetT* __restrict__ offsets, const int batch, const int bound /* 1..255 */,
-                       int32_t* __restrict__ sample_order) {
-  __shared__ unsigned total[256];                 // keys of the whole batch
-  __shared__ unsigned before[256];                // ... of the samples before this workgroup's
+BagChunkHistogramKernel(const OffsetT* __restrict__ offsets, const int batch, const int bound /* 1..255 */,
+                        unsigned* __restrict__ chunk_hist /* [chunks][256] */) {
+  __shared__ unsigned hist[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0u;
+  __syncthreads();
+  const int s = static_cast<int>(blockIdx.x) * kBagOrderThreads + tid;
+  const bool valid = s < batch;
+  const unsigned key = valid ? BagKeyOf(offsets[s], offsets[s + 1], bound) : 0u;
+  const unsigned long long peers = MatchDigit(key, valid);
+  if (valid && CountBelow(peers) == 0u) atomicAdd(&hist[key], static_cast<unsigned>(__popcll(peers)));
+  __syncthreads();
+  if (tid < 256) chunk_hist[static_cast<size_t>(blockIdx.x) * 256 + tid] = hist[tid];
+}
+
+template <typename OffsetT>
+__global__ void __launch_bounds__(kBagOrderThreads)
+BagOrderScatterKernel(const OffsetT* __restrict__ offsets, const int batch, const int bound,
+                      const unsigned* __restrict__ chunk_hist, int32_t* __restrict__ sample_order) {
+  __shared__ unsigned part_before[4][256], part_total[4][256];
+  __shared__ unsigned base_of[256];                       // first output position of this workgroup's samples with key k
   __shared__ unsigned wave_count[kBagOrderWaves][256];
   __shared__ unsigned scan_carry[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int first = static_cast<int>(blockIdx.x) * kBagOrderThreads;
-  if (tid < 256) total[tid] = 0u;
+  const int chunks = static_cast<int>(gridDim.x), me = static_cast<int>(blockIdx.x);
   for (int i = tid; i < kBagOrderWaves * 256; i += kBagOrderThreads) (&wave_count[0][0])[i] = 0u;
-  __syncthreads();
-  // One LDS atomic per group of equal keys in a wavefront (all bags alike would otherwise be 1,024 atomics on one word).
-  auto count_range = [&](const int lo, const int hi) {
-    for (int base = lo; base < hi; base += kBagOrderThreads) {
-      const int s = base + tid;
-      const bool valid = s < hi;
-      const unsigned key = valid ? BagKey(offsets, s, bound) : 0u;
-      const unsigned long long peers = MatchDigit(key, valid);
-      if (valid && CountBelow(peers) == 0u) atomicAdd(&total[key], static_cast<unsigned>(__popcll(peers)));
+  // my sample's key first: its two loads are in flight while the chunk counts are added up
+  const int s = me * kBagOrderThreads + tid;
+  const bool valid = s < batch;
+  OffsetT lo = OffsetT(0), hi = OffsetT(0);
+  if (valid) {
+    lo = offsets[s];
+    hi = offsets[s + 1];
+  }
+  {  // thread (k, quarter q) adds up the counts of key k over chunks q, q + 4, q + 8, ...: independent loads
+    const int k = tid & 255, q = tid >> 8;
+    unsigned before = 0u, total = 0u;
+    for (int c = q; c < chunks; c += 4) {
+      const unsigned h = chunk_hist[static_cast<size_t>(c) * 256 + k];
+      total += h;
+      if (c < me) before += h;
     }
-  };
-  count_range(0, first < batch ? first : batch);
-  __syncthreads();
-  if (tid < 256) before[tid] = total[tid];
-  __syncthreads();
-  count_range(first, batch);
+    part_before[q][k] = before;
+    part_total[q][k] = total;
+  }
   __syncthreads();
   // base of key k = samples with a smaller key (whole batch) + samples with key k before this workgroup
-  unsigned mine = 0u, incl = 0u;
+  unsigned mine = 0u, incl = 0u, before = 0u;
   if (tid < 256) {
-    mine = total[tid];
+    mine = part_total[0][tid] + part_total[1][tid] + part_total[2][tid] + part_total[3][tid];
+    before = part_before[0][tid] + part_before[1][tid] + part_before[2][tid] + part_before[3][tid];
     incl = mine;
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned up = __shfl_up(incl, off);
@@ -152,18 +178,16 @@ BagOrderCountingKernel(const OffsetT* __restrict__ offsets, const int batch, con
   if (tid < 256) {
     unsigned carry = 0u;
     for (int w = 0; w < wave; ++w) carry += scan_carry[w];
-    total[tid] = carry + incl - mine + before[tid];          // (total now holds the bases)
+    base_of[tid] = carry + incl - mine + before;
   }
   // rank of my sample among the workgroup's samples with the same key: lanes below me in my wavefront + earlier wavefronts
-  const int s = first + tid;
-  const bool valid = s < batch;
-  const unsigned key = valid ? BagKey(offsets, s, bound) : 0u;
+  const unsigned key = valid ? BagKeyOf(lo, hi, bound) : 0u;
   const unsigned long long peers = MatchDigit(key, valid);
   const unsigned below = CountBelow(peers);
   if (valid && below == 0u) wave_count[wave][key] = static_cast<unsigned>(__popcll(peers));
   __syncthreads();
   if (!valid) return;
-  unsigned pos = total[key] + below;
+  unsigned pos = base_of[key] + below;
   for (int w = 0; w < wave; ++w) pos += wave_count[w][key];
   sample_order[pos] = s;
 }

@@ -293,10 +293,9 @@ BagLengthKeysKernel(const OffsetT* __restrict__ offsets, const int batch_size, c
  * (TransposeFixedHotness with hotness 1: the payload is the position); `max_length` > 0, a bound on the bag length,
  * keeps the sort to the key bits that exist (longer bags are ranked as max_length: that costs balance, never
  * correctness); 0 = unknown; < 0 = "rank bags of 255 lookups and more alike".  With a bound of at most 255 and up to
- * 131,072 samples the order comes out of ONE launch (detail::BagOrderCountingKernel, a stable counting sort: the same
- * permutation as the general sort gives; 65,536 bags: ~5 us instead of 18) -- cheap enough to compute for every fresh
- * offsets array of a C3-like batch (0.170 -> 0.15 ms including the ordering).  It only depends on the offsets.
- * Two-phase workspace query as for Transpose() (the one-launch path needs none of it).
+ * 131,072 samples the order comes out of TWO small launches (hint_kernels.hpp: a stable counting sort in chunks of
+ * 1,024 samples, the same permutation as the general sort gives) -- cheap enough to compute for every fresh offsets
+ * array of a C3-like batch.  It only depends on the offsets.  Two-phase workspace query as for Transpose().
  */
 template <typename OffsetT>
 void BagOrderByLength(const OffsetT* offsets,
@@ -308,13 +307,18 @@ void BagOrderByLength(const OffsetT* offsets,
                       const hipStream_t stream = 0) {
   const int bound = max_length > 0 ? max_length : (max_length < 0 ? 255 : INT32_MAX);
   if (bound <= 255 && batch_size > 0 && batch_size <= detail::kBagOrderMaxBatch) {
+    const int chunks = (batch_size + detail::kBagOrderThreads - 1) / detail::kBagOrderThreads;
+    const size_t need = static_cast<size_t>(chunks) * 256 * sizeof(unsigned);     // the chunks' key counts
     if (work == nullptr) {
-      *lwork = 256;      // (nothing is needed; non-zero so that the second call has a pointer to pass)
+      *lwork = need;
       return;
     }
-    detail::BagOrderCountingKernel<OffsetT>
-        <<<(batch_size + detail::kBagOrderThreads - 1) / detail::kBagOrderThreads, detail::kBagOrderThreads, 0, stream>>>(
-            offsets, batch_size, bound, sample_order);
+    assert(*lwork >= need);
+    unsigned* chunk_hist = reinterpret_cast<unsigned*>(work);
+    detail::BagChunkHistogramKernel<OffsetT><<<chunks, detail::kBagOrderThreads, 0, stream>>>(offsets, batch_size, bound,
+                                                                                            chunk_hist);
+    detail::BagOrderScatterKernel<OffsetT><<<chunks, detail::kBagOrderThreads, 0, stream>>>(offsets, batch_size, bound,
+                                                                                          chunk_hist, sample_order);
     return;
   }
   int bits = 0;

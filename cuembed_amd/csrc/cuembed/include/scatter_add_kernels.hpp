@@ -648,27 +648,61 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
 //! lane group per run of equal row ids walks the run in nz order with the product and the running sum rounded to
 //! GradT at every lookup -- `grad += grad_y * weight` in GradT, the CPU reference's loop
 //! (embedding_lookup_cpu.hpp:131-143) -- so the result is bit-identical to it for ANY data.  A rounding chain cannot be
-//! cut into partial sums, hence one run = one lane group whatever its length: the hottest row of the C4 batch (65,528
-//! lookups) is walked by a single group.  8 row gathers in flight per group.
+//! cut into partial sums, hence one run = one chain whatever its length: the hottest row of the C4 batch is 65,528
+//! dependent additions.  What CAN be shared is everything around the chain:
+//!   * short runs: one lane group per run, 8 row gathers in flight;
+//!   * runs of kReferenceLongRun lookups and more (at most one can START inside a workgroup's 64 lookups): the whole
+//!     workgroup walks it -- all of its threads gather the next kReferenceChunk rows of grad_y into LDS at once (one
+//!     memory round trip per chunk instead of one per 8 lookups; sample ids and weights one chunk further ahead), and
+//!     every element of the row gets a thread of its own that runs the chain out of LDS (convert, [multiply, round,] add,
+//!     round: ~25 cycles a lookup) while the next chunk is in flight.  C4, fp16: 26.4 -> ~2 ms.
 //!   block = (lanes_per_row, groups); every group looks at kReferenceSpan consecutive lookups and walks the runs that
 //!   START there.
 constexpr int kReferenceSpan = 8;
+constexpr int kReferenceLongRun = 256;
+constexpr int kReferenceChunk = 64;          //!< rows per LDS buffer (two buffers); fewer for rows beyond 512 bytes
+constexpr int kReferenceMaxChains = 4;       //!< row elements per thread in the long-run path
+
+//! LDS rows per buffer for the long-run path, 0 = no long-run path for this shape (the launcher's and the kernel's rule).
+inline int ReferenceChunkRows(const size_t row_bytes, const int block_threads, const int groups, const int width) {
+  if (block_threads != 256 || width > kReferenceMaxChains * block_threads) return 0;
+  int rows = kReferenceChunk;
+  while (rows > groups && 2 * static_cast<size_t>(rows) * row_bytes > (size_t{48} << 10)) rows /= 2;
+  if (rows < groups || rows % groups != 0 || 2 * static_cast<size_t>(rows) * row_bytes > (size_t{48} << 10)) return 0;
+  return rows / groups <= 8 ? rows : 0;
+}
 
 template <typename GradT, typename IndexT, int N, bool kWeighted>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, const IndexT* __restrict__ rows,
                            const IndexT* __restrict__ sample_ids, const GradT* __restrict__ weights, const int64_t nnz,
                            GradT* __restrict__ grad_out, const bool add_to_output,
-                           const IndexT* __restrict__ run_ids, IndexT* __restrict__ inverse_mapping) {
+                           const IndexT* __restrict__ run_ids, IndexT* __restrict__ inverse_mapping,
+                           const int chunk_rows /* > 0: long runs are walked by the whole workgroup */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char reference_lds[];
+  __shared__ long long long_head;          // first lookup of the long run that starts in this workgroup's span, or -1
+  __shared__ int chunk_count[2];
   const int lane_x = threadIdx.x;
   const int64_t group = static_cast<int64_t>(blockIdx.x) * blockDim.y + threadIdx.y;
   const int64_t column0 = static_cast<int64_t>(lane_x) * N;
   typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
   constexpr int K = 8;
+  if (chunk_rows > 0) {
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      long_head = -1;
+      chunk_count[0] = 0;
+      chunk_count[1] = 0;
+    }
+    __syncthreads();
+  }
   for (int64_t p = group * kReferenceSpan; p < (group + 1) * kReferenceSpan && p < nnz; ++p) {
     const IndexT row = rows[p];
     if (p > 0 && rows[p - 1] == row) continue;   // not the first lookup of its run
     if (run_ids != nullptr && lane_x == 0) inverse_mapping[row] = run_ids[p];
+    if (chunk_rows > 0 && p + kReferenceLongRun < nnz && rows[p + kReferenceLongRun] == row) {
+      if (lane_x == 0) long_head = p;            // (one per workgroup at most: the run outlasts the workgroup's span)
+      continue;
+    }
     GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
     float acc[N];
     if (add_to_output) {
@@ -713,6 +747,100 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
 #pragma unroll
     for (int e = 0; e < N; ++e) result.v[e] = static_cast<GradT>(acc[e]);
     *reinterpret_cast<Pack<GradT, N>*>(dst) = result;
+  }
+  if (chunk_rows <= 0) return;
+  __syncthreads();
+  if (long_head < 0) return;
+  // ---- the long run that starts here: gathered by everybody, chained out of LDS ----
+  const int64_t p = long_head;
+  const IndexT row = rows[p];
+  const int threads = blockDim.x * blockDim.y;                 // 256 (ReferenceChunkRows)
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const int groups = blockDim.y;
+  const int per = chunk_rows / groups;                         // rows of a chunk that one lane group gathers (<= 8)
+  GradT* stage = reinterpret_cast<GradT*>(reference_lds);      // [2][chunk_rows][width]
+  GradT* stage_w = stage + 2 * static_cast<size_t>(chunk_rows) * width;   // [2][chunk_rows]
+  float acc[kReferenceMaxChains];
+#pragma unroll
+  for (int c = 0; c < kReferenceMaxChains; ++c) {
+    const int e = tid + c * threads;
+    acc[c] = (add_to_output && e < width) ? static_cast<float>(grad_out[static_cast<int64_t>(row) * width + e]) : 0.f;
+  }
+  // what a lane group knows about ITS rows of a chunk: sample id, weight, "still in the run" -- for the chunk whose rows
+  // are being gathered (`now`) and for the one after it (`next`: its ids are requested a whole chunk ahead, so that a
+  // gather never waits for them)
+  struct Lookups {
+    IndexT sid[8];
+    GradT w[8];
+    bool ok[8];
+  };
+  Lookups now, next;
+  auto look_up = [&](Lookups& l, const int64_t first) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t at = first + threadIdx.y + static_cast<int64_t>(k) * groups;
+      l.ok[k] = k < per && at < nnz && rows[at] == row;
+      l.sid[k] = l.ok[k] ? sample_ids[at] : IndexT(0);
+      if constexpr (kWeighted) l.w[k] = l.ok[k] ? weights[at] : static_cast<GradT>(0);
+    }
+  };
+  raw_t held[8];
+  auto gather = [&](const Lookups& l) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (l.ok[k]) held[k] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(l.sid[k]), width));
+  };
+  auto park = [&](const Lookups& l, const int buffer) {       // registers -> LDS, and how many rows of the chunk are the run's
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (l.ok[k]) {
+        const int slot = threadIdx.y + k * groups;
+        *reinterpret_cast<raw_t*>(stage + (static_cast<size_t>(buffer) * chunk_rows + slot) * width + column0) = held[k];
+        if constexpr (kWeighted)
+          if (lane_x == 0) stage_w[buffer * chunk_rows + slot] = l.w[k];
+        ++mine;
+      }
+    }
+    if (lane_x == 0 && mine > 0) atomicAdd(&chunk_count[buffer], mine);
+  };
+  look_up(now, p);
+  gather(now);
+  look_up(next, p + chunk_rows);
+  int64_t q = p;                             // first lookup of the chunk in `held`
+  for (int buffer = 0;; buffer ^= 1) {
+    park(now, buffer);                       // (waits for the gathers of this chunk)
+    now = next;
+    look_up(next, q + 2 * static_cast<int64_t>(chunk_rows));
+    __syncthreads();
+    const int count = chunk_count[buffer];   // the run's rows are a prefix of the chunk (the COO is sorted)
+    if (count == chunk_rows) gather(now);    // the next chunk's rows: in flight while this one is chained
+    const GradT* rows_now = stage + static_cast<size_t>(buffer) * chunk_rows * width;
+    const GradT* w_now = stage_w + buffer * chunk_rows;
+#pragma unroll
+    for (int c = 0; c < kReferenceMaxChains; ++c) {
+      const int e = tid + c * threads;
+      if (e < width) {
+        float a = acc[c];
+#pragma unroll 8
+        for (int j = 0; j < count; ++j) {
+#pragma clang fp contract(off)
+          float x = static_cast<float>(rows_now[static_cast<size_t>(j) * width + e]);
+          if constexpr (kWeighted) x = static_cast<float>(static_cast<GradT>(x * static_cast<float>(w_now[j])));   // product in GradT
+          a = static_cast<float>(static_cast<GradT>(a + x));                                                       // sum in GradT
+        }
+        acc[c] = a;
+      }
+    }
+    __syncthreads();                         // everybody is through with this buffer
+    if (tid == 0) chunk_count[buffer] = 0;   // (next used two chunks on, with barriers in between)
+    if (count < chunk_rows) break;           // the run ended inside this chunk
+    q += chunk_rows;
+  }
+#pragma unroll
+  for (int c = 0; c < kReferenceMaxChains; ++c) {
+    const int e = tid + c * threads;
+    if (e < width) grad_out[static_cast<int64_t>(row) * width + e] = static_cast<GradT>(acc[c]);
   }
 }
 
