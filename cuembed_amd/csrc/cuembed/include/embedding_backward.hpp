@@ -335,7 +335,8 @@ void EmbeddingBackward(const GradT* grad_y,
  * flush: identical on exactly representable data, closer to the true sum otherwise.)  A rounding chain cannot be cut
  * into partial sums, so one run is ONE chain of dependent additions (the hottest row of the C4 batch: 65,528 of them);
  * short runs are walked by one lane group each, runs of 256 lookups and more by a whole workgroup that gathers 64 rows at
- * a time into LDS and chains every element of the row on a thread of its own.  C4: ~8 x the default path's time in fp16.  skip_grad_init = true ADDS to what grad_embedding holds, like the
+ * a time into LDS and runs the chain out of it.  C4: 4.3 ms in fp16 (15 x the default path's 0.29 ms on the same data;
+ * 26.4 ms before the long-run path), 6.6 ms in fp32 (12 x).  skip_grad_init = true ADDS to what grad_embedding holds, like the
  * reference's loop on a buffer the caller did not zero.
  */
 template <typename GradT, typename IndexT>

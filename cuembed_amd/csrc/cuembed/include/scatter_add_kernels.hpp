@@ -654,22 +654,54 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
 //!   * runs of kReferenceLongRun lookups and more (at most one can START inside a workgroup's 64 lookups): the whole
 //!     workgroup walks it -- all of its threads gather the next kReferenceChunk rows of grad_y into LDS at once (one
 //!     memory round trip per chunk instead of one per 8 lookups; sample ids and weights one chunk further ahead), and
-//!     every element of the row gets a thread of its own that runs the chain out of LDS (convert, [multiply, round,] add,
-//!     round: ~25 cycles a lookup) while the next chunk is in flight.  C4, fp16: 26.4 -> ~2 ms.
+//!     the lanes of its first group run the chain out of LDS, each on its N elements (fp16: packed half arithmetic),
+//!     while the next chunk is in flight.  C4 (fp16 / fp32): 26.4 / 23.7 -> 4.3 / 6.6 ms; one run of 65,528 lookups costs
+//!     ~50 ns a lookup (was 295) -- tools/reference_sums_run_probe.py; what is left is per-chunk bookkeeping, not the
+//!     chain and not memory (the same time with every gather an L2 hit).
 //!   block = (lanes_per_row, groups); every group looks at kReferenceSpan consecutive lookups and walks the runs that
 //!   START there.
 constexpr int kReferenceSpan = 8;
 constexpr int kReferenceLongRun = 256;
 constexpr int kReferenceChunk = 64;          //!< rows per LDS buffer (two buffers); fewer for rows beyond 512 bytes
-constexpr int kReferenceMaxChains = 4;       //!< row elements per thread in the long-run path
 
 //! LDS rows per buffer for the long-run path, 0 = no long-run path for this shape (the launcher's and the kernel's rule).
 inline int ReferenceChunkRows(const size_t row_bytes, const int block_threads, const int groups, const int width) {
-  if (block_threads != 256 || width > kReferenceMaxChains * block_threads) return 0;
+  (void)width;
+  if (block_threads != 256) return 0;
   int rows = kReferenceChunk;
   while (rows > groups && 2 * static_cast<size_t>(rows) * row_bytes > (size_t{48} << 10)) rows /= 2;
   if (rows < groups || rows % groups != 0 || 2 * static_cast<size_t>(rows) * row_bytes > (size_t{48} << 10)) return 0;
   return rows / groups <= 8 ? rows : 0;
+}
+
+//! One step of the reference's rounding chain on the N elements of a lane: acc = GradT(acc + GradT(x * w)), every
+//! operation rounded to GradT (embedding_lookup_cpu.hpp:139-142).  fp16 runs on packed half arithmetic (v_pk_mul_f16 /
+//! v_pk_add_f16: one IEEE operation per element, the same bits as the float-and-round form -- a sum or product of two
+//! binary16 values rounded through binary32 cannot round differently, 24 >= 2 x 11 + 2 -- at a fifth of the instructions;
+//! never contracted into an FMA, which would skip the product's rounding).
+template <typename GradT, int N, bool kWeighted>
+__device__ __forceinline__ void ReferenceChainStep(Pack<GradT, N>& acc, const Pack<GradT, N>& x, const GradT w) {
+  if constexpr (std::is_same<GradT, _Float16>::value && N % 2 == 0) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    half2_t* a2 = reinterpret_cast<half2_t*>(&acc);
+    const half2_t* x2 = reinterpret_cast<const half2_t*>(&x);
+    const half2_t w2 = {w, w};
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+#pragma clang fp contract(off)
+      half2_t v = x2[i];
+      if constexpr (kWeighted) v = v * w2;
+      a2[i] = a2[i] + v;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+#pragma clang fp contract(off)
+      float v = static_cast<float>(x.v[e]);
+      if constexpr (kWeighted) v = static_cast<float>(static_cast<GradT>(v * static_cast<float>(w)));   // product in GradT
+      acc.v[e] = static_cast<GradT>(static_cast<float>(acc.v[e]) + v);                                  // sum in GradT
+    }
+  }
 }
 
 template <typename GradT, typename IndexT, int N, bool kWeighted>
@@ -760,41 +792,50 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   const int per = chunk_rows / groups;                         // rows of a chunk that one lane group gathers (<= 8)
   GradT* stage = reinterpret_cast<GradT*>(reference_lds);      // [2][chunk_rows][width]
   GradT* stage_w = stage + 2 * static_cast<size_t>(chunk_rows) * width;   // [2][chunk_rows]
-  float acc[kReferenceMaxChains];
+  // The chain is run by the lanes of group 0, each on the N elements it also gathers (N independent chains per lane, one
+  // 16-byte LDS read per lookup and lane).  (One THREAD per element -- four wavefronts reading 2 bytes per lookup each --
+  // measured the same 47-50 ns per lookup.)
+  const bool chains = threadIdx.y == 0;
+  GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
+  Pack<GradT, N> sum;                        // the chain's state lives in GradT: it is rounded to it at every step anyway
 #pragma unroll
-  for (int c = 0; c < kReferenceMaxChains; ++c) {
-    const int e = tid + c * threads;
-    acc[c] = (add_to_output && e < width) ? static_cast<float>(grad_out[static_cast<int64_t>(row) * width + e]) : 0.f;
-  }
+  for (int e = 0; e < N; ++e) sum.v[e] = static_cast<GradT>(0);
+  if (chains && add_to_output) sum = *reinterpret_cast<const Pack<GradT, N>*>(dst);
   // what a lane group knows about ITS rows of a chunk: sample id, weight, "still in the run" -- for the chunk whose rows
   // are being gathered (`now`) and for the one after it (`next`: its ids are requested a whole chunk ahead, so that a
   // gather never waits for them)
   struct Lookups {
+    IndexT rid[8];      //!< the row id found at the slot's position (compared with the run's row when the chunk is parked)
     IndexT sid[8];
     GradT w[8];
-    bool ok[8];
   };
   Lookups now, next;
+  // Eight UNCONDITIONAL loads per array at clamped positions, nothing decided here: a load under a runtime condition, or a
+  // comparison of a loaded row id kept as a lane mask, becomes a full wait behind every single load (eight dependent
+  // round trips per chunk instead of one: 3.8 us per 64 lookups).  Slots beyond `per` repeat slot 0's position.
   auto look_up = [&](Lookups& l, const int64_t first) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int64_t at = first + threadIdx.y + static_cast<int64_t>(k) * groups;
-      l.ok[k] = k < per && at < nnz && rows[at] == row;
-      l.sid[k] = l.ok[k] ? sample_ids[at] : IndexT(0);
-      if constexpr (kWeighted) l.w[k] = l.ok[k] ? weights[at] : static_cast<GradT>(0);
+      const int64_t at = first + threadIdx.y + static_cast<int64_t>(k < per ? k : 0) * groups;
+      const int64_t safe = at < nnz ? at : nnz - 1;
+      l.rid[k] = rows[safe];
+      l.sid[k] = sample_ids[safe];
+      if constexpr (kWeighted) l.w[k] = weights[safe];
     }
   };
   raw_t held[8];
-  auto gather = [&](const Lookups& l) {
-#pragma unroll
+  auto gather = [&](const Lookups& l) {      // (every slot loads -- a row of the run or, past its end, whatever row the
+#pragma unroll                               //  clamped position names: a valid sample id either way)
     for (int k = 0; k < 8; ++k)
-      if (l.ok[k]) held[k] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(l.sid[k]), width));
+      held[k] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(l.sid[k]), width));
   };
-  auto park = [&](const Lookups& l, const int buffer) {       // registers -> LDS, and how many rows of the chunk are the run's
+  // registers -> LDS for the slots that still belong to the run, and how many of the chunk's rows those are
+  auto park = [&](const Lookups& l, const int64_t first, const int buffer) {
     int mine = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (l.ok[k]) {
+      const int64_t at = first + threadIdx.y + static_cast<int64_t>(k) * groups;
+      if (k < per && at < nnz && l.rid[k] == row) {
         const int slot = threadIdx.y + k * groups;
         *reinterpret_cast<raw_t*>(stage + (static_cast<size_t>(buffer) * chunk_rows + slot) * width + column0) = held[k];
         if constexpr (kWeighted)
@@ -809,7 +850,7 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   look_up(next, p + chunk_rows);
   int64_t q = p;                             // first lookup of the chunk in `held`
   for (int buffer = 0;; buffer ^= 1) {
-    park(now, buffer);                       // (waits for the gathers of this chunk)
+    park(now, q, buffer);                    // (waits for the gathers of this chunk)
     now = next;
     look_up(next, q + 2 * static_cast<int64_t>(chunk_rows));
     __syncthreads();
@@ -817,31 +858,33 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
     if (count == chunk_rows) gather(now);    // the next chunk's rows: in flight while this one is chained
     const GradT* rows_now = stage + static_cast<size_t>(buffer) * chunk_rows * width;
     const GradT* w_now = stage_w + buffer * chunk_rows;
+    if (chains) {
+      const GradT* mine = rows_now + column0;
+      constexpr int kBatch = 8;              // LDS reads requested together, then the dependent additions over them
+      int j = 0;
+      for (; j + kBatch <= count; j += kBatch) {
+        raw_t x[kBatch];
+        GradT wj[kBatch];
 #pragma unroll
-    for (int c = 0; c < kReferenceMaxChains; ++c) {
-      const int e = tid + c * threads;
-      if (e < width) {
-        float a = acc[c];
-#pragma unroll 8
-        for (int j = 0; j < count; ++j) {
-#pragma clang fp contract(off)
-          float x = static_cast<float>(rows_now[static_cast<size_t>(j) * width + e]);
-          if constexpr (kWeighted) x = static_cast<float>(static_cast<GradT>(x * static_cast<float>(w_now[j])));   // product in GradT
-          a = static_cast<float>(static_cast<GradT>(a + x));                                                       // sum in GradT
+        for (int u = 0; u < kBatch; ++u) {
+          x[u] = *reinterpret_cast<const raw_t*>(mine + static_cast<size_t>(j + u) * width);
+          wj[u] = kWeighted ? w_now[j + u] : static_cast<GradT>(0);
         }
-        acc[c] = a;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+          ReferenceChainStep<GradT, N, kWeighted>(sum, __builtin_bit_cast(Pack<GradT, N>, x[u]), wj[u]);
       }
+      for (; j < count; ++j)
+        ReferenceChainStep<GradT, N, kWeighted>(
+            sum, *reinterpret_cast<const Pack<GradT, N>*>(mine + static_cast<size_t>(j) * width),
+            kWeighted ? w_now[j] : static_cast<GradT>(0));
     }
     __syncthreads();                         // everybody is through with this buffer
     if (tid == 0) chunk_count[buffer] = 0;   // (next used two chunks on, with barriers in between)
     if (count < chunk_rows) break;           // the run ended inside this chunk
     q += chunk_rows;
   }
-#pragma unroll
-  for (int c = 0; c < kReferenceMaxChains; ++c) {
-    const int e = tid + c * threads;
-    if (e < width) grad_out[static_cast<int64_t>(row) * width + e] = static_cast<GradT>(acc[c]);
-  }
+  if (chains) *reinterpret_cast<Pack<GradT, N>*>(dst) = sum;
 }
 
 }  // namespace detail

@@ -221,3 +221,45 @@ def test_reference_sums_opt_in_is_bit_identical_on_arbitrary_data(ce, oracle, ki
             got2, _ = ce.embedding_backward(gy_d, rows, dev(ti), dev(ts), None, w_d, skip_grad_init=True,
                                             grad_embedding=dev(start), reference_sums=True)
             assert np.array_equal(got2.cpu().numpy().view(np.uint16), want2.view(np.uint16))
+
+
+@pytest.mark.parametrize("kind,W", [("f16", 256), ("f16", 64), ("f16", 512), ("f16", 1024), ("bf16", 256), ("f32", 128),
+                                    ("f32", 32), ("f16", 40)])
+@pytest.mark.parametrize("weighted", [False, True], ids=["unweighted", "weighted"])
+def test_reference_sums_long_runs_through_the_workgroup_path(ce, oracle, kind, W, weighted):
+    """Runs of 257 lookups and more are walked by the WHOLE workgroup (rows gathered 64 / 16 / 8 at a time into LDS, one
+    thread per element running the rounding chain): every run length around the long-run threshold and the chunk sizes
+    -- 255, 256, 257, 64 k + {0, 1, 63}, 3,000, 9,000 --, long runs back to back, at the start and at the very end of the
+    COO, short runs in between, compressed and full gradients, a pre-filled buffer: the oracle's bits.  (W = 40 has a row
+    split without that path: the same lengths through the one-group walk.)"""
+    rng = np.random.default_rng(77 + W)
+    lengths = [300, 1, 2, 255, 256, 257, 5, 64 * 5, 64 * 5 + 1, 64 * 6 - 1, 3, 3000, 1, 1, 9000, 7, 512, 513, 1, 700]
+    row_ids = np.cumsum(rng.integers(1, 4, len(lengths)))             # ascending, gaps between them
+    ti = np.repeat(row_ids, lengths).astype(np.int32)
+    nnz, B, ncat = ti.shape[0], 5000, int(row_ids[-1]) + 3
+    ts = rng.integers(0, B, nnz).astype(np.int32)
+    gy32 = rng.uniform(-1.0, 1.0, (B, W)).astype(np.float32)
+    tw32 = rng.uniform(0.0, 1.0, nnz).astype(np.float32)
+    if kind == "f32":
+        gy_o, gy_d = gy32, dev(gy32)
+        w_o, w_d = (tw32, dev(tw32)) if weighted else (None, None)
+    else:
+        gy_o, gy_d, _ = _to_elem(oracle, gy32, kind)
+        w_o, w_d = (None, None)
+        if weighted:
+            w_o, w_d, _ = _to_elem(oracle, tw32, kind)
+    for compressed in (False, True):
+        remap = oracle.compute_compressed_grad_indices(ti) if compressed else None
+        rows = int(remap[-1]) + 1 if compressed else ncat
+        want, want_inv = oracle.embedding_backward(gy_o, W, rows, ti, ts, remap, w_o)
+        got, inv = ce.embedding_backward(gy_d, rows, dev(ti), dev(ts), dev(remap), w_d, reference_sums=True)
+        got_h = got.cpu().numpy() if kind == "f32" else _host(got, kind)
+        assert np.array_equal(got_h.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)), (kind, W, compressed)
+        if compressed:
+            assert np.array_equal(inv.cpu().numpy(), want_inv)
+    if kind == "f16":       # a pre-filled buffer: the chain starts from what is there
+        start = rng.uniform(-1, 1, (ncat, W)).astype(np.float16)
+        want2, _ = oracle.embedding_backward(gy_o, W, ncat, ti, ts, None, w_o, skip_grad_init=True, grad_embedding=start.copy())
+        got2, _ = ce.embedding_backward(gy_d, ncat, dev(ti), dev(ts), None, w_d, skip_grad_init=True,
+                                        grad_embedding=dev(start), reference_sums=True)
+        assert np.array_equal(got2.cpu().numpy().view(np.uint16), want2.view(np.uint16))
