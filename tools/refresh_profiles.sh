@@ -7,97 +7,99 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2> "$O/bench.err"     # the driver's protocol
+timeout 900 python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2> "$O/bench.err"     # the driver's protocol
 C2="--num_categories 10000000 --embed_width 256 --batch_size 65536 --alpha 1.15 --hotness 64 --half_embedding_type=true"
 C3="--num_categories 10000000 --embed_width 128 --batch_size 65536 --alpha 1.15 --hotness 128 --csr_input=true --weighted_sum=true"
 {
   for ex in "" "--bounded_sort" "--bounded_sort --fused_row_ids" "--bounded_sort --fused_row_ids --sample_blocks 0" "--bounded_sort --fused_row_ids --sample_blocks 0 --coalesce_blocks" "--use_int64_indices" "--use_int64_indices --bounded_sort --fused_row_ids"; do
-    echo "== C2/C4 $ex"; benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
+    echo "== C2/C4 $ex"; timeout 300 benchmarks/manual_benchmark $C2 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
   for ex in "" "--bag_order --forward_only" "--bounded_sort" "--bounded_sort --sample_blocks 0"; do
-    echo "== C3 $ex"; benchmarks/manual_benchmark $C3 --iterations 30 $ex 2>&1 | grep -E "Iterations"
+    echo "== C3 $ex"; timeout 300 benchmarks/manual_benchmark $C3 --iterations 30 $ex 2>&1 | grep -E "Iterations"
   done
 } > "$O/manual_benchmark_c2_c3.txt"
-python tools/secondary_kernels.py > "$O/secondary_kernels.txt" 2>&1
-python benchmarks/train_step_benchmark.py --exchange none > "$O/train_step_none.json" 2> "$O/train_step.err"
-python benchmarks/train_step_benchmark.py --exchange none --order reference >> "$O/train_step_none.json" 2>> "$O/train_step.err"
-python benchmarks/train_step_benchmark.py --exchange none --order blocked >> "$O/train_step_none.json" 2>> "$O/train_step.err"
-python benchmarks/train_step_benchmark.py --exchange none --reference_api >> "$O/train_step_none.json" 2>> "$O/train_step.err"
-python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_native_binding.jsonl" 2> "$O/torch_probe.err"
-python tools/torch_sparse_orders_probe.py > "$O/torch_sparse_orders_probe.json" 2>> "$O/torch_probe.err"
-python tools/bwd_blocked_coalesced_probe.py 2 3 4 > "$O/bwd_blocked_coalesced_probe.json" 2>> "$O/torch_probe.err"
-python tools/c3_balance_probe.py > "$O/c3_balance_probe.json" 2>> "$O/torch_probe.err"
-CUEMBED_PYT_BACKEND=python python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_python_ctypes_ops.jsonl" 2>> "$O/torch_probe.err"
-python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
-python tools/torch_step_profile.py > "$O/torch_step_profile_b1024.txt" 2>&1
-python tools/torch_policy_probe.py > "$O/torch_policy_probe.json" 2>> "$O/torch_probe.err"
-python tools/torch_graph_step_probe.py > "$O/torch_graph_step_probe.json" 2>> "$O/torch_probe.err"
+timeout 900 python tools/secondary_kernels.py > "$O/secondary_kernels.txt" 2>&1
+timeout 900 python benchmarks/train_step_benchmark.py --exchange none > "$O/train_step_none.json" 2> "$O/train_step.err"
+timeout 900 python benchmarks/train_step_benchmark.py --exchange none --order reference >> "$O/train_step_none.json" 2>> "$O/train_step.err"
+timeout 900 python benchmarks/train_step_benchmark.py --exchange none --order blocked >> "$O/train_step_none.json" 2>> "$O/train_step.err"
+timeout 900 python benchmarks/train_step_benchmark.py --exchange none --reference_api >> "$O/train_step_none.json" 2>> "$O/train_step.err"
+timeout 900 python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_native_binding.jsonl" 2> "$O/torch_probe.err"
+timeout 900 python tools/torch_sparse_orders_probe.py > "$O/torch_sparse_orders_probe.json" 2>> "$O/torch_probe.err"
+timeout 900 python tools/bwd_blocked_coalesced_probe.py 2 3 4 > "$O/bwd_blocked_coalesced_probe.json" 2>> "$O/torch_probe.err"
+timeout 900 python tools/c3_balance_probe.py > "$O/c3_balance_probe.json" 2>> "$O/torch_probe.err"
+CUEMBED_PYT_BACKEND=python timeout 900 python tools/torch_op_step_probe.py > "$O/torch_op_step_probe_python_ctypes_ops.jsonl" 2>> "$O/torch_probe.err"
+timeout 900 python tools/host_table_probe.py > "$O/host_table_probe.json" 2> "$O/host_table_probe.err"
+timeout 900 python tools/torch_step_profile.py > "$O/torch_step_profile_b1024.txt" 2>&1
+timeout 900 python tools/torch_policy_probe.py > "$O/torch_policy_probe.json" 2>> "$O/torch_probe.err"
+timeout 900 python tools/torch_graph_step_probe.py > "$O/torch_graph_step_probe.json" 2>> "$O/torch_probe.err"
 # index work of the sweep grid's small and mid-size shapes: reference call sequence and the one-call form
-SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1 32768:16" bash tools/small_sort_trace.sh refresh_ref > /dev/null 2>&1
-EXTRA="--fused_row_ids --fused_remap" SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1" bash tools/small_sort_trace.sh refresh_one_call > /dev/null 2>&1
+SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1 32768:16" timeout 900 bash tools/small_sort_trace.sh refresh_ref > /dev/null 2>&1
+EXTRA="--fused_row_ids --fused_remap" SHAPES="1024:1 1024:4 1024:16 1024:64 32768:1 131072:1" timeout 900 bash tools/small_sort_trace.sh refresh_one_call > /dev/null 2>&1
 cp "$R/gpurun_out/small_sort_refresh_ref.txt" "$O/small_sort_reference_sequence.txt"
 cp "$R/gpurun_out/small_sort_refresh_one_call.txt" "$O/small_sort_one_call.txt"
 # loads-only ceilings: random rows of every width, and the headline's own access pattern
-tools/row_read_ceiling > "$O/row_read_ceiling.csv" 2> "$O/row_read_ceiling.err"
-tools/row_read_ceiling --c2 1.15 > "$O/headline_pattern_loads_only_ceiling.csv" 2>> "$O/row_read_ceiling.err"
-tools/row_read_ceiling --c2 0 >> "$O/headline_pattern_loads_only_ceiling.csv" 2>> "$O/row_read_ceiling.err"
-tools/row_read_ceiling --c2-parts 1.15 > "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
-tools/row_read_ceiling --c2-parts 0 >> "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
-python tools/narrow_row_probe.py > "$O/narrow_row_probe.jsonl" 2>> "$O/row_read_ceiling.err"
-python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
+timeout 600 tools/row_read_ceiling > "$O/row_read_ceiling.csv" 2> "$O/row_read_ceiling.err"
+timeout 600 tools/row_read_ceiling --c2 1.15 > "$O/headline_pattern_loads_only_ceiling.csv" 2>> "$O/row_read_ceiling.err"
+timeout 600 tools/row_read_ceiling --c2 0 >> "$O/headline_pattern_loads_only_ceiling.csv" 2>> "$O/row_read_ceiling.err"
+timeout 600 tools/row_read_ceiling --c2-parts 1.15 > "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
+timeout 600 tools/row_read_ceiling --c2-parts 0 >> "$O/forward_parts_probe.csv" 2>> "$O/row_read_ceiling.err"
+timeout 900 python tools/narrow_row_probe.py > "$O/narrow_row_probe.jsonl" 2>> "$O/row_read_ceiling.err"
+timeout 1500 python benchmarks/sweep_parameters.py --iterations 30 --csv "$O/sweep_parameters_fwd_transpose_bwd.csv" > "$O/sweep.log" 2>&1
 # the same grid through the C++ benchmark binary (host launch cost of a C++ program, like the reference's sweep): mean / min /
 # median over 3 independent processes per point and every kernel's share of the step
-python benchmarks/sweep_parameters.py --binary --repetitions 3 --iterations 30 --csv "$O/sweep_parameters_cpp_binary.csv" > "$O/sweep_binary.log" 2>&1
-python tools/high_word_timing.py > "$O/high_word_timing.jsonl" 2>> "$O/torch_probe.err"
-CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 python tools/high_word_timing.py >> "$O/high_word_timing.jsonl" 2>> "$O/torch_probe.err"
-python tools/high_word_stress.py 120 > "$O/high_word_stress.json" 2>> "$O/torch_probe.err"
-python tools/row_loads_crossover_probe.py > "$O/row_loads_crossover.jsonl" 2>> "$O/torch_probe.err"
+timeout 2400 python benchmarks/sweep_parameters.py --binary --repetitions 3 --iterations 30 --csv "$O/sweep_parameters_cpp_binary.csv" > "$O/sweep_binary.log" 2>&1
+timeout 900 python tools/high_word_timing.py > "$O/high_word_timing.jsonl" 2>> "$O/torch_probe.err"
+CUEMBED_SORT_HIGH_WORD_LAUNCHES=1 timeout 900 python tools/high_word_timing.py >> "$O/high_word_timing.jsonl" 2>> "$O/torch_probe.err"
+timeout 900 python tools/high_word_stress.py 120 > "$O/high_word_stress.json" 2>> "$O/torch_probe.err"
+timeout 900 python tools/row_loads_crossover_probe.py > "$O/row_loads_crossover.jsonl" 2>> "$O/torch_probe.err"
+timeout 600 python tools/reference_sums_run_probe.py > "$O/reference_sums_run_probe.txt" 2>> "$O/torch_probe.err"
+timeout 600 python tools/reference_sums_timing.py >> "$O/reference_sums_run_probe.txt" 2>> "$O/torch_probe.err"
 # profiler passes last (they clock lower); the program goes directly after `--`
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-c5 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pipeline" -- "$R/benchmarks/manual_benchmark" $C2 --iterations 10 --clear_caches=false > "$O/prof_pipeline.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-c5 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pipeline" -- "$R/benchmarks/manual_benchmark" $C2 --iterations 10 --clear_caches=false > "$O/prof_pipeline.log" 2>&1
 cd "$R"
-python tools/rocprof_summary.py "$O/prof_bench" > "$O/bench_c2_kernel_trace_stats.txt" 2>/dev/null
-python tools/rocprof_summary.py "$O/prof_pipeline" > "$O/pipeline_c2_kernel_trace_stats.txt" 2>/dev/null
+timeout 900 python tools/rocprof_summary.py "$O/prof_bench" > "$O/bench_c2_kernel_trace_stats.txt" 2>/dev/null
+timeout 900 python tools/rocprof_summary.py "$O/prof_pipeline" > "$O/pipeline_c2_kernel_trace_stats.txt" 2>/dev/null
 rm -rf "$O/prof_bench" "$O/prof_pipeline"   # raw traces are large; the summaries stay
 # ---- counter passes (each counter set in its OWN run, never with another trace domain) -> traffic json
 cd /tmp
 N=8
 PF="python3 $R/tools/profile_forward.py --pattern all --iters $N"
 PP="$R/benchmarks/manual_benchmark $C2 --iterations 6 --clear_caches=false"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fwd_fetch" -- $PF > "$O/pmc_fwd.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_fwd_write" -- $PF >> "$O/pmc_fwd.log" 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_fwd_tcc" -- $PF >> "$O/pmc_fwd.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_pipe_fetch" -- $PP > "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_pipe_write" -- $PP >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_pipe_tcc" -- $PP >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fwd_fetch" -- $PF > "$O/pmc_fwd.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_fwd_write" -- $PF >> "$O/pmc_fwd.log" 2>&1
+timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_fwd_tcc" -- $PF >> "$O/pmc_fwd.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_pipe_fetch" -- $PP > "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_pipe_write" -- $PP >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_pipe_tcc" -- $PP >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$O/pmc_pipe_trace" -- $PP >> "$O/pmc_pipe.log" 2>&1
 # the same pipeline transposed in sample blocks (extension): the backward's traffic on the blocked order
 PB="$PP --bounded_sort --fused_row_ids --sample_blocks 0"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_blocks_fetch" -- $PB >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_blocks_write" -- $PB >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_blocks_tcc" -- $PB >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_blocks_fetch" -- $PB >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_blocks_write" -- $PB >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_blocks_tcc" -- $PB >> "$O/pmc_pipe.log" 2>&1
 # ... and with the reference's compressed gradient computed from that order (one scatter launch per block)
 PC2="$PB --coalesce_blocks"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_coal_fetch" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_coal_write" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_coal_tcc" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_coal_fetch" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_coal_write" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
+timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_coal_tcc" -- $PC2 >> "$O/pmc_pipe.log" 2>&1
 cd "$R"
 # C3 (fp32 weighted CSR forward): bench.py itself is the profiled program -- every GatherReduceKernel dispatch is a C3 launch
 cd /tmp
 PC="python3 $R/bench.py --workload c3 --steps 10 --warmup 0 --no-extras --no-c5 --no-cpu-baseline"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_c3_fetch" -- $PC > "$O/pmc_c3.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_c3_write" -- $PC >> "$O/pmc_c3.log" 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_c3_tcc" -- $PC >> "$O/pmc_c3.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_c3_fetch" -- $PC > "$O/pmc_c3.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_c3_write" -- $PC >> "$O/pmc_c3.log" 2>&1
+timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_c3_tcc" -- $PC >> "$O/pmc_c3.log" 2>&1
 cd "$R"
 : > "$O/traffic_rows.txt"
-python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
+timeout 900 python tools/traffic_from_pmc.py --iters $N --forward-fetch "$O/pmc_fwd_fetch" --forward-write "$O/pmc_fwd_write" \
   --forward-tcc "$O/pmc_fwd_tcc" --pipeline-fetch "$O/pmc_pipe_fetch" --pipeline-write "$O/pmc_pipe_write" \
   --pipeline-tcc "$O/pmc_pipe_tcc" --pipeline-trace "$O/pmc_pipe_trace" \
   --blocks-fetch "$O/pmc_blocks_fetch" --blocks-write "$O/pmc_blocks_write" --blocks-tcc "$O/pmc_blocks_tcc" \
   --coalesced-fetch "$O/pmc_coal_fetch" --coalesced-write "$O/pmc_coal_write" --coalesced-tcc "$O/pmc_coal_tcc" \
   --out "$O/traffic_c2.json" --rows-out "$O/traffic_rows.txt" > /dev/null
-python tools/traffic_from_pmc.py --c3-fetch "$O/pmc_c3_fetch" --c3-write "$O/pmc_c3_write" --c3-tcc "$O/pmc_c3_tcc" \
+timeout 900 python tools/traffic_from_pmc.py --c3-fetch "$O/pmc_c3_fetch" --c3-write "$O/pmc_c3_write" --c3-tcc "$O/pmc_c3_tcc" \
   --workload "c3 (fp32 weighted sum, CSR bags U[0,128], 10Mx128, batch 65536)" \
   --out "$O/traffic_c3.json" --rows-out "$O/traffic_rows.txt" > /dev/null
 {
@@ -107,12 +109,12 @@ python tools/traffic_from_pmc.py --c3-fetch "$O/pmc_c3_fetch" --c3-write "$O/pmc
 } > "$O/pmc_passes.txt"
 rm -rf "$O"/pmc_fwd_* "$O"/pmc_pipe_* "$O"/pmc_blocks_* "$O"/pmc_coal_* "$O"/pmc_c3_fetch "$O"/pmc_c3_write "$O"/pmc_c3_tcc
 # SQ issue / wait counters of the same pipeline (two passes of 8 counters)
-bash tools/pmc_sq_pass.sh > /dev/null 2>&1 && cp "$R/gpurun_out/pmc_sq.txt" "$O/pmc_sq_pipeline.txt"
+timeout 1200 bash tools/pmc_sq_pass.sh > /dev/null 2>&1 && cp "$R/gpurun_out/pmc_sq.txt" "$O/pmc_sq_pipeline.txt"
 # the bench line again, now with roofline.traffic from the traffic file measured above
 cp "$O/traffic_c2.json" "$R/profiles/traffic_c2.json"
 cp "$O/traffic_c3.json" "$R/profiles/traffic_c3.json"
-python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2>> "$O/bench.err"
-python bench.py --steps 200 --warmup 20 > "$O/bench_c2_line_200_steps.json" 2>> "$O/bench.err"
-python bench.py --gpus 2 --steps 20 --warmup 5 > "$O/bench_c2_two_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
-python bench.py --gpus 8 --steps 20 --warmup 5 > "$O/bench_c2_eight_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
+timeout 900 python bench.py --steps 20 --warmup 5 > "$O/bench_c2_line.json" 2>> "$O/bench.err"
+timeout 900 python bench.py --steps 200 --warmup 20 > "$O/bench_c2_line_200_steps.json" 2>> "$O/bench.err"
+timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 > "$O/bench_c2_two_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
+timeout 1500 python bench.py --gpus 8 --steps 20 --warmup 5 > "$O/bench_c2_eight_ranks_sharing_one_gpu.json" 2>> "$O/bench.err"
 ls -la "$O"
