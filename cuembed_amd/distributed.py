@@ -360,7 +360,9 @@ class SparseGradExchange:
 
     pair_capacity : rows one rank may send to one owner per step (a slot of the all-to-all);
     piece_capacity: distinct rows one owner may hold after merging (a piece of the all-gather);
-    local_capacity: distinct rows of this rank's own gradient after its local merge (coalesced=False only).
+    local_capacity: distinct rows of this rank's own gradient after its local merge (coalesced=False only);
+    input_capacity: rows of the caller's buffers that are looked at when a device-side `count` is given (the valid rows
+                    are a prefix; buffers sized for the worst case are cut there).
     Sized by hand or by calibrate() from a warm-up step.  A step that does not fit raises the sticky overflow word on
     EVERY rank (it travels with the all-gather) and delivers a well-formed but incomplete gradient: look at
     overflowed() whenever a host wait is affordable (every few hundred steps, or at the step where the loss is read
@@ -376,7 +378,7 @@ class SparseGradExchange:
     """
 
     def __init__(self, num_categories, width, dtype, device, pair_capacity, piece_capacity, local_capacity=0,
-                 group=None):
+                 group=None, input_capacity=0):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
@@ -384,6 +386,9 @@ class SparseGradExchange:
         self.num_categories, self.width, self.dtype, self.device = int(num_categories), int(width), dtype, device
         self.pair_capacity, self.piece_capacity = int(pair_capacity), int(piece_capacity)
         self.local_capacity = int(local_capacity)
+        # rows of the caller's (worst-case sized) buffers that are looked at: the valid rows are a prefix, and sorting
+        # and merging millions of rows past the count would cost more than the exchange (0 = all of them)
+        self.input_capacity = int(input_capacity)
         if self.pair_capacity < 1 or self.piece_capacity < 1:
             raise ValueError("capacities must be at least one row")
         bounds = owner_bounds(self.num_categories, self.world)
@@ -407,6 +412,7 @@ class SparseGradExchange:
         self._out = [(torch.zeros((w * (p + 2),), dtype=torch.int64, device=device),
                       torch.zeros((w * p, self.width), dtype=dtype, device=device)) for _ in range(2)]
         self._turn = 0
+        self._pending = None           # the last step's result while its all-gather may still read the piece buffers
         self._overflow = torch.zeros((1,), dtype=torch.int64, device=device)      # sticky, all ranks' words OR-ed
 
     # -- sizes ----------------------------------------------------------------------------------------------------
@@ -430,15 +436,15 @@ class SparseGradExchange:
         merged = torch.unique(torch.cat(_all_gather_ragged_ids(ids, group)))      # the owners' merged rows, all ranges
         got = torch.searchsorted(merged, cuts)
         piece = int((got[1:] - got[:-1]).max().item()) if merged.numel() else 0
-        need = torch.tensor([pair, piece, local], dtype=torch.int64,
+        need = torch.tensor([pair, piece, local, k], dtype=torch.int64,
                             device=rows.device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
-        pair, piece, local = (int(x) for x in need.tolist())
+        pair, piece, local, given = (int(x) for x in need.tolist())
 
         def grow(n):
             return max(int(n * headroom) + 16, 16)
         return cls(num_categories, rows.shape[1], rows.dtype, rows.device, grow(pair), grow(piece),
-                   0 if coalesced else grow(local), group=group)
+                   0 if coalesced else grow(local), group=group, input_capacity=grow(given))
 
     def overflowed(self, reset=False):
         """True when a step since the last reset did not fit the capacities on SOME rank (one host read-back)."""
@@ -459,9 +465,17 @@ class SparseGradExchange:
         returns a SparseGradResult.  Nothing in here waits for the device."""
         import torch.distributed as dist
         dev, w, s, p = self.device, self.world, self.pair_capacity, self.piece_capacity
+        if self._pending is not None:
+            # the previous step's all-gather reads the piece buffers this step is about to rewrite: order behind it
+            # (a stream-side wait; a caller that already waited pays nothing)
+            self._pending.wait()
+            self._pending = None
+        flag = torch.zeros((1,), dtype=torch.int64, device=dev)
+        if self.input_capacity and count is not None and inverse_mapping.numel() > self.input_capacity:
+            flag = flag | (count.reshape(1).to(dev) > self.input_capacity).to(torch.int64)
+            inverse_mapping, rows = inverse_mapping[: self.input_capacity], rows[: self.input_capacity]
         ids = inverse_mapping if inverse_mapping.dtype == torch.int64 else inverse_mapping.to(torch.int64)
         n = ids.numel()
-        flag = torch.zeros((1,), dtype=torch.int64, device=dev)
         if n and count is not None:      # rows past the count hold nothing: give them the padding id
             ids = torch.where(torch.arange(n, device=dev) < count.reshape(1).to(dev), ids,
                               torch.full_like(ids, self.num_categories))
@@ -505,6 +519,8 @@ class SparseGradExchange:
         result = SparseGradResult([x for x in works if x is not None], out_tail, out_rows, p, w)
         if not async_op:
             self.note_flags(result)
+        else:
+            self._pending = result
         return result
 
     def note_flags(self, result):

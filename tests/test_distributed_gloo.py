@@ -143,6 +143,18 @@ def _worker(rank, world, port, csr, ret):
             got_ids, got_rows = ex.compact(ids_all, rows_all, counts)
             assert torch.equal(got_ids, want_ids) and torch.equal(got_rows, want_rows), ("fixed compact", step)
         assert not ex.overflowed()
+        # ... buffers sized for the worst case (four times the rows, garbage behind the count): only input_capacity rows
+        # are looked at; a count beyond it raises the flag
+        big_rows = np.concatenate([comp, np.full((3 * comp.shape[0] + 40, W), 555.0, dtype=comp.dtype)])
+        big_inv = np.concatenate([inv, np.full((3 * inv.shape[0] + 40,), 1, dtype=inv.dtype)])
+        assert big_inv.shape[0] > ex.input_capacity >= nu
+        with _no_host_reads():
+            pending = ex.start(torch.from_numpy(big_rows), torch.from_numpy(big_inv), count=torch.tensor([nu]), async_op=False)
+        got_ids, got_rows = ex.compact(*pending.wait())
+        assert torch.equal(got_ids, want_ids) and torch.equal(got_rows, want_rows) and not ex.overflowed()
+        pending = ex.start(torch.from_numpy(big_rows), torch.from_numpy(big_inv), count=torch.tensor([ex.input_capacity + 1]),
+                           async_op=False)
+        assert ex.overflowed(reset=True)
         # ... an uncoalesced gradient: the rank's own rows are merged first, inside the same step
         ex_u = D.SparseGradExchange.calibrate(torch.from_numpy(u_rows), torch.from_numpy(u_ids), ncat, coalesced=False)
         with _no_host_reads():

@@ -32,7 +32,7 @@ cp $S/torch_graph_step_probe.json profiles/${R}_torch_graph_step_probe.json
 cp $S/forward_parts_probe.csv profiles/${R}_forward_parts_probe.csv
 cp $S/traffic_c2.json profiles/traffic_c2.json
 cp $S/traffic_c3.json profiles/traffic_c3.json
-for f in high_word_timing.jsonl high_word_stress.json row_loads_crossover.jsonl reference_sums_run_probe.txt; do
+for f in high_word_timing.jsonl high_word_stress.json row_loads_crossover.jsonl reference_sums_run_probe.txt exchange_device_time.json; do
   [ -f $S/$f ] && cp $S/$f profiles/${R}_$f
 done
 [ -f $S/sweep_parameters_cpp_binary.csv ] && cp $S/sweep_parameters_cpp_binary.csv profiles/${R}_sweep_parameters_cpp_binary_min_median_share.csv

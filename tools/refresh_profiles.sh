@@ -54,6 +54,7 @@ timeout 900 python tools/high_word_stress.py 120 > "$O/high_word_stress.json" 2>
 timeout 900 python tools/row_loads_crossover_probe.py > "$O/row_loads_crossover.jsonl" 2>> "$O/torch_probe.err"
 timeout 600 python tools/reference_sums_run_probe.py > "$O/reference_sums_run_probe.txt" 2>> "$O/torch_probe.err"
 timeout 600 python tools/reference_sums_timing.py >> "$O/reference_sums_run_probe.txt" 2>> "$O/torch_probe.err"
+timeout 600 python tools/exchange_device_time.py > "$O/exchange_device_time.json" 2>> "$O/torch_probe.err"
 # profiler passes last (they clock lower); the program goes directly after `--`
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-c5 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
