@@ -12,6 +12,8 @@ instead, i.e. only what the reference's API offers), ComputeCompressedGradIndice
 into a compressed gradient, then the exchange:
   sparse : all-gather of the compressed rows + local merge (~293 MB per rank at this shape)
   dense  : scatter into the dense table gradient + RCCL all-reduce (5.12 GB per rank)
+  sparse_fixed: the same sum through SparseGradExchange -- capacities fixed by one warm-up step, then no host read-back
+           per step and the all-gather of step i in flight behind the compute of step i + 1
   none   : no exchange (upper bound / single GPU)
 Rank 0 prints one JSON line with the step time (max over ranks) and its breakdown."""
 import argparse
@@ -33,7 +35,10 @@ def main():
     p.add_argument("--batch", type=int, default=65536, help="samples per GPU")
     p.add_argument("--hotness", type=int, default=64)
     p.add_argument("--alpha", type=float, default=1.15)
-    p.add_argument("--exchange", default="sparse", choices=["sparse", "dense", "none"])
+    p.add_argument("--exchange", default="sparse", choices=["sparse", "sparse_fixed", "dense", "none"],
+                   help="sparse = exact sizes (host read-backs per step); sparse_fixed = SparseGradExchange: capacities "
+                        "from one warm-up step, no host read-back per step, the all-gather of step i behind the compute "
+                        "of step i + 1")
     p.add_argument("--sparse_algorithm", default="auto", choices=["auto", "allgather", "owner"])
     p.add_argument("--order", default="blocked_uncoalesced", choices=["reference", "blocked", "blocked_uncoalesced"],
                    help="order of the transposed COO (benchmarks/c5_train_step.py): reference = fully sorted; blocked = "
@@ -84,6 +89,10 @@ def main():
             ts.count = ts.remap[-1:] + 1
         ts.index_work = reference_index_work
     names = ["forward", "transpose", "backward", "exchange"]
+    plan, state = None, {"pending": None}
+    if use_dist and a.exchange == "sparse_fixed":
+        ts.compute()
+        plan = ts.calibrate_exchange(D)                 # (the warm-up step that may look at sizes)
 
     def step(ev):
         ev[0].record()
@@ -93,7 +102,12 @@ def main():
         ev[2].record()
         ts.backward()
         ev[3].record()
-        if use_dist and a.exchange != "none":
+        if plan is not None:
+            if state["pending"] is not None:            # the previous step's gradient has arrived (stream-side wait)
+                state["pending"].wait()
+                plan.note_flags(state["pending"])
+            state["pending"] = ts.exchange_fixed(D, plan)
+        elif use_dist and a.exchange != "none":
             ts.exchange(D, algorithm=a.sparse_algorithm)
         ev[4].record()
 
@@ -109,6 +123,9 @@ def main():
     t0 = time.perf_counter()
     for s in range(a.steps):
         step(events[s])
+    if state["pending"] is not None:
+        state["pending"].wait()
+        plan.note_flags(state["pending"])
     sync()
     wall = time.perf_counter() - t0
     parts = {n: sum(e[i].elapsed_time(e[i + 1]) for e in events) / a.steps for i, n in enumerate(names)}
@@ -124,7 +141,8 @@ def main():
                           "ranks_share_gpus": world > ngpu,
                           "n_gpus": world, "ms_per_step": round(ms, 4),
                           "samples_per_s": round(world * B / (ms * 1e-3)),
-                          "breakdown_ms": {k: round(v, 4) for k, v in parts.items()}}), flush=True)
+                          "breakdown_ms": {k: round(v, 4) for k, v in parts.items()},
+                          "fixed_capacity_overflowed": None if plan is None else plan.overflowed()}), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -651,7 +651,8 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
 //! cut into partial sums, hence one run = one chain whatever its length: the hottest row of the C4 batch is 65,528
 //! dependent additions.  What CAN be shared is everything around the chain:
 //!   * short runs: one lane group per run, 8 row gathers in flight;
-//!   * runs of kReferenceLongRun lookups and more (at most one can START inside a workgroup's 64 lookups): the whole
+//!   * runs longer than kReferenceLongRun lookups and than the workgroup's own span (so that at most one can START inside
+//!     a workgroup's lookups): the whole
 //!     workgroup walks it -- all of its threads gather the next kReferenceChunk rows of grad_y into LDS at once (one
 //!     memory round trip per chunk instead of one per 8 lookups; sample ids and weights one chunk further ahead), and
 //!     the lanes of its first group run the chain out of LDS, each on its N elements (fp16: packed half arithmetic),
@@ -719,6 +720,10 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   const int64_t column0 = static_cast<int64_t>(lane_x) * N;
   typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
   constexpr int K = 8;
+  // "long" = longer than the workgroup's own span of lookups (narrow rows: 64 and more groups of 8 lookups), so that at
+  // most ONE long run can start inside it
+  const int span = static_cast<int>(blockDim.y) * kReferenceSpan;
+  const int long_run = span > kReferenceLongRun ? span : kReferenceLongRun;
   if (chunk_rows > 0) {
     if (threadIdx.x == 0 && threadIdx.y == 0) {
       long_head = -1;
@@ -731,7 +736,7 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
     const IndexT row = rows[p];
     if (p > 0 && rows[p - 1] == row) continue;   // not the first lookup of its run
     if (run_ids != nullptr && lane_x == 0) inverse_mapping[row] = run_ids[p];
-    if (chunk_rows > 0 && p + kReferenceLongRun < nnz && rows[p + kReferenceLongRun] == row) {
+    if (chunk_rows > 0 && p + long_run < nnz && rows[p + long_run] == row) {
       if (lane_x == 0) long_head = p;            // (one per workgroup at most: the run outlasts the workgroup's span)
       continue;
     }

@@ -336,7 +336,9 @@ class SparseGradResult:
     """What SparseGradExchange.start() returns: wait() -> (ids[world * piece], rows[world * piece, W], counts[world]),
     identical on every rank.  Piece r (entries [r * piece, (r + 1) * piece)) is owner r's merged id range: `counts[r]`
     ascending distinct ids with their summed rows, then zero rows with valid ids.  The whole is a valid uncoalesced
-    COO gradient of the table (scatter-add it as it is); SparseGradExchange.compact() gives the exact rows."""
+    COO gradient of the table (scatter-add it as it is); SparseGradExchange.compact() gives the exact rows.
+    The tensors are views of the exchange's two result buffers, used in turn: they stay as they are until the start()
+    after the next one."""
 
     def __init__(self, works, ids, rows, piece, world):
         self._works, self._ids, self._rows, self._piece, self._world = works, ids, rows, piece, world

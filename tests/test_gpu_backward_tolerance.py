@@ -224,14 +224,16 @@ def test_reference_sums_opt_in_is_bit_identical_on_arbitrary_data(ce, oracle, ki
 
 
 @pytest.mark.parametrize("kind,W", [("f16", 256), ("f16", 64), ("f16", 512), ("f16", 1024), ("bf16", 256), ("f32", 128),
-                                    ("f32", 32), ("f16", 40)])
+                                    ("f32", 32), ("f16", 40), ("f32", 16), ("f16", 8), ("f32", 4), ("f16", 2)])
 @pytest.mark.parametrize("weighted", [False, True], ids=["unweighted", "weighted"])
 def test_reference_sums_long_runs_through_the_workgroup_path(ce, oracle, kind, W, weighted):
     """Runs of 257 lookups and more are walked by the WHOLE workgroup (rows gathered 64 / 16 / 8 at a time into LDS, one
     thread per element running the rounding chain): every run length around the long-run threshold and the chunk sizes
     -- 255, 256, 257, 64 k + {0, 1, 63}, 3,000, 9,000 --, long runs back to back, at the start and at the very end of the
     COO, short runs in between, compressed and full gradients, a pre-filled buffer: the oracle's bits.  (W = 40 has a row
-    split without that path: the same lengths through the one-group walk.)"""
+    split without that path: the same lengths through the one-group walk.  Rows of 64 bytes and less put 64 and more lane
+    groups into a workgroup, whose span of lookups then exceeds 256: TWO runs of 257 ... 511 lookups can start inside one
+    workgroup -- the fuzzer found the second one dropped -- so "long" there means longer than the workgroup's span.)"""
     rng = np.random.default_rng(77 + W)
     lengths = [300, 1, 2, 255, 256, 257, 5, 64 * 5, 64 * 5 + 1, 64 * 6 - 1, 3, 3000, 1, 1, 9000, 7, 512, 513, 1, 700]
     row_ids = np.cumsum(rng.integers(1, 4, len(lengths)))             # ascending, gaps between them

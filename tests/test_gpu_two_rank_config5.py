@@ -38,19 +38,22 @@ def test_config5_ranks_share_one_gpu(oracle, world):
         assert "rank %d ok" % r in o
 
 
-def test_train_step_benchmark_under_torchrun_ranks_share_the_gpu():
+@pytest.mark.parametrize("exchange", ["sparse", "sparse_fixed"])
+def test_train_step_benchmark_under_torchrun_ranks_share_the_gpu(exchange):
     """benchmarks/train_step_benchmark.py (BASELINE configs[4]: fwd + bwd, batch sharded, sparse gradient exchange)
     launched exactly as on a multi-GPU node, with two ranks that have to share this box's GPU: the exchange then
-    runs over gloo on host copies.  Sample blocks (an uncoalesced gradient) through the owner-partitioned exchange."""
+    runs over gloo on host copies.  Sample blocks (an uncoalesced gradient) through the owner-partitioned exchange, with
+    exact sizes and with the fixed capacities of SparseGradExchange (calibrated by a warm-up step; no overflow)."""
     import json
     port = str(_free_port())
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port,
-                        os.path.join(ROOT, "benchmarks", "train_step_benchmark.py"), "--exchange", "sparse",
+                        os.path.join(ROOT, "benchmarks", "train_step_benchmark.py"), "--exchange", exchange,
                         "--sparse_algorithm", "owner", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["exchange"] == "sparse" and line["sample_blocks"] == 2
+    assert line["n_gpus"] == 2 and line["exchange"] == exchange and line["sample_blocks"] == 2
     assert line["ms_per_step"] > 0 and line["breakdown_ms"]["exchange"] > 0
+    assert line["fixed_capacity_overflowed"] is (False if exchange == "sparse_fixed" else None)

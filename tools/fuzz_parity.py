@@ -60,10 +60,21 @@ def one_case(rng, ce, O, np, torch, verbose=False):
         view = np.uint16 if es == 2 else np.uint32
         assert np.array_equal(got.cpu().numpy().view(view), want.view(view)), ("forward", desc)
         if csr and mode != "concat":   # the scheduling hint moves no result: a random order and the one by bag length
-            for order in (torch.randperm(B, device="cuda").int(), ce.bag_order_by_length(dev(offsets), batch_size=B)):
+            lengths = np.diff(offsets.astype(np.int64))
+            counting = ce.bag_order_by_length(dev(offsets), batch_size=B, max_length=-1)      # the counting sort (clamp at 255)
+            assert np.array_equal(counting.cpu().numpy(), np.argsort(-np.minimum(lengths, 255), kind="stable")), ("bag order", desc)
+            decision = ce.new_row_loads_decision()
+            decision[0] = int(rng.integers(0, 2))                                            # the device-side row-load word
+            for order in (torch.randperm(B, device="cuda").int(), ce.bag_order_by_length(dev(offsets), batch_size=B), counting):
                 got = ce.embedding_forward(dev(a["table"]), dev(indices), dev(offsets), dev(weights), batch_size=B,
-                                           num_hots=0, mode=mode, sample_order=order)
+                                           num_hots=0, mode=mode, sample_order=order, row_loads_device=decision)
                 assert np.array_equal(got.cpu().numpy().view(view), want.view(view)), ("forward, sample_order", desc)
+        elif not csr:
+            decision = ce.new_row_loads_decision()
+            decision[0] = int(rng.integers(0, 2))
+            got = ce.embedding_forward(dev(a["table"]), dev(indices), None, dev(weights), batch_size=B, num_hots=H, mode=mode,
+                                       row_loads_device=decision)
+            assert np.array_equal(got.cpu().numpy().view(view), want.view(view)), ("forward, row_loads_device", desc)
     if nnz == 0:
         return desc
     # ---- row ids, transpose, remap
