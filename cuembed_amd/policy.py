@@ -23,7 +23,9 @@ have the same two calls: cuembed_decide_row_loads, cuembed_bag_order_by_length).
                 in a recycled allocation would have been handed another batch's order: still a valid permutation,
                 but not the one it paid for).
 
-Nothing here runs under torch.compile tracing: the hints are then "no hint".  `set_enabled(False)` turns the whole
+Nothing here runs under torch.compile tracing: the hints are then "no hint".  Inside a HIP-graph capture the bag order
+is computed (two captured launches) and the table's EXISTING row-load decision is read by the captured forward; no new
+decision is taken there.  `set_enabled(False)` turns the whole
 module into "no hint" (the tests that pin kernels do).
 """
 import torch
@@ -64,11 +66,16 @@ def row_loads_device(params, indices):
         return None
     key = (params.data_ptr(), tuple(params.shape), params.dtype, params.device)
     state = _tables.get(key)
-    if state is None:
-        if len(_tables) > 64:
-            _tables.clear()
-        state = _tables[key] = [0, torch.zeros((4,), dtype=torch.int32, device=params.device)]
-    if state[0] % RECHECK_CALLS == 0:
+    if state is None or state[0] % RECHECK_CALLS == 0:
+        # (only here -- first sight of a table, and every RECHECK_CALLS calls -- is the capture query paid: ~3 us)
+        if torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture nothing is created or decided: a captured forward reads the table's existing
+            # decision words, which the eager calls around the graph keep fresh; a table first seen here gets no hint
+            return None if state is None else state[1]
+        if state is None:
+            if len(_tables) > 64:
+                _tables.clear()
+            state = _tables[key] = [0, torch.zeros((4,), dtype=torch.int32, device=params.device)]
         torch.ops.cuembed_pyt.cuembed_decide_row_loads(indices, params.numel() * params.element_size(), state[1])
     state[0] += 1
     return state[1]

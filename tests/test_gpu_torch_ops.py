@@ -468,6 +468,20 @@ def test_policy_hints_never_change_a_result(pyt):
     assert order is not None and order.dtype == torch.int32
     assert torch.equal(torch.sort(order.long()).values, torch.arange(B, device="cuda"))
     assert bool((lens[order.long()][1:] <= lens[order.long()][:-1]).all())         # descending bag length
+    # ... and inside a HIP-graph capture: the bag order is computed by captured launches, the captured forward reads the
+    # table's existing decision words; replayed on other indices in the same buffer -- the plain result's bits
+    idx_buf = uniform.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        pyt.cuemb_embedding(table, idx_buf, offsets, None)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out_g = pyt.cuemb_embedding(table, idx_buf, offsets, None)
+        idx_buf.copy_(skewed)
+        graph.replay()
+        side.synchronize()
+    assert torch.equal(out_g, plain_skewed)
     # a fresh offsets tensor gets ITS order (nothing is cached: nothing can go stale)
     lens2 = torch.flip(lens, [0])
     offsets2 = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), lens2.cumsum(0)])
