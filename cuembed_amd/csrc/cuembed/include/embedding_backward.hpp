@@ -334,9 +334,9 @@ void EmbeddingBackward(const GradT* grad_y,
  * are not exactly representable, runs of any length.  (EmbeddingBackward keeps fp32 partial sums and rounds once per
  * flush: identical on exactly representable data, closer to the true sum otherwise.)  A rounding chain cannot be cut
  * into partial sums, so one run is ONE chain of dependent additions (the hottest row of the C4 batch: 65,528 of them);
- * short runs are walked by one lane group each, runs of 256 lookups and more by a whole workgroup that gathers 64 rows at
- * a time into LDS and runs the chain out of it.  C4: 4.3 ms in fp16 (15 x the default path's 0.29 ms on the same data;
- * 26.4 ms before the long-run path), 6.6 ms in fp32 (12 x).  skip_grad_init = true ADDS to what grad_embedding holds, like the
+ * short runs are walked by one lane group each, runs of more than 256 lookups by a whole workgroup whose gather groups
+ * stage the rows in LDS while one wavefront runs the chain out of it.  C4: 2.6 ms in fp16 (9 x the default path's 0.29 ms
+ * on the same data; 26.4 ms before the long-run path), 4.7 ms in fp32 (9 x).  skip_grad_init = true ADDS to what grad_embedding holds, like the
  * reference's loop on a buffer the caller did not zero.
  */
 template <typename GradT, typename IndexT>
@@ -368,15 +368,16 @@ void EmbeddingBackwardReferenceSums(const GradT* grad_y,
   const ElemT* w = reinterpret_cast<const ElemT*>(transpose_weights);
   ElemT* out = reinterpret_cast<ElemT*>(grad_embedding);
   const int lanes = split.lanes_per_row;
-  const int groups = lanes >= detail::kDefaultBlockThreads ? 1 : detail::kDefaultBlockThreads / lanes;
+  const int groups = lanes >= detail::kReferenceBlockThreads ? 1 : detail::kReferenceBlockThreads / lanes;
   const dim3 block(lanes, groups, 1);
   const int64_t spans = (static_cast<int64_t>(nnz) + detail::kReferenceSpan - 1) / detail::kReferenceSpan;
-  const dim3 grid(static_cast<unsigned>((spans + groups - 1) / groups), 1, 1);
+  const dim3 plain_grid(static_cast<unsigned>((spans + groups - 1) / groups), 1, 1);
   constexpr int kMaxN = 16 / static_cast<int>(sizeof(ElemT));
   // runs of 256 lookups and more are walked by the whole workgroup out of LDS (see the kernel); 0: shape without that path
   const size_t row_bytes = static_cast<size_t>(embed_width) * sizeof(ElemT);
-  const int chunk = detail::ReferenceChunkRows(row_bytes, lanes * groups, groups, embed_width);
+  const int chunk = detail::ReferenceLongRun(row_bytes, lanes, groups).chunk_rows;
   const size_t lds = chunk > 0 ? 2 * static_cast<size_t>(chunk) * (row_bytes + sizeof(ElemT)) : 0;
+  const dim3 grid(chunk > 0 ? 2 * plain_grid.x : plain_grid.x, 1, 1);      // (long-run half first, then the short runs)
 #define CUEMBED_LAUNCH_REFERENCE(NN)                                                                               \
   do {                                                                                                             \
     if (w != nullptr)                                                                                              \

@@ -652,27 +652,43 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
 //! dependent additions.  What CAN be shared is everything around the chain:
 //!   * short runs: one lane group per run, 8 row gathers in flight;
 //!   * runs longer than kReferenceLongRun lookups and than the workgroup's own span (so that at most one can START inside
-//!     a workgroup's lookups): the whole
-//!     workgroup walks it -- all of its threads gather the next kReferenceChunk rows of grad_y into LDS at once (one
-//!     memory round trip per chunk instead of one per 8 lookups; sample ids and weights one chunk further ahead), and
-//!     the lanes of its first group run the chain out of LDS, each on its N elements (fp16: packed half arithmetic),
-//!     while the next chunk is in flight.  C4 (fp16 / fp32): 26.4 / 23.7 -> 4.3 / 6.6 ms; one run of 65,528 lookups costs
-//!     ~50 ns a lookup (was 295) -- tools/reference_sums_run_probe.py; what is left is per-chunk bookkeeping, not the
-//!     chain and not memory (the same time with every gather an L2 hit).
+//!     a workgroup's lookups): the whole workgroup walks it with its wavefronts SPECIALISED -- the gather groups fetch the
+//!     next chunk of rows of grad_y into LDS (one memory round trip per chunk instead of one per 8 lookups; a chunk's
+//!     gathers and the next chunk's ids are in flight for a whole iteration), the lanes of group 0 run the chain out of LDS,
+//!     each on its N elements (fp16: packed half arithmetic); two LDS buffers, ONE barrier per chunk.  Up to 1,024 threads
+//!     per workgroup, so that a gather thread handles one or two rows of a chunk: per-thread bookkeeping, not the chain
+//!     and not memory, was what a lone workgroup of 256 threads spent its time on (tools/reference_sums_run_probe.py:
+//!     295 ns a lookup with one lane group per run, 50 with 256 threads sharing the work, 30 specialised).  C4 (fp16 /
+//!     fp32): 26.4 / 23.7 -> 2.6 / 4.7 ms.
 //!   block = (lanes_per_row, groups); every group looks at kReferenceSpan consecutive lookups and walks the runs that
 //!   START there.
 constexpr int kReferenceSpan = 8;
 constexpr int kReferenceLongRun = 256;
-constexpr int kReferenceChunk = 64;          //!< rows per LDS buffer (two buffers); fewer for rows beyond 512 bytes
+constexpr int kReferenceBlockThreads = 1024;  //!< lane groups x lanes of a workgroup of the reference-sums kernel
+constexpr int kReferenceMaxPer = 2;           //!< rows of a chunk per gather group: with 1,024 threads one, two for rows of 4 KB and more
 
-//! LDS rows per buffer for the long-run path, 0 = no long-run path for this shape (the launcher's and the kernel's rule).
-inline int ReferenceChunkRows(const size_t row_bytes, const int block_threads, const int groups, const int width) {
-  (void)width;
-  if (block_threads != 256) return 0;
-  int rows = kReferenceChunk;
-  while (rows > groups && 2 * static_cast<size_t>(rows) * row_bytes > (size_t{48} << 10)) rows /= 2;
-  if (rows < groups || rows % groups != 0 || 2 * static_cast<size_t>(rows) * row_bytes > (size_t{48} << 10)) return 0;
-  return rows / groups <= 8 ? rows : 0;
+//! Long-run path: which lane groups of a workgroup chain and which gather.  The wavefront(s) of group 0 run the chain
+//! (group 0's lanes; the other groups of that wavefront idle in the loop: work of theirs would be executed by the chain
+//! wavefront too); every other group gathers `per` rows of each chunk.
+struct ReferenceLongRunShape {
+  int chain_groups;   //!< groups in the chain wavefront(s): lanes < 64 -> 64 / lanes, else 1
+  int gather_groups;  //!< the rest
+  int per;            //!< rows of a chunk per gather group (1 .. kReferenceMaxPer)
+  int chunk_rows;     //!< per x gather_groups; 0 = no long-run path for this shape
+};
+__host__ __device__ inline ReferenceLongRunShape ReferenceLongRun(const size_t row_bytes, const int lanes, const int groups) {
+  ReferenceLongRunShape s{1, 0, 0, 0};
+  const bool aligned = lanes > 0 && (lanes < 64 ? 64 % lanes == 0 : lanes % 64 == 0);
+  if (!aligned || (lanes * groups) % 64 != 0) return s;
+  s.chain_groups = lanes < 64 ? 64 / lanes : 1;
+  s.gather_groups = groups - s.chain_groups;
+  if (s.gather_groups < 1) return s;
+  const size_t max_rows = (size_t{48} << 10) / (2 * row_bytes);        // two LDS buffers within 48 KB
+  s.per = static_cast<int>(max_rows / static_cast<size_t>(s.gather_groups));
+  if (s.per > kReferenceMaxPer) s.per = kReferenceMaxPer;
+  if (s.per < 1) return s;
+  s.chunk_rows = s.per * s.gather_groups;
+  return s;
 }
 
 //! One step of the reference's rounding chain on the N elements of a lane: acc = GradT(acc + GradT(x * w)), every
@@ -716,7 +732,16 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   __shared__ long long long_head;          // first lookup of the long run that starts in this workgroup's span, or -1
   __shared__ int chunk_count[2];
   const int lane_x = threadIdx.x;
-  const int64_t group = static_cast<int64_t>(blockIdx.x) * blockDim.y + threadIdx.y;
+  // With the long-run path the grid has TWO halves over the same lookups: the first half only looks for long runs and
+  // walks them (a workgroup without one leaves at once), the second walks the short runs.  Workgroups are dispatched in
+  // blockIdx order, so every long run -- the kernel's critical path is the hottest row's chain -- starts within
+  // microseconds instead of queueing behind thousands of short-run workgroups (C4: the hottest run takes 2.0 ms, the
+  // kernel took 4.0 with one mixed grid).
+  const unsigned half = chunk_rows > 0 ? gridDim.x / 2 : gridDim.x;
+  const bool long_phase = chunk_rows > 0 && blockIdx.x < half;
+  const bool short_phase = !long_phase;
+  const int64_t block_in_phase = blockIdx.x < half ? blockIdx.x : blockIdx.x - half;
+  const int64_t group = block_in_phase * blockDim.y + threadIdx.y;
   const int64_t column0 = static_cast<int64_t>(lane_x) * N;
   typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, N>) / 4))) raw_t;
   constexpr int K = 8;
@@ -735,11 +760,13 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   for (int64_t p = group * kReferenceSpan; p < (group + 1) * kReferenceSpan && p < nnz; ++p) {
     const IndexT row = rows[p];
     if (p > 0 && rows[p - 1] == row) continue;   // not the first lookup of its run
-    if (run_ids != nullptr && lane_x == 0) inverse_mapping[row] = run_ids[p];
-    if (chunk_rows > 0 && p + long_run < nnz && rows[p + long_run] == row) {
-      if (lane_x == 0) long_head = p;            // (one per workgroup at most: the run outlasts the workgroup's span)
+    if (short_phase && run_ids != nullptr && lane_x == 0) inverse_mapping[row] = run_ids[p];
+    const bool is_long = chunk_rows > 0 && p + long_run < nnz && rows[p + long_run] == row;
+    if (long_phase) {
+      if (is_long && lane_x == 0) long_head = p; // (one per workgroup at most: the run outlasts the workgroup's span)
       continue;
     }
+    if (is_long) continue;                       // (walked by the first half of the grid)
     GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
     float acc[N];
     if (add_to_output) {
@@ -785,63 +812,61 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
     for (int e = 0; e < N; ++e) result.v[e] = static_cast<GradT>(acc[e]);
     *reinterpret_cast<Pack<GradT, N>*>(dst) = result;
   }
-  if (chunk_rows <= 0) return;
+  if (!long_phase) return;
   __syncthreads();
   if (long_head < 0) return;
-  // ---- the long run that starts here: gathered by everybody, chained out of LDS ----
+  // ---- the long run that starts here: gathered by the gather groups, chained out of LDS by group 0 ----
   const int64_t p = long_head;
   const IndexT row = rows[p];
-  const int threads = blockDim.x * blockDim.y;                 // 256 (ReferenceChunkRows)
-  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-  const int groups = blockDim.y;
-  const int per = chunk_rows / groups;                         // rows of a chunk that one lane group gathers (<= 8)
+  const ReferenceLongRunShape shape =
+      ReferenceLongRun(static_cast<size_t>(width) * sizeof(GradT), static_cast<int>(blockDim.x), static_cast<int>(blockDim.y));
+  const int gather_groups = shape.gather_groups, per = shape.per;
+  const bool chains = threadIdx.y == 0;
+  const bool gathers = static_cast<int>(threadIdx.y) >= shape.chain_groups;
+  const int gi = static_cast<int>(threadIdx.y) - shape.chain_groups;      // this gather group's number
   GradT* stage = reinterpret_cast<GradT*>(reference_lds);      // [2][chunk_rows][width]
   GradT* stage_w = stage + 2 * static_cast<size_t>(chunk_rows) * width;   // [2][chunk_rows]
-  // The chain is run by the lanes of group 0, each on the N elements it also gathers (N independent chains per lane, one
-  // 16-byte LDS read per lookup and lane).  (One THREAD per element -- four wavefronts reading 2 bytes per lookup each --
-  // measured the same 47-50 ns per lookup.)
-  const bool chains = threadIdx.y == 0;
   GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
   Pack<GradT, N> sum;                        // the chain's state lives in GradT: it is rounded to it at every step anyway
 #pragma unroll
   for (int e = 0; e < N; ++e) sum.v[e] = static_cast<GradT>(0);
   if (chains && add_to_output) sum = *reinterpret_cast<const Pack<GradT, N>*>(dst);
-  // what a lane group knows about ITS rows of a chunk: sample id, weight, "still in the run" -- for the chunk whose rows
+  // what a gather group knows about ITS rows of a chunk: row id found there, sample id, weight -- for the chunk whose rows
   // are being gathered (`now`) and for the one after it (`next`: its ids are requested a whole chunk ahead, so that a
   // gather never waits for them)
   struct Lookups {
-    IndexT rid[8];      //!< the row id found at the slot's position (compared with the run's row when the chunk is parked)
-    IndexT sid[8];
-    GradT w[8];
+    IndexT rid[kReferenceMaxPer];      //!< the row id found at the slot's position (compared with the run's row when the chunk is parked)
+    IndexT sid[kReferenceMaxPer];
+    GradT w[kReferenceMaxPer];
   };
   Lookups now, next;
-  // Eight UNCONDITIONAL loads per array at clamped positions, nothing decided here: a load under a runtime condition, or a
-  // comparison of a loaded row id kept as a lane mask, becomes a full wait behind every single load (eight dependent
-  // round trips per chunk instead of one: 3.8 us per 64 lookups).  Slots beyond `per` repeat slot 0's position.
+  // UNCONDITIONAL loads at clamped positions, nothing decided here: a load under a runtime condition, or a comparison of a
+  // loaded row id kept as a lane mask, becomes a full wait behind every single load (eight dependent round trips per
+  // chunk instead of one: 3.8 us per 64 lookups).  Slots beyond `per` repeat slot 0's position.
   auto look_up = [&](Lookups& l, const int64_t first) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int64_t at = first + threadIdx.y + static_cast<int64_t>(k < per ? k : 0) * groups;
+    for (int k = 0; k < kReferenceMaxPer; ++k) {
+      const int64_t at = first + gi + static_cast<int64_t>(k < per ? k : 0) * gather_groups;
       const int64_t safe = at < nnz ? at : nnz - 1;
       l.rid[k] = rows[safe];
       l.sid[k] = sample_ids[safe];
       if constexpr (kWeighted) l.w[k] = weights[safe];
     }
   };
-  raw_t held[8];
+  raw_t held[kReferenceMaxPer];
   auto gather = [&](const Lookups& l) {      // (every slot loads -- a row of the run or, past its end, whatever row the
 #pragma unroll                               //  clamped position names: a valid sample id either way)
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < kReferenceMaxPer; ++k)
       held[k] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(l.sid[k]), width));
   };
   // registers -> LDS for the slots that still belong to the run, and how many of the chunk's rows those are
   auto park = [&](const Lookups& l, const int64_t first, const int buffer) {
     int mine = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int64_t at = first + threadIdx.y + static_cast<int64_t>(k) * groups;
+    for (int k = 0; k < kReferenceMaxPer; ++k) {
+      const int64_t at = first + gi + static_cast<int64_t>(k) * gather_groups;
       if (k < per && at < nnz && l.rid[k] == row) {
-        const int slot = threadIdx.y + k * groups;
+        const int slot = gi + k * gather_groups;
         *reinterpret_cast<raw_t*>(stage + (static_cast<size_t>(buffer) * chunk_rows + slot) * width + column0) = held[k];
         if constexpr (kWeighted)
           if (lane_x == 0) stage_w[buffer * chunk_rows + slot] = l.w[k];
@@ -850,21 +875,26 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
     }
     if (lane_x == 0 && mine > 0) atomicAdd(&chunk_count[buffer], mine);
   };
-  look_up(now, p);
-  gather(now);
-  look_up(next, p + chunk_rows);
-  int64_t q = p;                             // first lookup of the chunk in `held`
+  if (gathers) {
+    look_up(now, p);
+    gather(now);
+    look_up(next, p + chunk_rows);
+  }
+  int64_t q = p;                             // first lookup of the chunk that is parked next
+  int seen[2] = {0, 0};                      // rows counted into each buffer's (never reset) counter so far
   for (int buffer = 0;; buffer ^= 1) {
-    park(now, q, buffer);                    // (waits for the gathers of this chunk)
-    now = next;
-    look_up(next, q + 2 * static_cast<int64_t>(chunk_rows));
-    __syncthreads();
-    const int count = chunk_count[buffer];   // the run's rows are a prefix of the chunk (the COO is sorted)
-    if (count == chunk_rows) gather(now);    // the next chunk's rows: in flight while this one is chained
-    const GradT* rows_now = stage + static_cast<size_t>(buffer) * chunk_rows * width;
-    const GradT* w_now = stage_w + buffer * chunk_rows;
+    if (gathers) {
+      park(now, q, buffer);                  // (waits for this chunk's gathers, requested a whole iteration ago)
+      now = next;
+      look_up(next, q + 2 * static_cast<int64_t>(chunk_rows));
+      gather(now);                           // the next chunk's rows: in flight while this one is chained
+    }
+    __syncthreads();                         // the chunk is in LDS; the buffer written next is the other one
+    const int count = chunk_count[buffer] - seen[buffer];   // the run's rows are a prefix of the chunk (the COO is sorted)
+    seen[buffer] += count;
     if (chains) {
-      const GradT* mine = rows_now + column0;
+      const GradT* mine = stage + static_cast<size_t>(buffer) * chunk_rows * width + column0;
+      const GradT* w_now = stage_w + buffer * chunk_rows;
       constexpr int kBatch = 8;              // LDS reads requested together, then the dependent additions over them
       int j = 0;
       for (; j + kBatch <= count; j += kBatch) {
@@ -884,9 +914,7 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
             sum, *reinterpret_cast<const Pack<GradT, N>*>(mine + static_cast<size_t>(j) * width),
             kWeighted ? w_now[j] : static_cast<GradT>(0));
     }
-    __syncthreads();                         // everybody is through with this buffer
-    if (tid == 0) chunk_count[buffer] = 0;   // (next used two chunks on, with barriers in between)
-    if (count < chunk_rows) break;           // the run ended inside this chunk
+    if (count < chunk_rows) break;           // the run ended inside this chunk (the same count for every thread)
     q += chunk_rows;
   }
   if (chains) *reinterpret_cast<Pack<GradT, N>*>(dst) = sum;
