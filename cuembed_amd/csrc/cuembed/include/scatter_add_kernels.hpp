@@ -658,8 +658,8 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
 //!     each on its N elements (fp16: packed half arithmetic); two LDS buffers, ONE barrier per chunk.  Up to 1,024 threads
 //!     per workgroup, so that a gather thread handles one or two rows of a chunk: per-thread bookkeeping, not the chain
 //!     and not memory, was what a lone workgroup of 256 threads spent its time on (tools/reference_sums_run_probe.py:
-//!     295 ns a lookup with one lane group per run, 50 with 256 threads sharing the work, 30 specialised).  C4 (fp16 /
-//!     fp32): 26.4 / 23.7 -> 2.6 / 4.7 ms.
+//!     295 ns a lookup with one lane group per run, 50 with 256 threads sharing the work, 30 specialised, 22 with chunks
+//!     of 60 rows instead of 30).  C4 (fp16 / fp32): 26.4 / 23.7 -> 1.8 / 2.9 ms.
 //!   block = (lanes_per_row, groups); every group looks at kReferenceSpan consecutive lookups and walks the runs that
 //!   START there.
 constexpr int kReferenceSpan = 8;
@@ -683,7 +683,9 @@ __host__ __device__ inline ReferenceLongRunShape ReferenceLongRun(const size_t r
   s.chain_groups = lanes < 64 ? 64 / lanes : 1;
   s.gather_groups = groups - s.chain_groups;
   if (s.gather_groups < 1) return s;
-  const size_t max_rows = (size_t{48} << 10) / (2 * row_bytes);        // two LDS buffers within 48 KB
+  // two LDS buffers (+ their weights) within 62 KB -- below the 64 KB a workgroup gets without asking: the barrier and
+  // the bookkeeping of a chunk are paid once per chunk, so a chunk should be as long as LDS allows (512-byte rows: 60)
+  const size_t max_rows = (size_t{62} << 10) / (2 * (row_bytes + 8));
   s.per = static_cast<int>(max_rows / static_cast<size_t>(s.gather_groups));
   if (s.per > kReferenceMaxPer) s.per = kReferenceMaxPer;
   if (s.per < 1) return s;
