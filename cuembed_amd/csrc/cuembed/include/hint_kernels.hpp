@@ -49,10 +49,20 @@ DecideRowLoadsKernel(const IndexT* __restrict__ indices, const int64_t nnz, cons
   const int64_t sampled = static_cast<int64_t>(per_group) * groups;
   const int64_t stride = nnz / sampled > 0 ? nnz / sampled : 1;
   unsigned mine = 0;
-  for (int j = threadIdx.x; j < per_group; j += kDecideThreads) {
+  // (a thread's keys are requested together -- unconditional loads at clamped positions -- before the first is inserted)
+  constexpr int kKeysPerThread = kDecideGroupSample / kDecideThreads;
+  Key mine_keys[kKeysPerThread];
+#pragma unroll
+  for (int u = 0; u < kKeysPerThread; ++u) {
+    const int64_t at = (static_cast<int64_t>(threadIdx.x + u * kDecideThreads) * groups + blockIdx.x) * stride;
+    mine_keys[u] = static_cast<Key>(indices[at < nnz ? at : nnz - 1]);
+  }
+#pragma unroll
+  for (int u = 0; u < kKeysPerThread; ++u) {
+    const int j = threadIdx.x + u * kDecideThreads;
     const int64_t at = (static_cast<int64_t>(j) * groups + blockIdx.x) * stride;
-    if (at >= nnz) break;
-    const Key key = static_cast<Key>(indices[at]);
+    if (j >= per_group || at >= nnz) continue;
+    const Key key = mine_keys[u];
     if (key == kEmpty) continue;                                   // (-1 is not a row)
     unsigned h = (static_cast<unsigned>(key) ^ static_cast<unsigned>(static_cast<unsigned long long>(key) >> 32)) * 0x9E3779B1u;
     h >>= 32 - 13;                                                  // kDecideSlots = 2^13
@@ -153,10 +163,21 @@ BagOrderScatterKernel(const OffsetT* __restrict__ offsets, const int batch, cons
   {  // thread (k, quarter q) adds up the counts of key k over chunks q, q + 4, q + 8, ...: independent loads
     const int k = tid & 255, q = tid >> 8;
     unsigned before = 0u, total = 0u;
-    for (int c = q; c < chunks; c += 4) {
-      const unsigned h = chunk_hist[static_cast<size_t>(c) * 256 + k];
-      total += h;
-      if (c < me) before += h;
+    // (eight unconditional loads at clamped chunk numbers in flight, then the masked adds: one load per trip of a loop
+    // with a runtime bound is one exposed L2 latency per chunk)
+    for (int c0 = q; c0 < chunks; c0 += 4 * 8) {
+      unsigned h[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 4 * u;
+        h[u] = chunk_hist[static_cast<size_t>(c < chunks ? c : chunks - 1) * 256 + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 4 * u;
+        total += c < chunks ? h[u] : 0u;
+        before += c < me ? h[u] : 0u;       // (me < chunks)
+      }
     }
     part_before[q][k] = before;
     part_total[q][k] = total;
