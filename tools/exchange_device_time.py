@@ -11,7 +11,6 @@ import socket
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 import torch.distributed as dist
 import cuembed_amd as ce

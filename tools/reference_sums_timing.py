@@ -1,6 +1,10 @@
+#!/usr/bin/env python3
+"""EmbeddingBackward at the C4 shape (10M x 256, 65,536 x 64 lookups, alpha 1.15, compressed gradient) on
+NON-representable grad_y: the default entry point (fp32 partial sums) against EmbeddingBackwardReferenceSums (the
+reference's per-lookup GradT rounding), fp16 and fp32.  Prints one line per (type, path): ms per call."""
 import sys, time
 sys.path.insert(0, '.')
-import numpy as np, torch
+import torch
 import cuembed_amd as ce
 from cuembed_amd import harness
 B,H,W,rows=65536,64,256,10_000_000

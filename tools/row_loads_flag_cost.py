@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""What reading the device-side row-load decision costs the forward: EmbeddingForward at C2 (alpha 1.15) with and
+without ForwardOptions::row_loads_device (decision word 0), 200 launches each, three repetitions.  (Nothing: ratio 1.001.)"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
