@@ -17,7 +17,7 @@ have the same two calls: cuembed_decide_row_loads, cuembed_bag_order_by_length).
                 host-side rule, >= 80 % of a 65,536 sample, chose it there), the table is >= 1 GiB and the
                 batch has >= 2^18 lookups (the gates are the library's: kStreamingMinTableBytes / kStreamingMinLookups).
   sample_order  the samples of a ragged CSR batch by descending bag length (cuembed::BagOrderByLength; C3: 0.170 ->
-                0.148 ms).  With bag lengths clamped at 255 it is two small launches, 8 us together (a stable counting sort), cheap
+                0.148 ms).  With bag lengths clamped at 255 it is two small launches, 7 us together (a stable counting sort), cheap
                 enough to be computed for EVERY batch from its own offsets -- no cache, nothing to go stale (round 5
                 kept an order per offsets tensor, keyed by address and version; a pipeline that builds fresh offsets
                 in a recycled allocation would have been handed another batch's order: still a valid permutation,
