@@ -1,5 +1,5 @@
 """The scheduling hints decided on the device (hint_kernels.hpp): ForwardOptions::row_loads_device / DecideRowLoads and
-the one-launch BagOrderByLength.  A hint never changes a result: every forward here is compared with the ORACLE, bit
+the counting-sort BagOrderByLength (two small launches).  A hint never changes a result: every forward here is compared with the ORACLE, bit
 for bit; the decisions and the order themselves are compared with their definitions computed in numpy.
 (Reference: embedding_lookup.cuh:186-208 -- one launch rule whatever the data; these replace a caller's own statistics.)"""
 import numpy as np
