@@ -36,6 +36,11 @@ def _declare(L):
     L.cuembed_decide_row_loads.argtypes = [_VP, _I, ctypes.c_int64, ctypes.c_int64, _VP, ctypes.c_uint, _VP]
     L.cuembed_bag_order_by_length.restype = None
     L.cuembed_bag_order_by_length.argtypes = [_VP, _I, _I, _I, _VP, _VP, ctypes.POINTER(ctypes.c_size_t), _VP]
+    _L = ctypes.c_int64
+    L.cuembed_exchange_pack_rows.restype = None
+    L.cuembed_exchange_pack_rows.argtypes = [_VP, _I, _VP, _I, _L, _I, _VP, _VP, _I, _L, _L, _L, _VP, _VP, _VP, _VP, _VP]
+    L.cuembed_exchange_finish_piece.restype = None
+    L.cuembed_exchange_finish_piece.argtypes = [_VP, _VP, _L, _L, _L, _L, _L, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP]
     L.cuembed_set_forward_row_load_policy.restype = None
     L.cuembed_set_forward_row_load_policy.argtypes = [_I]
     L.cuembed_get_forward_row_load_policy.restype = _I

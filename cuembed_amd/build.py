@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcuembed_amd.so")
 HARNESS_PATH = os.path.join(LIB_DIR, "libcuembed_harness.so")
 OBJ_DIR = os.path.join(PKG, "build")
-UNITS = ["c_api_forward.hip", "c_api_backward.hip", "c_api_transforms.hip"]
+UNITS = ["c_api_forward.hip", "c_api_backward.hip", "c_api_transforms.hip", "c_api_exchange.hip"]
 ARCH = "gfx950"
 
 HIPCC_FLAGS = [

@@ -651,6 +651,121 @@ class CuEmbEmbeddingNode : public torch::autograd::Function<CuEmbEmbeddingNode> 
   }
 };
 
+// ---- multi-GPU: the device-side halves of the sparse gradient exchange (cuembed_amd/distributed.py) ----------------
+// As a chain of tensor operations (searchsorted, where, index_select, index_fill_, ...) the index work around the
+// collectives was ~60 launches and more host time than the whole forward + backward step; here it is two ops that
+// enqueue 2 and ~13 launches without returning to Python.  Nothing is read back.
+
+// Extension (cuembed::PackRowsByOwner): the rank's compressed gradient into the fixed slots of the all-to-all.
+void cuembed_exchange_pack_op(const at::Tensor& ids, const at::Tensor& rows, const c10::optional<at::Tensor>& count,
+                              const at::Tensor& cuts, const int64_t slot_capacity, const int64_t input_capacity,
+                              const int64_t num_categories, at::Tensor send_ids, at::Tensor send_rows,
+                              at::Tensor range_starts, at::Tensor flag) {
+  CheckGpu(ids, "ids");
+  CheckGpu(rows, "rows");
+  CheckGpu(cuts, "cuts");
+  CheckGpu(send_ids, "send_ids");
+  CheckGpu(send_rows, "send_rows");
+  CheckGpu(range_starts, "range_starts");
+  CheckGpu(flag, "flag");
+  const int idx = IndexCode(ids, "ids");
+  const int elem = ElemCode(rows, "rows");
+  TORCH_CHECK(rows.dim() == 2 && ids.dim() == 1 && rows.size(0) == ids.numel() && ids.is_contiguous() && rows.is_contiguous(),
+              "cuembed_pyt: rows must be a contiguous [n, width] tensor with one contiguous id per row");
+  const int64_t world = cuts.numel() - 1;
+  TORCH_CHECK(world >= 1 && world <= 1024 && cuts.scalar_type() == at::kLong && cuts.is_contiguous(),
+              "cuembed_pyt: cuts must be world + 1 contiguous int64 words (world <= 1024)");
+  TORCH_CHECK(slot_capacity >= 1, "cuembed_pyt: slot_capacity must be at least one row");
+  TORCH_CHECK(send_ids.scalar_type() == at::kLong && send_ids.is_contiguous() && send_ids.numel() == world * slot_capacity,
+              "cuembed_pyt: send_ids must be world * slot_capacity contiguous int64 words");
+  TORCH_CHECK(send_rows.scalar_type() == rows.scalar_type() && send_rows.is_contiguous() &&
+                  send_rows.numel() == world * slot_capacity * rows.size(1),
+              "cuembed_pyt: send_rows must be a contiguous [world * slot_capacity, width] tensor of rows' dtype");
+  TORCH_CHECK(range_starts.scalar_type() == at::kLong && range_starts.is_contiguous() && range_starts.numel() >= world + 1,
+              "cuembed_pyt: range_starts must hold world + 1 contiguous int64 words");
+  TORCH_CHECK(flag.scalar_type() == at::kLong && flag.numel() >= 1 && flag.is_contiguous(),
+              "cuembed_pyt: flag must be a contiguous int64 word");
+  const at::DeviceGuard guard(rows.device());
+  at::Tensor cnt;
+  if (count.has_value() && count->defined()) {
+    CheckGpu(*count, "count");
+    TORCH_CHECK(count->numel() >= 1, "cuembed_pyt: count must hold one word");
+    // (one word, read by the kernel: a count of the other integer type is converted here, one tiny launch)
+    cnt = count->scalar_type() == ids.scalar_type() ? count->contiguous() : count->to(ids.scalar_type());
+  }
+  ::cuembed_exchange_pack_rows(Ptr(ids), idx, Ptr(rows), elem, ids.numel(), static_cast<int>(rows.size(1)), Ptr(cnt),
+                               static_cast<const int64_t*>(cuts.data_ptr()), static_cast<int>(world), slot_capacity,
+                               input_capacity, num_categories, static_cast<int64_t*>(send_ids.data_ptr()),
+                               send_rows.data_ptr(), static_cast<int64_t*>(range_starts.data_ptr()),
+                               static_cast<int64_t*>(flag.data_ptr()), CurrentStream(rows));
+}
+
+// Extension: the owner's fixed-capacity merge -- TransposeFixedHotness (+ remap) of the received ids, EmbeddingBackward
+// with a device-side row count and pad_to_capacity into out_ids[capacity + 1] / out_rows[capacity + 1, width],
+// cuembed::FinishOwnerPiece -- as one op.  ids >= num_categories are padding and dropped.  `tail`: capacity + 2 words
+// (the ids, the count, the flag word), `count`: one word; either may be absent.
+void cuembed_exchange_merge_op(const at::Tensor& ids, const at::Tensor& rows, const int64_t num_categories,
+                               const int64_t pad_lo, const int64_t pad_len, at::Tensor out_ids, at::Tensor out_rows,
+                               const c10::optional<at::Tensor>& tail, at::Tensor flag,
+                               const c10::optional<at::Tensor>& count) {
+  CheckGpu(ids, "ids");
+  CheckGpu(rows, "rows");
+  CheckGpu(out_ids, "out_ids");
+  CheckGpu(out_rows, "out_rows");
+  CheckGpu(flag, "flag");
+  const int elem = ElemCode(rows, "rows");
+  const int64_t nnz = ids.numel();
+  TORCH_CHECK(ids.scalar_type() == at::kLong && ids.is_contiguous() && nnz >= 1 && nnz <= INT32_MAX,
+              "cuembed_pyt: ids must be 1 .. 2^31 - 1 contiguous int64 words");
+  TORCH_CHECK(rows.dim() == 2 && rows.size(0) == nnz && rows.is_contiguous(),
+              "cuembed_pyt: rows must be a contiguous [n, width] tensor with one id per row");
+  const int64_t width = rows.size(1);
+  const int64_t capacity = out_ids.numel() - 1;
+  TORCH_CHECK(capacity >= 1 && capacity < INT32_MAX && out_ids.scalar_type() == at::kLong && out_ids.is_contiguous(),
+              "cuembed_pyt: out_ids must be capacity + 1 contiguous int64 words");
+  TORCH_CHECK(out_rows.scalar_type() == rows.scalar_type() && out_rows.is_contiguous() && out_rows.dim() == 2 &&
+                  out_rows.size(0) == capacity + 1 && out_rows.size(1) == width,
+              "cuembed_pyt: out_rows must be a contiguous [capacity + 1, width] tensor of rows' dtype");
+  TORCH_CHECK(flag.scalar_type() == at::kLong && flag.numel() >= 1 && flag.is_contiguous(),
+              "cuembed_pyt: flag must be a contiguous int64 word");
+  TORCH_CHECK(pad_len >= 1, "cuembed_pyt: pad_len must be at least 1");
+  int64_t* tail_ptr = nullptr;
+  if (tail.has_value() && tail->defined()) {
+    CheckGpu(*tail, "tail");
+    TORCH_CHECK(tail->scalar_type() == at::kLong && tail->is_contiguous() && tail->numel() == capacity + 2,
+                "cuembed_pyt: tail must be capacity + 2 contiguous int64 words");
+    tail_ptr = static_cast<int64_t*>(tail->data_ptr());
+  }
+  int64_t* count_ptr = nullptr;
+  if (count.has_value() && count->defined()) {
+    CheckGpu(*count, "count");
+    TORCH_CHECK(count->scalar_type() == at::kLong && count->numel() >= 1 && count->is_contiguous(),
+                "cuembed_pyt: count must be a contiguous int64 word");
+    count_ptr = static_cast<int64_t*>(count->data_ptr());
+  }
+  const at::DeviceGuard guard(rows.device());
+  const cuembed_stream_t stream = CurrentStream(rows);
+  at::Tensor t_idx = at::empty_like(ids), t_pos = at::empty_like(ids), remap = at::empty_like(ids);
+  size_t lwork = 0;
+  const int bits = IndexBits(num_categories + 1);   // the padding id num_categories is a key too
+  ::cuembed_transpose_fixed_hotness_remapped(nullptr, nullptr, static_cast<int>(nnz), 1, CUEMBED_I64, CUEMBED_F32, nullptr,
+                                             nullptr, nullptr, nullptr, nullptr, &lwork, bits, 1, nullptr);
+  at::Tensor work = at::empty({static_cast<int64_t>(lwork > 0 ? lwork : 1)}, ids.options().dtype(at::kByte));
+  ::cuembed_transpose_fixed_hotness_remapped(Ptr(ids), nullptr, static_cast<int>(nnz), 1, CUEMBED_I64, CUEMBED_F32,
+                                             MutPtr(t_idx), MutPtr(t_pos), nullptr, MutPtr(remap),
+                                             static_cast<char*>(work.data_ptr()), &lwork, bits, 1, stream);
+  // capacity + 1 rows: the run of the padding ids needs a row too; too many distinct ids -> the kernels write nothing
+  ::cuembed_embedding_backward_bounded(Ptr(rows), elem, static_cast<int>(width), -1, static_cast<int>(nnz), Ptr(t_idx),
+                                       Ptr(t_pos), Ptr(remap), CUEMBED_I64, nullptr, /*skip_grad_init=*/0,
+                                       out_rows.data_ptr(), out_ids.data_ptr(), 1, nullptr,
+                                       static_cast<int>(capacity + 1), nullptr, /*pad_to_capacity=*/1, stream);
+  ::cuembed_exchange_finish_piece(static_cast<const int64_t*>(t_idx.data_ptr()),
+                                  static_cast<const int64_t*>(remap.data_ptr()), nnz, capacity, num_categories, pad_lo,
+                                  pad_len, static_cast<int64_t*>(out_ids.data_ptr()), out_rows.data_ptr(), elem,
+                                  static_cast<int>(width), tail_ptr, static_cast<int64_t*>(flag.data_ptr()), count_ptr,
+                                  stream);
+}
+
 // grad_kind: see GradKind.
 at::Tensor cuemb_embedding_autograd_op(const at::Tensor& params, const at::Tensor& indices, const at::Tensor& offsets,
                                     const at::Tensor& weights, const int64_t grad_kind, const int64_t row_loads,
@@ -700,6 +815,12 @@ TORCH_LIBRARY(cuembed_pyt, m) {
       "row_loads, Tensor? sample_order, Tensor? row_loads_device) -> Tensor");
   m.def("cuembed_decide_row_loads(Tensor indices, int table_bytes, Tensor(a!) decision) -> ()");
   m.def("cuembed_bag_order_by_length(Tensor offsets, int max_length) -> Tensor");
+  m.def(
+      "cuembed_exchange_pack(Tensor ids, Tensor rows, Tensor? count, Tensor cuts, int slot_capacity, int input_capacity, "
+      "int num_categories, Tensor(a!) send_ids, Tensor(b!) send_rows, Tensor(c!) range_starts, Tensor(d!) flag) -> ()");
+  m.def(
+      "cuembed_exchange_merge(Tensor ids, Tensor rows, int num_categories, int pad_lo, int pad_len, Tensor(a!) out_ids, "
+      "Tensor(b!) out_rows, Tensor(c!)? tail, Tensor(d!) flag, Tensor(e!)? count) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(cuembed_pyt, Autograd, m) {
@@ -730,4 +851,6 @@ TORCH_LIBRARY_IMPL(cuembed_pyt, CUDA, m) {  // HIP tensors use the CUDA dispatch
   m.impl("cuembed_embedding_forward_hinted", cuembed_embedding_forward_hinted_op);
   m.impl("cuembed_bag_order_by_length", cuembed_bag_order_by_length_op);
   m.impl("cuembed_decide_row_loads", cuembed_decide_row_loads_op);
+  m.impl("cuembed_exchange_pack", cuembed_exchange_pack_op);
+  m.impl("cuembed_exchange_merge", cuembed_exchange_merge_op);
 }

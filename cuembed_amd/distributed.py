@@ -279,57 +279,83 @@ def exchange_model_ms(world, rows_per_rank, merged_rows_total, width, elem_size,
             "links_used": min(world - 1, XGMI_LINKS_PER_GPU), "link_GBps": link_GBps}
 
 
-def _merge_fixed(ids, vals, num_categories, capacity, pad_lo, pad_len, out_ids=None, out_rows=None):
+def _exchange_ops():
+    """The native halves of the exchange for GPU tensors: the torch ops of libcuembed_pyt.so (least host time), or --
+    CUEMBED_PYT_BACKEND=python -- the same C entry points through ctypes (cuembed_amd.ops)."""
+    global _EXCHANGE_OPS
+    if _EXCHANGE_OPS is None:
+        from . import cuembed_pyt, ops
+
+        class _Ops:
+            pass
+        o = _Ops()
+        if cuembed_pyt.BACKEND == "native":
+            o.pack = torch.ops.cuembed_pyt.cuembed_exchange_pack
+            o.merge = torch.ops.cuembed_pyt.cuembed_exchange_merge
+        else:
+            o.pack, o.merge = ops.exchange_pack_rows, ops.exchange_merge
+        _EXCHANGE_OPS = o
+    return _EXCHANGE_OPS
+
+
+_EXCHANGE_OPS = None
+
+
+def _merge_fixed(ids, vals, num_categories, capacity, pad_lo, pad_len, out_ids=None, out_rows=None, tail=None,
+                 flag=None):
     """Sum rows with equal id into buffers of a FIXED capacity, without a host read-back on the GPU.
 
     ids >= num_categories are padding of the caller's fixed-size input and are dropped.  Returns (uniq[capacity + 1],
-    rows[capacity + 1, W], count[1], overflow[1]): the first `count` entries are the ascending distinct ids and their
+    rows[capacity + 1, W], count[1], overflow[1] -- `flag` itself when one was given): the first `count` entries are the ascending distinct ids and their
     sums (the same bits as _merge gives), every entry past them a ZERO row whose id names a row of
     [pad_lo, pad_lo + pad_len) in turn -- harmless to whoever scatter-adds the lot.  overflow != 0: more than
-    `capacity` distinct ids; the buffers then keep what they held (well-formed, but not this step's gradient)."""
+    `capacity` distinct ids; the buffers then keep what they held (well-formed, but not this step's gradient).
+    tail (int64[capacity + 2], optional): the all-gather's id buffer -- the ids, min(count, capacity), the flag word;
+    flag (int64[1], optional): the step's overflow word so far, returned with this merge's overflow OR-ed in."""
     m = ids.numel()
     dev = vals.device
     width = vals.shape[1]
     if out_rows is None:
         out_rows = torch.zeros((capacity + 1, width), dtype=vals.dtype, device=dev)
         out_ids = torch.zeros((capacity + 1,), dtype=torch.int64, device=dev)
+    if m and vals.is_cuda:
+        # (the padding id num_categories sorts behind every real id and becomes ONE extra run at the end; capacity + 1
+        # rows: that run needs a row too; too many distinct ids -> the kernels write nothing.  One native op: Transpose
+        # with the remap from the same call, EmbeddingBackward with a device-side count, cuembed::FinishOwnerPiece)
+        count = torch.empty((1,), dtype=torch.int64, device=dev)
+        flag = torch.zeros((1,), dtype=torch.int64, device=dev) if flag is None else flag
+        _exchange_ops().merge(ids.contiguous(), vals.contiguous(), num_categories, pad_lo, max(pad_len, 1), out_ids,
+                              out_rows, tail, flag, count)
+        return out_ids, out_rows, count, flag
+    # ---- host tensors (the gloo tests), or nothing to merge: the same result from tensor operations
     pad_ids = pad_lo + torch.arange(capacity + 1, dtype=torch.int64, device=dev) % max(pad_len, 1)
+    count = torch.zeros((1,), dtype=torch.int64, device=dev)
+    overflow = torch.zeros((1,), dtype=torch.int64, device=dev)
     if m == 0:
         out_rows.zero_()
         out_ids.copy_(pad_ids)
-        z = torch.zeros((1,), dtype=torch.int64, device=dev)
-        return out_ids, out_rows, z, z.clone()
-    if vals.is_cuda:
-        from . import ops
-        pos = ops.extract_row_ids_for_concat(m, torch.int64, dev)
-        # (the padding id num_categories sorts behind every real id and becomes ONE extra run at the end)
-        t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories + 1, num_rows=m)
-        remap = ops.compute_compressed_grad_indices(t_ids)
-        has_pad = (t_ids[-1:] >= num_categories).to(torch.int64)
-        count = remap[-1:] + 1 - has_pad
-        overflow = (count > capacity).to(torch.int64)
-        # capacity + 1 rows: the run of the padding ids needs a row too; too many distinct ids -> the kernels write nothing
-        ops.embedding_backward(vals.contiguous(), None, t_ids, t_pos, remap, grad_embedding=out_rows,
-                               inverse_mapping=out_ids, pad_to_capacity=True)
-        # the padding run's "sum" sits right behind the real rows: zero it (when there is none, the spare last row)
-        out_rows.index_fill_(0, torch.where(has_pad > 0, count, torch.full_like(count, capacity)).clamp_(max=capacity), 0)
-        # entries past the count: a valid id each, different ones in turn (one id for the whole tail serialises
-        # whoever coalesces the result)
-        torch.where(torch.arange(capacity + 1, device=dev) < count, out_ids, pad_ids, out=out_ids)
-        return out_ids, out_rows, count, overflow
-    keep = ids < num_categories
-    uniq, inverse = torch.unique(ids[keep], sorted=True, return_inverse=True)
-    k = uniq.numel()
-    count = torch.tensor([k], dtype=torch.int64)
-    if k > capacity:
-        return out_ids, out_rows, count, torch.ones((1,), dtype=torch.int64)
-    summed = torch.zeros((k, width), dtype=torch.float32)
-    summed.index_add_(0, inverse, vals[keep].float())
-    out_rows.zero_()
-    out_rows[:k] = summed.to(vals.dtype)
-    out_ids.copy_(pad_ids)
-    out_ids[:k] = uniq
-    return out_ids, out_rows, count, torch.zeros((1,), dtype=torch.int64)
+    else:
+        keep = ids < num_categories
+        uniq, inverse = torch.unique(ids[keep], sorted=True, return_inverse=True)
+        k = uniq.numel()
+        count.fill_(k)
+        if k > capacity:
+            overflow.fill_(1)
+        else:
+            summed = torch.zeros((k, width), dtype=torch.float32, device=dev)
+            summed.index_add_(0, inverse, vals[keep].float())
+            out_rows.zero_()
+            out_rows[:k] = summed.to(vals.dtype)
+            out_ids.copy_(pad_ids)
+            out_ids[:k] = uniq
+    if flag is not None:
+        flag |= overflow
+        overflow = flag
+    if tail is not None:
+        tail[:capacity] = out_ids[:capacity]
+        tail[capacity: capacity + 1] = torch.clamp(count, max=capacity)
+        tail[capacity + 1:] = overflow
+    return out_ids, out_rows, count, overflow
 
 
 class SparseGradResult:
@@ -398,8 +424,14 @@ class SparseGradExchange:
         self._lo, hi = bounds[self.rank]
         self._range = max(hi - self._lo, 1)
         w, s, p = self.world, self.pair_capacity, self.piece_capacity
-        self._slot = torch.arange(s, dtype=torch.int64, device=device)
+        on_gpu = torch.device(device).type == "cuda"
+        self._slot = None if on_gpu else torch.arange(s, dtype=torch.int64, device=device)
         self._send_ids = torch.empty((w * s,), dtype=torch.int64, device=device)
+        # (GPU: the pack kernel's own buffers; zero-initialised ONCE -- rows behind a slot's ids are never written and
+        # must stay finite, their padding id drops them at the owner)
+        self._send_rows = torch.zeros((w * s, self.width), dtype=dtype, device=device) if on_gpu else None
+        self._starts = torch.zeros((w + 1,), dtype=torch.int64, device=device)
+        self._flag = torch.zeros((1,), dtype=torch.int64, device=device)       # this step's overflow word
         self._recv_ids = torch.empty((w * s,), dtype=torch.int64, device=device)
         self._recv_rows = torch.empty((w * s, self.width), dtype=dtype, device=device)
         # (zero-initialised ONCE: a step that overflows leaves them as they were -- finite rows, valid ids)
@@ -472,47 +504,45 @@ class SparseGradExchange:
             # (a stream-side wait; a caller that already waited pays nothing)
             self._pending.wait()
             self._pending = None
-        flag = torch.zeros((1,), dtype=torch.int64, device=dev)
+        flag = self._flag
+        flag.zero_()
+        check = 0            # (input_capacity when the buffers are cut there: the pack then flags a count beyond it)
         if self.input_capacity and count is not None and inverse_mapping.numel() > self.input_capacity:
-            flag = flag | (count.reshape(1).to(dev) > self.input_capacity).to(torch.int64)
+            check = self.input_capacity
             inverse_mapping, rows = inverse_mapping[: self.input_capacity], rows[: self.input_capacity]
-        ids = inverse_mapping if inverse_mapping.dtype == torch.int64 else inverse_mapping.to(torch.int64)
-        n = ids.numel()
-        if n and count is not None:      # rows past the count hold nothing: give them the padding id
-            ids = torch.where(torch.arange(n, device=dev) < count.reshape(1).to(dev), ids,
-                              torch.full_like(ids, self.num_categories))
-        if n and not coalesced:
-            if not self.local_capacity:
-                raise ValueError("coalesced=False needs local_capacity (the rank's own rows are merged first)")
-            ids, rows, mine, over = _merge_fixed(ids, rows, self.num_categories, self.local_capacity, 0, 1,
-                                                 self._local_ids, self._local_rows)
-            # (behind the count the merged buffer holds zero rows named 0: give them the padding id again)
-            ids = torch.where(torch.arange(ids.numel(), device=dev) < mine, ids, torch.full_like(ids, self.num_categories))
-            flag = flag | over
-            n = ids.numel()
-        # ---- pack: owner r's rows into slot r of the send buffers (device-side counts, fixed slot size)
-        if n:
-            pos = torch.searchsorted(ids, self._cuts)                       # padding ids sort behind the last cut
-            have = pos[1:] - pos[:-1]
-            flag = flag | (have > s).any().reshape(1).to(torch.int64)
-            valid = self._slot.unsqueeze(0) < have.unsqueeze(1)             # [world, slot]
-            src = torch.where(valid, pos[:-1].unsqueeze(1) + self._slot.unsqueeze(0), torch.zeros_like(valid, dtype=torch.int64))
-            src = src.reshape(-1)
-            torch.where(valid.reshape(-1), ids[src], torch.full_like(src, self.num_categories), out=self._send_ids)
-            send_rows = rows.index_select(0, src)       # (rows of unused slot entries: row 0 again and again -- their id drops them)
+        n = inverse_mapping.numel()
+        native = rows.is_cuda
+        if native:
+            ids = inverse_mapping
+            if n and not coalesced:
+                # the owner ranges are cut out of ASCENDING ids: the rank's own rows are merged first (one more native
+                # merge; it also sends fewer rows).  Afterwards `count` is the merged row count, on the device.
+                if not self.local_capacity:
+                    raise ValueError("coalesced=False needs local_capacity (the rank's own rows are merged first)")
+                ids = ids.to(torch.int64)
+                if count is not None:      # rows past the count hold nothing: give them the padding id
+                    given = count.reshape(1).to(dev)
+                    ids = torch.where(torch.arange(n, device=dev) < given, ids,
+                                      torch.full((1,), self.num_categories, dtype=torch.int64, device=dev))
+                    if check:
+                        flag |= (given > check).to(torch.int64)
+                        check = 0
+                ids, rows, count, _ = _merge_fixed(ids, rows, self.num_categories, self.local_capacity,
+                                                   self.num_categories, 1, self._local_ids, self._local_rows, None, flag)
+            # ---- pack: owner r's rows into slot r of the send buffers (two launches, device-side counts)
+            _exchange_ops().pack(ids.contiguous(), rows.contiguous(), None if count is None else count.reshape(-1),
+                                 self._cuts, s, check, self.num_categories, self._send_ids, self._send_rows,
+                                 self._starts, flag)
+            send_rows = self._send_rows
         else:
-            self._send_ids.fill_(self.num_categories)
-            send_rows = torch.zeros((w * s, self.width), dtype=self.dtype, device=dev)
+            send_rows = self._pack_on_host(inverse_mapping, rows, count, coalesced, check, flag)
         # ---- all-to-all with equal splits: no sizes to agree on
         _all_to_all_equal(self._recv_ids, self._send_ids, self.group)
         _all_to_all_equal(self._recv_rows, send_rows, self.group)
-        # ---- merge my range into the piece (fixed capacity, device-side count)
-        _, _, cnt, over = _merge_fixed(self._recv_ids, self._recv_rows, self.num_categories, p, self._lo, self._range,
-                                       self._piece_ids, self._piece_rows)
-        flag = flag | over
-        self._piece_tail[:p] = self._piece_ids[:p]
-        self._piece_tail[p: p + 1] = torch.clamp(cnt, max=p)
-        self._piece_tail[p + 1:] = flag
+        # ---- merge my range into the piece (fixed capacity, device-side count; the piece's id buffer carries the
+        #      count and the overflow word in-band)
+        _merge_fixed(self._recv_ids, self._recv_rows, self.num_categories, p, self._lo, self._range, self._piece_ids,
+                     self._piece_rows, self._piece_tail, flag)
         # ---- all-gather of the fixed-size pieces (ids carry count and overflow word in-band)
         out_tail, out_rows = self._out[self._turn]
         self._turn ^= 1
@@ -524,6 +554,38 @@ class SparseGradExchange:
         else:
             self._pending = result
         return result
+
+    def _pack_on_host(self, inverse_mapping, rows, count, coalesced, check, flag):
+        """The pack of start() from tensor operations: host tensors (the gloo tests).  Same send buffers as
+        cuembed::PackRowsByOwner, except that the rows of unused slot entries are row 0 again and again instead of
+        whatever the buffer held (their id drops them either way)."""
+        dev, w, s = self.device, self.world, self.pair_capacity
+        ids = inverse_mapping if inverse_mapping.dtype == torch.int64 else inverse_mapping.to(torch.int64)
+        n = ids.numel()
+        if check:
+            flag |= (count.reshape(1).to(dev) > check).to(torch.int64)
+        if n and count is not None:      # rows past the count hold nothing: give them the padding id
+            ids = torch.where(torch.arange(n, device=dev) < count.reshape(1).to(dev), ids,
+                              torch.full_like(ids, self.num_categories))
+        if n and not coalesced:
+            if not self.local_capacity:
+                raise ValueError("coalesced=False needs local_capacity (the rank's own rows are merged first)")
+            ids, rows, mine, _ = _merge_fixed(ids, rows, self.num_categories, self.local_capacity, 0, 1,
+                                              self._local_ids, self._local_rows, None, flag)
+            # (behind the count the merged buffer holds zero rows named 0: give them the padding id again)
+            ids = torch.where(torch.arange(ids.numel(), device=dev) < mine, ids, torch.full_like(ids, self.num_categories))
+            n = ids.numel()
+        if not n:
+            self._send_ids.fill_(self.num_categories)
+            return torch.zeros((w * s, self.width), dtype=self.dtype, device=dev)
+        pos = torch.searchsorted(ids, self._cuts)                       # padding ids sort behind the last cut
+        have = pos[1:] - pos[:-1]
+        flag |= (have > s).any().reshape(1).to(torch.int64)
+        valid = self._slot.unsqueeze(0) < have.unsqueeze(1)             # [world, slot]
+        src = torch.where(valid, pos[:-1].unsqueeze(1) + self._slot.unsqueeze(0), torch.zeros_like(valid, dtype=torch.int64))
+        src = src.reshape(-1)
+        torch.where(valid.reshape(-1), ids[src], torch.full_like(src, self.num_categories), out=self._send_ids)
+        return rows.index_select(0, src)
 
     def note_flags(self, result):
         """(after result.wait()) folds the step's overflow words of all ranks into the sticky one; device-side."""

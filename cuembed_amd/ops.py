@@ -698,3 +698,77 @@ ComputeCompressedGradIndices = compute_compressed_grad_indices
 ExtractRowIdsFromFixed = extract_row_ids_from_fixed
 ExtractRowIdsFromCSR = extract_row_ids_from_csr
 ExtractRowIdsForConcat = extract_row_ids_for_concat
+
+
+# ---- multi-GPU: the device-side halves of the sparse gradient exchange (cuembed_amd/distributed.py) -----------------
+def exchange_pack_rows(ids, rows, count, cuts, slot_capacity, input_capacity, num_categories, send_ids, send_rows,
+                       range_starts, flag):
+    """cuembed::PackRowsByOwner (extension): the first `count` (1-element device tensor of ids' dtype, None = all)
+    ascending ids[n] / rows[n, W] into the fixed slots of an equal-split all-to-all -- slot r of
+    send_ids[world * slot_capacity] (int64) / send_rows[world * slot_capacity, W] gets the rows of the id range
+    [cuts[r], cuts[r + 1]) (cuts: int64[world + 1] on the device), then the padding id num_categories.
+    range_starts: int64[world + 1] scratch; flag: an int64 word, |= 1 when a range exceeds its slot or (with
+    input_capacity > 0) count exceeds input_capacity.  Two launches, nothing read back."""
+    _check_dev("rows", rows)
+    dev = rows.device
+    for name, t in (("ids", ids), ("cuts", cuts), ("send_ids", send_ids), ("send_rows", send_rows),
+                    ("range_starts", range_starts), ("flag", flag)):
+        _check_dev(name, t, dev)
+    it = _index_code("ids", ids)
+    et = _elem_code("rows", rows)
+    world = cuts.numel() - 1
+    if rows.dim() != 2 or rows.shape[0] != ids.numel() or not rows.is_contiguous() or not ids.is_contiguous():
+        raise ValueError("rows must be a contiguous [n, width] tensor with one contiguous id per row")
+    if cuts.dtype != torch.int64 or world < 1 or world > 1024 or not cuts.is_contiguous():
+        raise ValueError("cuts must be world + 1 contiguous int64 words (world <= 1024)")
+    if send_ids.dtype != torch.int64 or send_ids.numel() != world * slot_capacity or not send_ids.is_contiguous():
+        raise ValueError("send_ids must be world * slot_capacity contiguous int64 words")
+    if send_rows.dtype != rows.dtype or send_rows.numel() != world * slot_capacity * rows.shape[1] or \
+            not send_rows.is_contiguous():
+        raise ValueError("send_rows must be a contiguous [world * slot_capacity, width] tensor of rows' dtype")
+    if range_starts.dtype != torch.int64 or range_starts.numel() < world + 1 or flag.dtype != torch.int64:
+        raise ValueError("range_starts must hold world + 1 int64 words, flag one")
+    if count is not None:
+        _check_dev("count", count, dev)
+        count = count.contiguous() if count.dtype == ids.dtype else count.to(ids.dtype)
+    with torch.cuda.device(dev):
+        _lib.lib().cuembed_exchange_pack_rows(_ptr(ids), it, _ptr(rows), et, ids.numel(), rows.shape[1], _ptr(count),
+                                              _ptr(cuts), world, int(slot_capacity), int(input_capacity),
+                                              int(num_categories), _ptr(send_ids), _ptr(send_rows), _ptr(range_starts),
+                                              _ptr(flag), _stream(rows))
+
+
+def exchange_merge(ids, rows, num_categories, pad_lo, pad_len, out_ids, out_rows, tail, flag, count=None):
+    """The owner's fixed-capacity merge (extension): transpose_fixed_hotness(ids as n samples of hotness 1, remapped) +
+    embedding_backward(device-side row count, pad_to_capacity) into out_ids[capacity + 1] (int64) /
+    out_rows[capacity + 1, W] + cuembed::FinishOwnerPiece.  ids (int64) >= num_categories are padding and dropped.
+    Afterwards: the first *count entries are the ascending distinct ids and their summed rows, every entry past them a
+    zero row named pad_lo + i % pad_len; `tail` (int64[capacity + 2] or None) = the ids, min(count, capacity), the flag
+    word; flag |= 1 when count > capacity (nothing was written then).  Nothing read back."""
+    _check_dev("rows", rows)
+    dev = rows.device
+    for name, t in (("ids", ids), ("out_ids", out_ids), ("out_rows", out_rows), ("flag", flag)):
+        _check_dev(name, t, dev)
+    et = _elem_code("rows", rows)
+    n = ids.numel()
+    capacity = out_ids.numel() - 1
+    if ids.dtype != torch.int64 or out_ids.dtype != torch.int64 or flag.dtype != torch.int64:
+        raise TypeError("ids, out_ids and flag must be int64")
+    if n < 1 or rows.dim() != 2 or rows.shape[0] != n or not rows.is_contiguous() or not ids.is_contiguous():
+        raise ValueError("rows must be a contiguous [n, width] tensor with one contiguous id per row, n >= 1")
+    if capacity < 1 or out_rows.dtype != rows.dtype or tuple(out_rows.shape) != (capacity + 1, rows.shape[1]) or \
+            not out_rows.is_contiguous() or not out_ids.is_contiguous():
+        raise ValueError("out_ids / out_rows must be contiguous with capacity + 1 entries / rows")
+    if tail is not None and (tail.dtype != torch.int64 or tail.numel() != capacity + 2 or not tail.is_contiguous()):
+        raise ValueError("tail must be capacity + 2 contiguous int64 words")
+    if count is not None and (count.dtype != torch.int64 or not count.is_contiguous()):
+        raise ValueError("count must be a contiguous int64 word")
+    if pad_len < 1:
+        raise ValueError("pad_len must be at least 1")
+    t_ids, t_pos, _, remap = transpose_fixed_hotness(ids, n, 1, num_categories=num_categories + 1, remapped=True)
+    embedding_backward(rows, None, t_ids, t_pos, remap, grad_embedding=out_rows, inverse_mapping=out_ids,
+                       pad_to_capacity=True)
+    with torch.cuda.device(dev):
+        _lib.lib().cuembed_exchange_finish_piece(_ptr(t_ids), _ptr(remap), n, capacity, int(num_categories), int(pad_lo),
+                                                 int(pad_len), _ptr(out_ids), _ptr(out_rows), et, rows.shape[1],
+                                                 _ptr(tail), _ptr(flag), _ptr(count), _stream(rows))

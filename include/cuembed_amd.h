@@ -433,6 +433,35 @@ void cuembed_bag_order_by_length(const void* offsets, int offset_type, int batch
 void cuembed_set_backward_tuning(int segment_len, int column_slices);
 void cuembed_get_backward_tuning(int* out2);
 
+/* ---- multi-GPU: the device-side halves of the sparse gradient exchange (extensions) ------
+ * The reference is single-GPU (README.md:108-119: multi-device is future work).  A data-parallel step sums the ranks'
+ * compressed gradients with an owner-partitioned exchange of FIXED-size buffers (cuembed_amd/distributed.py:
+ * SparseGradExchange; the collectives are the caller's); these two calls are the index work around the collectives,
+ * without any read-back (cuembed::PackRowsByOwner / FinishOwnerPiece, exchange_transforms.hpp).
+ *
+ * cuembed_exchange_pack_rows: ids[num_rows] (index_type) ascending in their first *count entries (count: one device
+ * word of index_type; NULL = all), rows[num_rows, embed_width]; cuts[world + 1] device words (cuts[r] = first row id
+ * of owner r, cuts[world] = num_categories).  Slot r of send_ids[world * slot_capacity] /
+ * send_rows[world * slot_capacity, embed_width] gets the ids / rows of owner r's range, then the padding id
+ * num_categories.  range_starts[world + 1]: device scratch.  *flag |= 1 (a 64-bit device word the caller zeroes) when
+ * a range exceeds its slot or, with input_capacity > 0, *count exceeds input_capacity.  Two launches. */
+void cuembed_exchange_pack_rows(const void* ids, int index_type, const void* rows, int elem_type, int64_t num_rows,
+                                int embed_width, const void* count, const int64_t* cuts, int world,
+                                int64_t slot_capacity, int64_t input_capacity, int64_t num_categories,
+                                int64_t* send_ids, void* send_rows, int64_t* range_starts, int64_t* flag,
+                                cuembed_stream_t stream);
+/* cuembed_exchange_finish_piece: after the owner merged what it received -- cuembed_transpose_fixed_hotness_remapped
+ * (the received int64 ids as nnz samples of hotness 1, index bits of num_categories + 1) and
+ * cuembed_embedding_backward_bounded (capacity_rows = capacity + 1, pad_to_capacity) into ids[capacity + 1] /
+ * rows[capacity + 1, embed_width] -- this finishes the piece on the device: *count (may be NULL) = distinct real ids;
+ * the padding ids' run (or the spare last row) zeroed; ids behind the count = pad_lo + i % pad_len; and, when `tail`
+ * (capacity + 2 words) is given, the id buffer of the all-gather: the ids, min(count, capacity), *flag.
+ * *flag |= 1 when count > capacity (the merge then wrote nothing).  One launch. */
+void cuembed_exchange_finish_piece(const int64_t* sorted_ids, const int64_t* remapped_ids, int64_t nnz, int64_t capacity,
+                                   int64_t num_categories, int64_t pad_lo, int64_t pad_len, int64_t* ids, void* rows,
+                                   int elem_type, int embed_width, int64_t* tail, int64_t* flag, int64_t* count,
+                                   cuembed_stream_t stream);
+
 /* ---- introspection ------------------------------------------------------- */
 /* Launch shape the forward would use (no launch): out[0] = elements per lane,
  * out[1] = lanes per row, out[2] = samples per workgroup, out[3] = grid size,
