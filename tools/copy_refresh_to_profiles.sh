@@ -35,6 +35,17 @@ cp $S/traffic_c3.json profiles/traffic_c3.json
 for f in high_word_timing.jsonl high_word_stress.json row_loads_crossover.jsonl reference_sums_run_probe.txt exchange_device_time.json; do
   [ -f $S/$f ] && cp $S/$f profiles/${R}_$f
 done
+if [ -s $S/exchange_one_rank_rccl_kernel_trace_stats.txt ]; then
+  { cat <<'EOT'
+# rocprofv3 --kernel-trace --stats of tools/exchange_device_time.py: ONE rank over real RCCL (world size 1), the C4 gradient of
+# one GPU (572,029 compressed rows of 512 bytes): SparseGradExchange.start() + wait() (13 steps), the exact-size
+# allreduce_sparse_grad() (12 steps) and the pack / merge halves alone (13 each) in one process.  With one rank the
+# collectives are RCCL self-copies (rcclGenericKernel, copyBuffer: not what a link costs); everything else is the on-device
+# work of a step that DESIGN section 6's link model does not contain: OwnerRangeStartsKernel + PackRowsByOwnerKernel (pack),
+# three radix passes + SegmentedScatterAddKernel + FinishOwnerPieceKernel (the owner's merge).
+EOT
+    cat $S/exchange_one_rank_rccl_kernel_trace_stats.txt; } > profiles/${R}_exchange_one_rank_rccl_kernel_trace_stats.txt
+fi
 [ -f $S/sweep_parameters_cpp_binary.csv ] && cp $S/sweep_parameters_cpp_binary.csv profiles/${R}_sweep_parameters_cpp_binary_min_median_share.csv
 [ -f $S/bench_c2_eight_ranks_sharing_one_gpu.json ] && cp $S/bench_c2_eight_ranks_sharing_one_gpu.json profiles/${R}_bench_c2_eight_ranks_sharing_one_gpu.json
 ls -la profiles | grep ${R}

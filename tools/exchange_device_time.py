@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """What the fixed-capacity sparse exchange costs ON THE DEVICE besides the links: one rank over real RCCL (world size 1:
 the collectives degenerate to copies), the C4 gradient of one GPU (572 k compressed rows of 512 bytes).  The time of
-start() + wait() is then the pack (searchsorted + index_select into the slots), the owner's merge (Transpose +
-ComputeCompressedGradIndices + EmbeddingBackward with a device-side count) and the local copies -- the part that the
-link model of DESIGN section 6 does not contain.  With 8 ranks an owner merges 8 slots of ~89 k rows (about the same
+start() + wait() is then the pack (cuembed::PackRowsByOwner: two launches), the owner's merge (TransposeFixedHotness
+with the remap + EmbeddingBackward with a device-side count + cuembed::FinishOwnerPiece: one native op) and RCCL's
+local copies -- the pack and the merge are the part that the link model of DESIGN section 6 does not contain, and are
+timed on their own as well (`pack_ms`, `merge_ms`: what remains of the step is RCCL copying 366 MB to itself three
+times, which the links replace on a real node).  With 8 ranks an owner merges 8 slots of ~89 k rows (about the same
 number of rows as here).  One JSON line."""
 import json
 import os
@@ -46,6 +48,26 @@ def main():
     z.record()
     z.synchronize()
     fixed_ms = a.elapsed_time(z) / n
+    # the two native halves alone, on the exchange's own buffers (no collective in between)
+    ex = D._exchange_ops()
+
+    def pack():
+        ex.pack(inv, grad, count.reshape(-1), plan._cuts, plan.pair_capacity, 0, rows, plan._send_ids, plan._send_rows,
+                plan._starts, plan._flag)
+
+    def merge():
+        D._merge_fixed(plan._send_ids, plan._send_rows, rows, plan.piece_capacity, plan._lo, plan._range,
+                       plan._piece_ids, plan._piece_rows, plan._piece_tail, plan._flag)
+    parts = {}
+    for name, fn in (("pack_ms", pack), ("merge_ms", merge)):
+        for _ in range(3):
+            fn()
+        a.record()
+        for _ in range(n):
+            fn()
+        z.record()
+        z.synchronize()
+        parts[name] = round(a.elapsed_time(z) / n, 4)
     for _ in range(2):
         D.allreduce_sparse_grad(grad, inv, rows, algorithm="owner", num_unique=count)
     torch.cuda.synchronize()
@@ -57,6 +79,7 @@ def main():
     exact_ms = a.elapsed_time(z) / n
     print(json.dumps({"rows_per_rank": int(count.item()), "pair_capacity": plan.pair_capacity,
                       "piece_capacity": plan.piece_capacity, "fixed_capacity_exchange_device_ms": round(fixed_ms, 4),
+                      "pack_ms": parts["pack_ms"], "merge_ms": parts["merge_ms"],
                       "exact_size_exchange_ms_with_its_read_backs": round(exact_ms, 4), "world": 1, "backend": "nccl",
                       "overflowed": plan.overflowed()}))
     dist.destroy_process_group()

@@ -54,7 +54,7 @@ timeout 900 python tools/high_word_stress.py 120 > "$O/high_word_stress.json" 2>
 timeout 900 python tools/row_loads_crossover_probe.py > "$O/row_loads_crossover.jsonl" 2>> "$O/torch_probe.err"
 timeout 600 python tools/reference_sums_run_probe.py > "$O/reference_sums_run_probe.txt" 2>> "$O/torch_probe.err"
 timeout 600 python tools/reference_sums_timing.py >> "$O/reference_sums_run_probe.txt" 2>> "$O/torch_probe.err"
-timeout 600 python tools/exchange_device_time.py > "$O/exchange_device_time.json" 2>> "$O/torch_probe.err"
+timeout 600 python tools/exchange_device_time.py 2>> "$O/torch_probe.err" | grep '^{' > "$O/exchange_device_time.json"   # (RCCL prints its banner on stdout)
 # profiler passes last (they clock lower); the program goes directly after `--`
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-extras --no-c5 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
@@ -62,6 +62,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_pip
 cd "$R"
 timeout 900 python tools/rocprof_summary.py "$O/prof_bench" > "$O/bench_c2_kernel_trace_stats.txt" 2>/dev/null
 timeout 900 python tools/rocprof_summary.py "$O/prof_pipeline" > "$O/pipeline_c2_kernel_trace_stats.txt" 2>/dev/null
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_exchange" -- python3 "$R/tools/exchange_device_time.py" > "$O/prof_exchange.log" 2>&1)
+timeout 900 python tools/rocprof_summary.py "$O/prof_exchange" > "$O/exchange_one_rank_rccl_kernel_trace_stats.txt" 2>/dev/null
+rm -rf "$O/prof_exchange"
 rm -rf "$O/prof_bench" "$O/prof_pipeline"   # raw traces are large; the summaries stay
 # ---- counter passes (each counter set in its OWN run, never with another trace domain) -> traffic json
 cd /tmp
