@@ -105,16 +105,16 @@ def allreduce_dense_grad(grad_embedding, group=None, async_op=False):
 def _merge_on_gpu(ids, vals, num_categories):
     """Sum rows that carry the same id with the library's own kernels: the merge of the gathered
     (id, row) pairs IS an embedding backward -- Transpose sorts the ids (carrying the position of
-    each row), ComputeCompressedGradIndices numbers the distinct ids, and EmbeddingBackward adds
+    each row; TransposeFixedHotness with hotness 1), ComputeCompressedGradIndices numbers the distinct ids (from the same call), and EmbeddingBackward adds
     the rows of each run (fp32 partial sums) into the compressed result.
     Returns (ids[capacity], rows[capacity, W], count) with count a 1-element device tensor: the
     number of distinct ids stays on the device (EmbeddingBackward's num_grad_embedding_rows=None
     extension), so the merge itself has no host read-back."""
     from . import ops
     m = ids.numel()
-    pos = ops.extract_row_ids_for_concat(m, torch.int64, ids.device)
-    t_ids, t_pos, _ = ops.transpose(pos, ids.contiguous(), num_categories=num_categories, num_rows=m)
-    remap = ops.compute_compressed_grad_indices(t_ids)
+    # (hotness 1: the position of each row is generated by the first sorting pass, the compressed ids by the last)
+    t_ids, t_pos, _, remap = ops.transpose_fixed_hotness(ids.contiguous(), m, 1, num_categories=num_categories,
+                                                         remapped=True)
     cap = min(m, num_categories)
     merged = torch.empty((cap, vals.shape[1]), dtype=vals.dtype, device=vals.device)
     uniq = torch.empty((cap,), dtype=torch.int64, device=vals.device)
