@@ -79,3 +79,70 @@ def test_fwd_bwd_allreduce_world1(oracle):
         assert torch.equal(out2, out)
     finally:
         dist.destroy_process_group()
+
+
+def test_fixed_exchange_of_an_uncoalesced_gradient_world1():
+    """An UNCOALESCED gradient (sample blocks) in worst-case buffers with a device-side count through the fixed-capacity
+    exchange over RCCL: the rank's own rows are merged first, natively, inside the same step -- without a host wait; and
+    an exchange whose capacities do not fit: a sticky flag, a well-formed result, no overrun, no exception.
+    Integer-valued gradients: every sum is exact, whatever the order."""
+    import torch.distributed as dist
+    import cuembed_amd as ce
+    from cuembed_amd import distributed as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ncat, W, B, H, blocks = 30_000, 64, 16384, 12, 2
+        g = torch.Generator(device="cpu").manual_seed(5)
+        idx = (torch.rand((B * H,), generator=g) ** 3 * ncat).to(torch.int32).clamp_(max=ncat - 1).cuda()
+        gy = torch.randint(-3, 4, (B, W), generator=g).half().cuda()
+        sid = ce.extract_row_ids_from_fixed(B, H, torch.int32, "cuda")
+        want = torch.zeros((ncat, W), dtype=torch.float32, device="cuda")
+        want.index_add_(0, idx.long(), gy.float()[sid.long()])
+        b_ti, b_ts, _, b_remap = ce.transpose_fixed_hotness(idx, B, H, num_categories=ncat, sample_blocks=blocks,
+                                                            remapped=True)
+        assert ce.transpose_sample_block_length(B * H, blocks) < B * H            # really two blocks
+        u_cap = B * H
+        u_rows = torch.zeros((u_cap, W), dtype=torch.float16, device="cuda")
+        u_inv = torch.zeros((u_cap,), dtype=torch.int32, device="cuda")
+        u_count = b_remap[-1:] + 1
+        ce.embedding_backward(gy, None, b_ti, b_ts, b_remap, grad_embedding=u_rows, inverse_mapping=u_inv)
+        k = int(u_count.item())
+        distinct = int(torch.unique(idx).numel())
+        assert distinct < k <= blocks * distinct                                   # some rows are there once per block
+        ex = D.SparseGradExchange.calibrate(u_rows, u_inv, ncat, count=u_count, coalesced=False)
+        assert ex.input_capacity < u_cap
+        ex.start(u_rows, u_inv, count=u_count, coalesced=False).wait()
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(2):
+                pending = ex.start(u_rows, u_inv, count=u_count, coalesced=False)
+                ids_all, rows_all, counts = pending.wait()
+                ex.note_flags(pending)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert not ex.overflowed()
+        assert int(counts.sum().item()) == distinct
+        got_ids, got_rows = ex.compact(ids_all, rows_all, counts)
+        assert bool((got_ids[1:] > got_ids[:-1]).all())
+        rebuilt = torch.zeros((ncat, W), dtype=torch.float32, device="cuda")
+        rebuilt[got_ids] = got_rows.float()
+        assert torch.equal(rebuilt, want)
+        # as it comes (zero rows with valid ids fill the slack) it is the same gradient
+        as_is = torch.zeros((ncat, W), dtype=torch.float32, device="cuda").index_add_(0, ids_all, rows_all.float())
+        assert torch.equal(as_is, want)
+        # capacities that do not fit, one at a time and all together
+        fits = dict(pair_capacity=ex.pair_capacity, piece_capacity=ex.piece_capacity, local_capacity=ex.local_capacity,
+                    input_capacity=ex.input_capacity)
+        for tight in ({"pair_capacity": distinct // 4}, {"piece_capacity": distinct // 4}, {"local_capacity": distinct // 4},
+                      {"input_capacity": k // 2},
+                      {"pair_capacity": 7, "piece_capacity": 5, "local_capacity": 3, "input_capacity": 11}):
+            small = D.SparseGradExchange(ncat, W, torch.float16, torch.device("cuda"), **dict(fits, **tight))
+            pending = small.start(u_rows, u_inv, count=u_count, coalesced=False, async_op=False)
+            ids_s, rows_s, _ = pending.wait()
+            assert small.overflowed(reset=True) and not small.overflowed(), tight
+            assert bool(((ids_s >= 0) & (ids_s < ncat)).all()) and bool(torch.isfinite(rows_s.float()).all()), tight
+    finally:
+        dist.destroy_process_group()
