@@ -7,12 +7,15 @@
 //   * RowPool::Gather                : every lookup pooled exactly once and IN ORDER for every count around the unroll
 //                                      and pipelining boundaries (0 .. 40 lookups), plain and weighted, both load kinds;
 //   * FinishPooledRow                : mean = multiply by the reciprocal of the weight sum, zeros for an empty bag;
-//   * AccumulateRow                  : the backward's fp32 partial sums of fp16 rows, weighted and not.
+//   * AccumulateRow                  : the backward's fp32 partial sums of fp16 rows, weighted and not;
+//   * PackRowsByOwner / FinishOwnerPiece (exchange_transforms.hpp, the header API itself): range starts, slots, padding
+//                                      ids, untouched slack, the flag word; the piece's count, zeroed row, tail.
 // Small kernels instantiate the blocks directly (one wavefront each); the host recomputes with the same
 // single-rounding operations (Arith is __host__ __device__) and compares BITS.  Built by cuembed_amd.build, run by
 // tests/test_gpu_device_blocks.py (-m gpu).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +24,7 @@
 #include <vector>
 
 #include "cuembed/include/embedding_lookup.hpp"
+#include "cuembed/include/exchange_transforms.hpp"
 
 using namespace cuembed::detail;
 
@@ -248,6 +252,101 @@ static void BackwardPartialSums(const char* name) {
   }
 }
 
+// ---- the exchange's device-side halves ---------------------------------------------------------------------------------
+template <typename IndexT>
+static void ExchangePack(const char* name, const int world, const int64_t n, const int64_t slot, const int64_t given,
+                         const int width) {
+  std::mt19937_64 rng(91 + world + n);
+  const int64_t num_categories = 40000;
+  std::vector<IndexT> ids(n);
+  {   // ascending, distinct
+    std::vector<int64_t> pool(num_categories);
+    for (int64_t i = 0; i < num_categories; ++i) pool[i] = i;
+    for (int64_t i = 0; i < n; ++i) std::swap(pool[i], pool[i + rng() % (num_categories - i)]);
+    std::sort(pool.begin(), pool.begin() + n);
+    for (int64_t i = 0; i < n; ++i) ids[i] = static_cast<IndexT>(pool[i]);
+  }
+  std::vector<float> rows(n * width);
+  for (auto& x : rows) x = static_cast<float>(static_cast<int>(rng() % 17) - 8);
+  std::vector<int64_t> cuts(world + 1);
+  for (int r = 0; r <= world; ++r) cuts[r] = num_categories * r / world;
+  const int64_t valid = given < 0 ? n : std::min(given, n);
+  const DeviceArray<IndexT> d_ids(ids);
+  const DeviceArray<float> d_rows(rows);
+  const DeviceArray<int64_t> d_cuts(cuts);
+  const std::vector<IndexT> count_word(1, static_cast<IndexT>(given));
+  const DeviceArray<IndexT> d_count(count_word);
+  DeviceArray<int64_t> d_send_ids(std::vector<int64_t>(world * slot, -7));
+  DeviceArray<float> d_send_rows(std::vector<float>(world * slot * width, 3.0f));
+  DeviceArray<int64_t> d_starts(std::vector<int64_t>(world + 1, -1));
+  DeviceArray<int64_t> d_flag(std::vector<int64_t>(1, 0));
+  cuembed::PackRowsByOwner<IndexT, float>(d_ids.ptr, d_rows.ptr, n, width, given < 0 ? nullptr : d_count.ptr, d_cuts.ptr,
+                                          world, slot, 0, num_categories, d_send_ids.ptr, d_send_rows.ptr, d_starts.ptr,
+                                          d_flag.ptr, nullptr);
+  HIP_OK(hipDeviceSynchronize());
+  const auto send_ids = d_send_ids.Download();
+  const auto send_rows = d_send_rows.Download();
+  const auto starts = d_starts.Download();
+  bool too_many = false;
+  for (int r = 0; r < world; ++r) {
+    const int64_t lo = std::lower_bound(ids.begin(), ids.begin() + valid, static_cast<IndexT>(cuts[r])) - ids.begin();
+    const int64_t hi = r + 1 == world ? valid
+                                      : std::lower_bound(ids.begin(), ids.begin() + valid, static_cast<IndexT>(cuts[r + 1])) - ids.begin();
+    CHECK(starts[r] == lo, "%s: range %d starts at %lld, host %lld", name, r, (long long)starts[r], (long long)lo);
+    too_many = too_many || hi - lo > slot;
+    for (int64_t j = 0; j < slot; ++j) {
+      const bool real = j < hi - lo;
+      const int64_t want_id = real ? static_cast<int64_t>(ids[lo + j]) : num_categories;
+      CHECK(send_ids[r * slot + j] == want_id, "%s: slot %d entry %lld holds id %lld, host %lld", name, r, (long long)j,
+            (long long)send_ids[r * slot + j], (long long)want_id);
+      for (int c = 0; c < width; ++c) {
+        const float got = send_rows[(r * slot + j) * width + c];
+        const float want = real ? rows[(lo + j) * width + c] : 3.0f;      // slack: not written
+        CHECK(got == want, "%s: slot %d entry %lld column %d: %g, host %g", name, r, (long long)j, c, got, want);
+      }
+    }
+  }
+  CHECK(starts[world] == valid, "%s: the last start is the count", name);
+  CHECK(d_flag.Download()[0] == (too_many ? 1 : 0), "%s: flag word", name);
+}
+
+static void ExchangeFinish(const char* name, const int64_t distinct, const int64_t padding, const int64_t capacity) {
+  // what the owner's merge leaves: sorted ids (padding id last), their compressed ids, ids / rows from EmbeddingBackward
+  const int64_t num_categories = 1000, pad_lo = 250, pad_len = 7;
+  const int width = 24;
+  std::vector<int64_t> sorted, remap;
+  for (int64_t u = 0; u < distinct; ++u)
+    for (int rep = 0; rep <= u % 3; ++rep) { sorted.push_back(3 * u + 1); remap.push_back(u); }
+  for (int64_t k = 0; k < padding; ++k) { sorted.push_back(num_categories); remap.push_back(distinct); }
+  const int64_t nnz = static_cast<int64_t>(sorted.size());
+  std::vector<int64_t> ids(capacity + 1, 555);
+  std::vector<float> rows((capacity + 1) * width, 2.0f);
+  const bool fits = distinct + (padding > 0 ? 1 : 0) <= capacity + 1;
+  if (fits) for (int64_t u = 0; u < distinct; ++u) ids[u] = 3 * u + 1;     // (the merge wrote its rows)
+  DeviceArray<int64_t> d_sorted(sorted), d_remap(remap), d_ids(ids), d_tail(std::vector<int64_t>(capacity + 2, -1));
+  DeviceArray<float> d_rows(rows);
+  DeviceArray<int64_t> d_flag(std::vector<int64_t>(1, 0)), d_count(std::vector<int64_t>(1, -1));
+  cuembed::FinishOwnerPiece<float>(d_sorted.ptr, d_remap.ptr, nnz, capacity, num_categories, pad_lo, pad_len, d_ids.ptr,
+                                   d_rows.ptr, width, d_tail.ptr, d_flag.ptr, d_count.ptr, nullptr);
+  HIP_OK(hipDeviceSynchronize());
+  const auto got_ids = d_ids.Download();
+  const auto got_rows = d_rows.Download();
+  const auto tail = d_tail.Download();
+  const bool overflow = distinct > capacity;
+  CHECK(d_count.Download()[0] == distinct, "%s: count %lld, host %lld", name, (long long)d_count.Download()[0], (long long)distinct);
+  CHECK(d_flag.Download()[0] == (overflow ? 1 : 0), "%s: flag", name);
+  const int64_t zeroed = std::min(padding > 0 ? distinct : capacity, capacity);
+  for (int64_t i = 0; i <= capacity; ++i) {
+    const int64_t want = i < distinct ? ids[i] : pad_lo + i % pad_len;
+    CHECK(got_ids[i] == want, "%s: id %lld is %lld, host %lld", name, (long long)i, (long long)got_ids[i], (long long)want);
+    if (i < capacity) CHECK(tail[i] == want, "%s: tail id %lld", name, (long long)i);
+    for (int c = 0; c < width; ++c)
+      CHECK(got_rows[i * width + c] == (i == zeroed ? 0.0f : 2.0f), "%s: row %lld column %d is %g", name, (long long)i, c,
+            got_rows[i * width + c]);
+  }
+  CHECK(tail[capacity] == std::min(distinct, capacity) && tail[capacity + 1] == (overflow ? 1 : 0), "%s: tail words", name);
+}
+
 int main() {
   Addressing<float, int32_t>("f32 rows, i32 ids");
   Addressing<float, int64_t>("f32 rows, i64 ids");
@@ -266,6 +365,15 @@ int main() {
   BackwardPartialSums<_Float16, 8, false>("fp16 grad_y rows, fp32 partial sums");
   BackwardPartialSums<_Float16, 8, true>("fp16 grad_y rows x weight, fp32 partial sums");
   BackwardPartialSums<float, 4, true>("fp32 grad_y rows x weight");
+  ExchangePack<int32_t>("pack: 8 owners, i32 ids", 8, 5000, 700, -1, 16);
+  ExchangePack<int64_t>("pack: 3 owners, i64 ids, a device-side count", 3, 4000, 1500, 3100, 5);
+  ExchangePack<int64_t>("pack: a slot that overflows", 4, 3000, 600, -1, 8);
+  ExchangePack<int32_t>("pack: nothing valid", 5, 64, 16, 0, 4);
+  ExchangePack<int32_t>("pack: one owner, 1 KiB rows", 1, 300, 512, 257, 256);
+  ExchangeFinish("finish: padding run present", 40, 13, 64);
+  ExchangeFinish("finish: no padding, exactly full", 64, 0, 64);
+  ExchangeFinish("finish: overflow", 70, 5, 64);
+  ExchangeFinish("finish: one row", 1, 900, 4);
   if (g_fail != 0) {
     std::fprintf(stderr, "%d device building-block checks FAILED\n", g_fail);
     return 1;

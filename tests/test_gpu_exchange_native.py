@@ -93,6 +93,33 @@ def test_pack_keeps_a_raised_flag_and_takes_an_empty_gradient():
     assert bool((send_ids == num_categories).all()) and bool((starts == 0).all())
 
 
+@pytest.mark.parametrize("shift_elems,width", [(4, 256), (2, 256), (1, 256), (1, 33), (3, 8)])
+def test_pack_takes_rows_at_any_alignment(shift_elems, width):
+    """rows / send_rows that start 8, 4 or 2 bytes into an allocation: the copy falls back to narrower pieces."""
+    pack, _ = _backends()["torch_op"]
+    rng = np.random.default_rng(5)
+    num_categories, world, n, slot = 10_000, 3, 2000, 900
+    ids = np.sort(rng.choice(num_categories, size=n, replace=False)).astype(np.int64)
+    rows = rng.integers(-8, 9, size=(n, width)).astype(np.float32)
+    cuts = _cuts(num_categories, world)
+    base = torch.zeros((n * width + 16,), dtype=torch.float16, device="cuda")
+    d_rows = base[shift_elems: shift_elems + n * width].view(n, width)
+    d_rows.copy_(torch.from_numpy(rows))
+    out_base = torch.full((world * slot * width + 16,), 3.0, dtype=torch.float16, device="cuda")
+    send_rows = out_base[shift_elems: shift_elems + world * slot * width].view(world * slot, width)
+    send_ids = torch.zeros((world * slot,), dtype=torch.int64, device="cuda")
+    starts = torch.zeros((world + 1,), dtype=torch.int64, device="cuda")
+    flag = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    pack(torch.from_numpy(ids).cuda(), d_rows, None, torch.from_numpy(cuts).cuda(), slot, 0, num_categories, send_ids,
+         send_rows, starts, flag)
+    e_ids, e_rows, written, _, e_flag = _pack_expected(ids, rows, None, cuts, slot, 0, num_categories)
+    assert np.array_equal(send_ids.cpu().numpy(), e_ids) and int(flag.item()) == e_flag
+    got = send_rows.float().cpu().numpy()
+    assert np.array_equal(got[written], e_rows[written]) and np.all(got[~written] == 3.0)
+    edge = out_base.float().cpu().numpy()
+    assert np.all(edge[:shift_elems] == 3.0) and np.all(edge[shift_elems + world * slot * width:] == 3.0)
+
+
 def _merge_expected(ids, rows, num_categories, capacity, pad_lo, pad_len, before_ids, before_rows):
     keep = ids < num_categories
     uniq, inverse = np.unique(ids[keep], return_inverse=True)
