@@ -391,6 +391,9 @@ class SparseGradExchange:
     local_capacity: distinct rows of this rank's own gradient after its local merge (coalesced=False only);
     input_capacity: rows of the caller's buffers that are looked at when a device-side `count` is given (the valid rows
                     are a prefix; buffers sized for the worst case are cut there).
+    gather_group  : (optional) a second process group over the same ranks for the all-gathers: a group runs its
+                    collectives in issue order, so with one group the next step's all-to-all queues behind this step's
+                    all-gather; with two, all-to-all + merge of step i + 1 overlap the pieces of step i on the links.
     Sized by hand or by calibrate() from a warm-up step.  A step that does not fit raises the sticky overflow word on
     EVERY rank (it travels with the all-gather) and delivers a well-formed but incomplete gradient: look at
     overflowed() whenever a host wait is affordable (every few hundred steps, or at the step where the loss is read
@@ -406,9 +409,16 @@ class SparseGradExchange:
     """
 
     def __init__(self, num_categories, width, dtype, device, pair_capacity, piece_capacity, local_capacity=0,
-                 group=None, input_capacity=0):
+                 group=None, input_capacity=0, gather_group=None):
         import torch.distributed as dist
         self.group = group
+        # A process group executes its collectives in issue order, so with ONE group the all-to-all of step i + 1 waits
+        # for the all-gather of step i (the longest transfer of the step) although nothing in it depends on that.
+        # gather_group: a second group over the same ranks (dist.new_group()) for the all-gathers -- the all-to-all and
+        # the owner's merge of the next step then run while the pieces of this one are still on the links.
+        self.gather_group = group if gather_group is None else gather_group
+        if dist.get_world_size(self.gather_group) != dist.get_world_size(group):
+            raise ValueError("gather_group must span the same ranks as group")
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.num_categories, self.width, self.dtype, self.device = int(num_categories), int(width), dtype, device
@@ -435,9 +445,11 @@ class SparseGradExchange:
         self._recv_ids = torch.empty((w * s,), dtype=torch.int64, device=device)
         self._recv_rows = torch.empty((w * s, self.width), dtype=dtype, device=device)
         # (zero-initialised ONCE: a step that overflows leaves them as they were -- finite rows, valid ids)
-        self._piece_rows = torch.zeros((p + 1, self.width), dtype=dtype, device=device)
-        self._piece_ids = torch.zeros((p + 1,), dtype=torch.int64, device=device)
-        self._piece_tail = torch.zeros((p + 2,), dtype=torch.int64, device=device)    # ids, count, overflow word
+        # two sets of piece buffers, used in turn like the result buffers: the all-gather of step i may still read one
+        # while the merge of step i + 1 fills the other (rows, ids, [ids | count | overflow word])
+        self._piece = [(torch.zeros((p + 1, self.width), dtype=dtype, device=device),
+                        torch.zeros((p + 1,), dtype=torch.int64, device=device),
+                        torch.zeros((p + 2,), dtype=torch.int64, device=device)) for _ in range(2)]
         self._local_rows = self._local_ids = None
         if self.local_capacity:
             self._local_rows = torch.zeros((self.local_capacity + 1, self.width), dtype=dtype, device=device)
@@ -446,12 +458,13 @@ class SparseGradExchange:
         self._out = [(torch.zeros((w * (p + 2),), dtype=torch.int64, device=device),
                       torch.zeros((w * p, self.width), dtype=dtype, device=device)) for _ in range(2)]
         self._turn = 0
-        self._pending = None           # the last step's result while its all-gather may still read the piece buffers
+        self._pending = [None, None]   # per set of piece buffers: the result whose all-gather may still read it
         self._overflow = torch.zeros((1,), dtype=torch.int64, device=device)      # sticky, all ranks' words OR-ed
 
     # -- sizes ----------------------------------------------------------------------------------------------------
     @classmethod
-    def calibrate(cls, rows, inverse_mapping, num_categories, count=None, coalesced=True, group=None, headroom=1.25):
+    def calibrate(cls, rows, inverse_mapping, num_categories, count=None, coalesced=True, group=None, headroom=1.25,
+                  gather_group=None):
         """Warm-up: looks at THIS step's sizes on the host (read-backs, an exchange of the ids alone) and returns an
         exchange whose capacities are `headroom` x the largest slot / piece / local gradient any rank needs for it."""
         import torch.distributed as dist
@@ -478,7 +491,7 @@ class SparseGradExchange:
         def grow(n):
             return max(int(n * headroom) + 16, 16)
         return cls(num_categories, rows.shape[1], rows.dtype, rows.device, grow(pair), grow(piece),
-                   0 if coalesced else grow(local), group=group, input_capacity=grow(given))
+                   0 if coalesced else grow(local), group=group, input_capacity=grow(given), gather_group=gather_group)
 
     def overflowed(self, reset=False):
         """True when a step since the last reset did not fit the capacities on SOME rank (one host read-back)."""
@@ -499,11 +512,7 @@ class SparseGradExchange:
         returns a SparseGradResult.  Nothing in here waits for the device."""
         import torch.distributed as dist
         dev, w, s, p = self.device, self.world, self.pair_capacity, self.piece_capacity
-        if self._pending is not None:
-            # the previous step's all-gather reads the piece buffers this step is about to rewrite: order behind it
-            # (a stream-side wait; a caller that already waited pays nothing)
-            self._pending.wait()
-            self._pending = None
+        turn = self._turn
         flag = self._flag
         flag.zero_()
         check = 0            # (input_capacity when the buffers are cut there: the pack then flags a count beyond it)
@@ -541,18 +550,25 @@ class SparseGradExchange:
         _all_to_all_equal(self._recv_rows, send_rows, self.group)
         # ---- merge my range into the piece (fixed capacity, device-side count; the piece's id buffer carries the
         #      count and the overflow word in-band)
-        _merge_fixed(self._recv_ids, self._recv_rows, self.num_categories, p, self._lo, self._range, self._piece_ids,
-                     self._piece_rows, self._piece_tail, flag)
+        if self._pending[turn] is not None:
+            # the all-gather of two steps ago read the piece buffers this merge is about to rewrite: order behind it (a
+            # stream-side wait; a caller that already waited pays nothing).  Only the merge: the pack and the all-to-all
+            # above touch neither the pieces nor the results.
+            self._pending[turn].wait()
+            self._pending[turn] = None
+        piece_rows, piece_ids, piece_tail = self._piece[turn]
+        _merge_fixed(self._recv_ids, self._recv_rows, self.num_categories, p, self._lo, self._range, piece_ids,
+                     piece_rows, piece_tail, flag)
         # ---- all-gather of the fixed-size pieces (ids carry count and overflow word in-band)
-        out_tail, out_rows = self._out[self._turn]
+        out_tail, out_rows = self._out[turn]
         self._turn ^= 1
-        works = [_all_gather_into(out_tail, self._piece_tail, self.group, async_op),
-                 _all_gather_into(out_rows, self._piece_rows[:p], self.group, async_op)]
+        works = [_all_gather_into(out_tail, piece_tail, self.gather_group, async_op),
+                 _all_gather_into(out_rows, piece_rows[:p], self.gather_group, async_op)]
         result = SparseGradResult([x for x in works if x is not None], out_tail, out_rows, p, w)
         if not async_op:
             self.note_flags(result)
         else:
-            self._pending = result
+            self._pending[turn] = result
         return result
 
     def _pack_on_host(self, inverse_mapping, rows, count, coalesced, check, flag):

@@ -177,6 +177,26 @@ def _worker(rank, world, port, csr, ret):
         pending = small.start(torch.from_numpy(comp), torch.from_numpy(inv), async_op=False)
         ids_all, rows_all, counts = pending.wait()
         assert small.overflowed() and int(ids_all.min()) >= 0 and int(ids_all.max()) < ncat
+        # ... pipelined: the all-gathers on a second group over the same ranks, three steps in flight back to back with
+        # DIFFERENT gradients (scaled by the step) -- each result must be its own step's (two sets of piece and result
+        # buffers used in turn; a result stays valid until the start() after the next one)
+        piped = D.SparseGradExchange.calibrate(torch.from_numpy(comp), torch.from_numpy(inv), ncat,
+                                               gather_group=dist.new_group())
+        with _no_host_reads():
+            results, previous = [], None
+            for step in range(4):
+                pending = piped.start(torch.from_numpy(comp_pad * (step + 1)), torch.from_numpy(inv_pad),
+                                      count=torch.tensor([nu]))
+                if previous is not None:
+                    ids_p, rows_p, _ = previous.wait()
+                    piped.note_flags(previous)
+                    results.append(torch.zeros_like(want_dense).index_add_(0, ids_p, rows_p))
+                previous = pending
+            ids_p, rows_p, _ = previous.wait()
+            results.append(torch.zeros_like(want_dense).index_add_(0, ids_p, rows_p))
+        for step, got in enumerate(results):
+            assert torch.equal(got, want_dense * (step + 1)), ("pipelined", step)
+        assert not piped.overflowed()
         # ... and nothing to exchange at all
         pending = ex.start(torch.empty((0, W)), torch.empty((0,), dtype=torch.int64))
         ids_all, rows_all, counts = pending.wait()

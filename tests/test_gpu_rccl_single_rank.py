@@ -77,6 +77,29 @@ def test_fwd_bwd_allreduce_world1(oracle):
         got_ids, got_rows = ex.compact(ids_all, rows_all, counts)
         assert torch.equal(got_ids, want_ids.long()) and torch.equal(got_rows, want_rows)
         assert torch.equal(out2, out)
+        # the all-gathers on a second RCCL communicator (the next step's all-to-all does not queue behind them), steps
+        # back to back with different gradients: every result is its own step's
+        piped = D.SparseGradExchange.calibrate(rows, inv, ncat, gather_group=dist.new_group())
+        piped.start(rows, inv).wait()
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            got, previous = [], None
+            for step in range(4):
+                pending = piped.start(rows * (step + 1), inv)
+                if previous is not None:
+                    ids_p, rows_p, _ = previous.wait()
+                    piped.note_flags(previous)
+                    got.append(torch.zeros((ncat, W), dtype=torch.float32, device="cuda").index_add_(0, ids_p, rows_p.float()))
+                previous = pending
+            ids_p, rows_p, _ = previous.wait()
+            got.append(torch.zeros((ncat, W), dtype=torch.float32, device="cuda").index_add_(0, ids_p, rows_p.float()))
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        for step, g in enumerate(got):
+            sent = (rows * (step + 1)).float()          # (what start() was handed, fp16 product included)
+            assert torch.equal(g, torch.zeros_like(g).index_add_(0, inv.long(), sent)), step
+        assert not piped.overflowed() and bool(got[0].any())
     finally:
         dist.destroy_process_group()
 

@@ -56,8 +56,9 @@ def main():
                 plan._starts, plan._flag)
 
     def merge():
+        piece_rows, piece_ids, piece_tail = plan._piece[0]
         D._merge_fixed(plan._send_ids, plan._send_rows, rows, plan.piece_capacity, plan._lo, plan._range,
-                       plan._piece_ids, plan._piece_rows, plan._piece_tail, plan._flag)
+                       piece_ids, piece_rows, piece_tail, plan._flag)
     parts = {}
     for name, fn in (("pack_ms", pack), ("merge_ms", merge)):
         for _ in range(3):
