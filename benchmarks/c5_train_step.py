@@ -101,10 +101,13 @@ class TrainStep:
         return plan.start(self.comp_rows, self.comp_inv, count=self.count,
                           coalesced=self.order != "blocked_uncoalesced")
 
-    def calibrate_exchange(self, D, headroom=1.25):
-        """(warm-up, after a compute()) capacities for exchange_fixed from this step's sizes; reads them back."""
+    def calibrate_exchange(self, D, headroom=1.25, gather_group=None):
+        """(warm-up, after a compute()) capacities for exchange_fixed from this step's sizes; reads them back.
+        gather_group: a second process group for the all-gathers (SparseGradExchange: the next step's all-to-all then
+        does not queue behind this step's pieces)."""
         return D.SparseGradExchange.calibrate(self.comp_rows, self.comp_inv, self.rows, count=self.count,
-                                              coalesced=self.order != "blocked_uncoalesced", headroom=headroom)
+                                              coalesced=self.order != "blocked_uncoalesced", headroom=headroom,
+                                              gather_group=gather_group)
 
     def exchanged_bytes(self):
         """(after a step) gradient bytes this rank puts on the wire: rows x (W x elem + 8-byte id) -- one read-back"""
