@@ -6,7 +6,7 @@ key / row bounds; the fused fixed-hotness variant; signed keys and arbitrary pay
 remap, EmbeddingBackward dense and compressed (exact on small-integer gradients), the compressed backward with
 num_unique left on the device, Transpose in sample blocks + the uncoalesced compressed gradient it leads to, and the
 reference's compressed gradient computed from that blocked order (ComputeCompressedGradIndicesBlocked +
-EmbeddingBackward(sample_blocks)).
+EmbeddingBackward(sample_blocks)), and the device-side halves of the multi-GPU sparse gradient exchange against numpy.
 
     python tools/fuzz_parity.py [--seconds 300] [--seed 0]
 
@@ -206,7 +206,70 @@ def one_case(rng, ce, O, np, torch, verbose=False):
                                                  block_row_ids=table)
                 assert np.array_equal(cc.float().cpu().numpy(), want_c), ("blocked coalesced backward", P, desc)
                 assert np.array_equal(cinv.cpu().numpy(), want_inv), ("blocked coalesced inverse mapping", P, desc)
+    exchange_case(rng, ce, np, torch, elem, idx_t, W, ncat, desc)
     return desc
+
+
+def exchange_case(rng, ce, np, torch, elem, idx_t, W, ncat, desc):
+    """The device-side halves of the sparse gradient exchange (PackRowsByOwner, the owner's fixed-capacity merge with
+    FinishOwnerPiece) against numpy: random owners, slot and piece capacities (fitting and not), device-side counts."""
+    from cuembed_amd import ops
+    world = int(rng.integers(1, 10))
+    n = int(rng.integers(0, min(ncat, 30000) + 1))
+    ids = np.sort(rng.choice(ncat, size=n, replace=False)).astype(idx_t)
+    rows = rng.integers(-4, 5, size=(n, W)).astype(elem)
+    count = None if rng.integers(0, 3) == 0 else int(rng.integers(0, n + 2))
+    valid = n if count is None else min(count, n)
+    slot = max(1, int(rng.integers(1, 2 * (n // world + 2))))
+    cuts = np.array([ncat * r // world for r in range(world)] + [ncat], dtype=np.int64)
+    send_ids = torch.full((world * slot,), -1, dtype=torch.int64, device="cuda")
+    send_rows = torch.zeros((world * slot, W), dtype=torch.from_numpy(rows).dtype, device="cuda")
+    starts = torch.zeros((world + 1,), dtype=torch.int64, device="cuda")
+    flag = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    d_count = None if count is None else torch.tensor([count], dtype=torch.from_numpy(ids).dtype, device="cuda")
+    ops.exchange_pack_rows(torch.from_numpy(ids).cuda(), torch.from_numpy(rows).cuda().reshape(n, W), d_count, dev(cuts),
+                           slot, 0, ncat, send_ids, send_rows, starts, flag)
+    pos = np.searchsorted(ids[:valid], cuts, side="left")
+    want_ids = np.full((world * slot,), ncat, dtype=np.int64)
+    want_rows = np.zeros((world * slot, W), dtype=np.float32)
+    over = False
+    for r in range(world):
+        take = min(int(pos[r + 1] - pos[r]), slot)
+        over = over or pos[r + 1] - pos[r] > slot
+        want_ids[r * slot: r * slot + take] = ids[pos[r]: pos[r] + take]
+        want_rows[r * slot: r * slot + take] = rows[pos[r]: pos[r] + take]
+    what = dict(desc, world=world, n=n, count=count, slot=slot)
+    assert np.array_equal(starts.cpu().numpy(), pos), ("exchange pack: range starts", what)
+    assert np.array_equal(send_ids.cpu().numpy(), want_ids), ("exchange pack: ids", what)
+    assert np.array_equal(send_rows.float().cpu().numpy(), want_rows), ("exchange pack: rows", what)   # (slack: still zero)
+    assert int(flag.item()) == int(over), ("exchange pack: flag", what)
+    # the owner's merge of what one rank "received": several copies of the slots, so that ids repeat
+    copies = int(rng.integers(1, 4))
+    got_ids = send_ids.repeat(copies)
+    got_rows = send_rows.repeat(copies, 1)
+    real = want_ids[want_ids < ncat]
+    distinct = np.unique(real).shape[0]
+    capacity = max(1, distinct + int(rng.integers(-2, 6)))
+    out_ids = torch.zeros((capacity + 1,), dtype=torch.int64, device="cuda")
+    out_rows = torch.zeros((capacity + 1, W), dtype=send_rows.dtype, device="cuda")
+    tail = torch.zeros((capacity + 2,), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    flag.zero_()
+    pad_lo, pad_len = int(cuts[world // 2]), max(1, int(cuts[world // 2 + 1] - cuts[world // 2]))
+    ops.exchange_merge(got_ids, got_rows, ncat, pad_lo, pad_len, out_ids, out_rows, tail, flag, cnt)
+    assert int(cnt.item()) == distinct, ("exchange merge: count", what)
+    assert int(flag.item()) == int(distinct > capacity), ("exchange merge: flag", what)
+    t = tail.cpu().numpy()
+    assert t[capacity] == min(distinct, capacity) and t[capacity + 1] == int(distinct > capacity), ("exchange merge: tail", what)
+    if distinct <= capacity:
+        uniq, inverse = np.unique(real, return_inverse=True)
+        sums = np.zeros((capacity + 1, W), dtype=np.float64)
+        np.add.at(sums, inverse, want_rows[want_ids < ncat].astype(np.float64) * copies)
+        e_ids = pad_lo + np.arange(capacity + 1, dtype=np.int64) % pad_len
+        e_ids[:distinct] = uniq
+        assert np.array_equal(out_ids.cpu().numpy(), e_ids), ("exchange merge: ids", what)
+        assert np.array_equal(out_rows.float().cpu().numpy(), sums.astype(np.float32)), ("exchange merge: rows", what)
+        assert np.array_equal(t[:capacity], e_ids[:capacity]), ("exchange merge: tail ids", what)
 
 
 def run(seconds=60.0, seed=0, max_cases=None, verbose=False):
