@@ -335,8 +335,8 @@ void EmbeddingBackward(const GradT* grad_y,
  * flush: identical on exactly representable data, closer to the true sum otherwise.)  A rounding chain cannot be cut
  * into partial sums, so one run is ONE chain of dependent additions (the hottest row of the C4 batch: 65,528 of them);
  * short runs are walked by one lane group each, runs of more than 256 lookups by a whole workgroup whose gather groups
- * stage the rows in LDS while one wavefront runs the chain out of it.  C4: 1.8 ms in fp16 (6 x the default path's 0.29 ms
- * on the same data; 26.4 ms before the long-run path), 2.9 ms in fp32 (5 x).  skip_grad_init = true ADDS to what grad_embedding holds, like the
+ * stage the rows in LDS while one wavefront runs the chain out of it.  C4: 1.2 ms in fp16 (4.5 x the default path's 0.26 ms
+ * on the same data; 26.4 ms before the long-run path), 1.8 ms in fp32 (3.4 x).  skip_grad_init = true ADDS to what grad_embedding holds, like the
  * reference's loop on a buffer the caller did not zero.
  */
 template <typename GradT, typename IndexT>

@@ -650,16 +650,20 @@ ZeroSharedAndTailRowsKernel(const IndexT* __restrict__ rows, const int64_t nnz, 
 //! (embedding_lookup_cpu.hpp:131-143) -- so the result is bit-identical to it for ANY data.  A rounding chain cannot be
 //! cut into partial sums, hence one run = one chain whatever its length: the hottest row of the C4 batch is 65,528
 //! dependent additions.  What CAN be shared is everything around the chain:
-//!   * short runs: one lane group per run, 8 row gathers in flight;
+//!   * short runs: a lane group chains the runs that START among its kReferenceSpan lookups in one pass over the span --
+//!     row ids, sample ids, weights and the span's rows of grad_y are requested up front, unconditionally, at clamped
+//!     positions (two memory round trips per span instead of six dependent ones per run);
 //!   * runs longer than kReferenceLongRun lookups and than the workgroup's own span (so that at most one can START inside
-//!     a workgroup's lookups): the whole workgroup walks it with its wavefronts SPECIALISED -- the gather groups fetch the
-//!     next chunk of rows of grad_y into LDS (one memory round trip per chunk instead of one per 8 lookups; a chunk's
-//!     gathers and the next chunk's ids are in flight for a whole iteration), the lanes of group 0 run the chain out of LDS,
-//!     each on its N elements (fp16: packed half arithmetic); two LDS buffers, ONE barrier per chunk.  Up to 1,024 threads
-//!     per workgroup, so that a gather thread handles one or two rows of a chunk: per-thread bookkeeping, not the chain
-//!     and not memory, was what a lone workgroup of 256 threads spent its time on (tools/reference_sums_run_probe.py:
-//!     295 ns a lookup with one lane group per run, 50 with 256 threads sharing the work, 30 specialised, 22 with chunks
-//!     of 60 rows instead of 30).  C4 (fp16 / fp32): 26.4 / 23.7 -> 1.8 / 2.9 ms.
+//!     a workgroup's lookups): the whole workgroup walks it with its wavefronts SPECIALISED -- the gather groups fetch
+//!     chunks of rows of grad_y into LDS through a pipeline two chunks deep (rows requested two chunks ahead, their ids
+//!     four; nothing compared or counted per row: a chunk whose LAST lookup belongs to the run belongs to it entirely),
+//!     the lanes of the chain wavefront run the chain out of LDS -- the wavefront's lane groups share it, each lane on
+//!     N / 2 or N / 4 of its group's elements, packed half arithmetic for fp16, LDS addresses as immediate offsets for the
+//!     common row widths; two LDS buffers, ONE barrier per chunk.  Up to 1,024 threads per workgroup, so that a gather
+//!     thread handles one or two rows of a chunk.  tools/reference_sums_run_probe.py, ns per lookup of one run of 65,528:
+//!     295 with one lane group per run, 50 with 256 threads sharing the work, 30 specialised, 22 with chunks of 60 rows,
+//!     14.4 with the shared chain, the constant strides and the lighter, deeper gather side.
+//!     C4 (fp16 / fp32): 26.4 / 23.7 -> 1.8 / 2.9 -> 1.2 / 1.8 ms.
 //!   block = (lanes_per_row, groups); every group looks at kReferenceSpan consecutive lookups and walks the runs that
 //!   START there.
 constexpr int kReferenceSpan = 8;
@@ -668,8 +672,8 @@ constexpr int kReferenceBlockThreads = 1024;  //!< lane groups x lanes of a work
 constexpr int kReferenceMaxPer = 2;           //!< rows of a chunk per gather group: with 1,024 threads one, two for rows of 4 KB and more
 
 //! Long-run path: which lane groups of a workgroup chain and which gather.  The wavefront(s) of group 0 run the chain
-//! (group 0's lanes; the other groups of that wavefront idle in the loop: work of theirs would be executed by the chain
-//! wavefront too); every other group gathers `per` rows of each chunk.
+//! (ReferenceChainSplit of its groups share it, the rest of that wavefront idles: work of theirs would be executed by
+//! the chain wavefront too); every other group gathers `per` rows of each chunk.
 struct ReferenceLongRunShape {
   int chain_groups;   //!< groups in the chain wavefront(s): lanes < 64 -> 64 / lanes, else 1
   int gather_groups;  //!< the rest
@@ -723,6 +727,70 @@ __device__ __forceinline__ void ReferenceChainStep(Pack<GradT, N>& acc, const Pa
   }
 }
 
+//! How many lane groups of the chain wavefront SHARE the chain of a long run: a wavefront pays for an instruction
+//! whatever the number of its lanes that execute it, so with rows of 32 lanes (512 bytes) half of the chain wavefront
+//! idled while the other half issued four packed additions per lookup; split 2 (4) ways, every lane chains N / 2 (N / 4)
+//! of its group's elements and the wavefront issues half (a quarter of) the additions per lookup.  Pieces of at least
+//! 4 bytes (one LDS word); the arithmetic per element is the same, so are the bits.
+template <typename GradT, int N>
+__host__ __device__ inline int ReferenceChainSplit(const int chain_groups) {
+  int split = 1;
+  while (split * 2 <= chain_groups && split * 2 <= 4 && N % (split * 2) == 0 &&
+         (N / (split * 2)) * static_cast<int>(sizeof(GradT)) >= 4)
+    split *= 2;
+  return split;
+}
+
+//! The rows [0, count) of one LDS chunk chained onto `sum` (E elements of a lane; `mine` = the lane's piece of row 0).
+//! kWidth > 0: the row width in elements is a compile-time constant -- the LDS addresses of a batch become immediate
+//! offsets of ONE base register (no address arithmetic between the reads: a third of the chain wavefront's instructions).
+template <typename GradT, int E, bool kWeighted, int kWidth = 0>
+__device__ __forceinline__ void ReferenceChainChunk(Pack<GradT, E>& sum, const GradT* mine, const GradT* w_now,
+                                                    const int count, const int runtime_width) {
+  const int width = kWidth > 0 ? kWidth : runtime_width;
+  typedef uint32_t __attribute__((ext_vector_type(sizeof(Pack<GradT, E>) / 4))) piece_t;
+  int j = 0;
+  // LDS reads requested together, then the dependent additions over them: batches of 8, then one of 4 (a full chunk of
+  // 512-byte rows has 60: no row is left to the one-by-one loop, whose every read is a full LDS round trip)
+  auto batch = [&](auto size) {
+    constexpr int kBatch = decltype(size)::value;
+    piece_t x[kBatch];
+    GradT wj[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      x[u] = *reinterpret_cast<const piece_t*>(mine + static_cast<size_t>(j + u) * width);
+      wj[u] = kWeighted ? w_now[j + u] : static_cast<GradT>(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u)
+      ReferenceChainStep<GradT, E, kWeighted>(sum, __builtin_bit_cast(Pack<GradT, E>, x[u]), wj[u]);
+    j += kBatch;
+  };
+  while (j + 12 <= count) batch(std::integral_constant<int, 12>{});
+  if (j + 8 <= count) batch(std::integral_constant<int, 8>{});
+  if (j + 4 <= count) batch(std::integral_constant<int, 4>{});
+  if (j + 2 <= count) batch(std::integral_constant<int, 2>{});
+  if (j < count) batch(std::integral_constant<int, 1>{});
+}
+
+//! fn(std::integral_constant<int, E>) for E = N / split (the splits ReferenceChainSplit can return for this type).
+template <typename GradT, int N, typename Fn>
+__device__ __forceinline__ void ReferenceWithSplit(const int split, Fn&& fn) {
+  if constexpr (N % 4 == 0 && (N / 4) * sizeof(GradT) >= 4) {
+    if (split == 4) {
+      fn(std::integral_constant<int, N / 4>{});
+      return;
+    }
+  }
+  if constexpr (N % 2 == 0 && (N / 2) * sizeof(GradT) >= 4) {
+    if (split == 2) {
+      fn(std::integral_constant<int, N / 2>{});
+      return;
+    }
+  }
+  fn(std::integral_constant<int, N>{});
+}
+
 template <typename GradT, typename IndexT, int N, bool kWeighted>
 __global__ void __launch_bounds__(kMaxBlockThreads)
 ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, const IndexT* __restrict__ rows,
@@ -732,7 +800,8 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
                            const int chunk_rows /* > 0: long runs are walked by the whole workgroup */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char reference_lds[];
   __shared__ long long long_head;          // first lookup of the long run that starts in this workgroup's span, or -1
-  __shared__ int chunk_count[2];
+  __shared__ int chunk_full[2];            // the chunk parked in this buffer lies entirely inside the run
+  __shared__ int last_count;               // the run's rows in its last chunk
   const int lane_x = threadIdx.x;
   // With the long-run path the grid has TWO halves over the same lookups: the first half only looks for long runs and
   // walks them (a workgroup without one leaves at once), the second walks the short runs.  Workgroups are dispatched in
@@ -754,65 +823,118 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   if (chunk_rows > 0) {
     if (threadIdx.x == 0 && threadIdx.y == 0) {
       long_head = -1;
-      chunk_count[0] = 0;
-      chunk_count[1] = 0;
+      chunk_full[0] = 0;
+      chunk_full[1] = 0;
+      last_count = 0;
     }
     __syncthreads();
   }
-  for (int64_t p = group * kReferenceSpan; p < (group + 1) * kReferenceSpan && p < nnz; ++p) {
-    const IndexT row = rows[p];
-    if (p > 0 && rows[p - 1] == row) continue;   // not the first lookup of its run
-    if (short_phase && run_ids != nullptr && lane_x == 0) inverse_mapping[row] = run_ids[p];
-    const bool is_long = chunk_rows > 0 && p + long_run < nnz && rows[p + long_run] == row;
-    if (long_phase) {
-      if (is_long && lane_x == 0) long_head = p; // (one per workgroup at most: the run outlasts the workgroup's span)
-      continue;
+  if (long_phase) {
+    // does a long run START among this workgroup's lookups?  One thread per lookup, three loads at clamped positions
+    // and one round trip for the whole workgroup (the lane groups used to walk their eight lookups one after the other,
+    // a dependent load or two each: the hottest row's workgroup sits somewhere among thousands of these)
+    const int threads = static_cast<int>(blockDim.x * blockDim.y);
+    const int64_t first = block_in_phase * span;
+    for (int i = static_cast<int>(threadIdx.y * blockDim.x + threadIdx.x); i < span; i += threads) {
+      const int64_t at = first + i;
+      const int64_t here = at < nnz ? at : nnz - 1;
+      const int64_t far = at + long_run;
+      const IndexT row = rows[here];
+      const IndexT before = rows[here > 0 ? here - 1 : 0];
+      const IndexT ahead = rows[far < nnz ? far : nnz - 1];
+      if (at < nnz && (at == 0 || before != row) && far < nnz && ahead == row)
+        long_head = at;                          // (one per workgroup at most: the run outlasts the workgroup's span)
     }
-    if (is_long) continue;                       // (walked by the first half of the grid)
-    GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
-    float acc[N];
-    if (add_to_output) {
-      const Pack<GradT, N> was = *reinterpret_cast<const Pack<GradT, N>*>(dst);
+  }
+  const int64_t p0 = group * kReferenceSpan;
+  if (short_phase && p0 < nnz) {
+    // ---- the short runs that START among this lane group's kReferenceSpan lookups ----
+    // Everything the span can need is requested up front, UNCONDITIONALLY, at clamped positions -- the row ids around
+    // the span, the ids `long_run` further on, sample ids, weights, run names, then the span's rows of grad_y: two memory
+    // round trips per span.  (Walking the lookups one by one, every load behind the comparison before it, was six
+    // dependent round trips per run: uniform indices, 3.4 M runs of one or two lookups, took 2.3 ms.)  One pass over the
+    // span then chains every run that starts in it, in lookup order; a run that outlasts the span is finished in batches
+    // of K lookups with the same discipline.
+    constexpr int S = kReferenceSpan;
+    const int64_t last_pos = nnz - 1;
+    IndexT rid[S + 2];                           // rows[p0 - 1 .. p0 + S]
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = static_cast<float>(was.v[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    for (int j = 0; j < S + 2; ++j) {
+      const int64_t at = p0 - 1 + j;
+      rid[j] = rows[at < 0 ? 0 : (at < nnz ? at : last_pos)];
     }
-    for (int64_t q = p; q < nnz;) {
-      // the next K lookups of the run (fewer at its end): all gathers requested, then added in order
-      int count = 0;
-      raw_t g[K];
-      GradT w[K];
+    IndexT ahead[S];                             // rows[p + long_run]: does a run that starts at p belong to the other half?
+    IndexT sid[S];
+    GradT w[S];
+    IndexT name[S];
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const bool mine = count == j && q + j < nnz && rows[q + j] == row;
-        if (mine) {
-          ++count;
-          g[j] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(sample_ids[q + j]), width));
-          if constexpr (kWeighted) w[j] = weights[q + j];
+    for (int j = 0; j < S; ++j) {
+      const int64_t at = p0 + j < nnz ? p0 + j : last_pos;
+      const int64_t far = p0 + j + long_run;
+      ahead[j] = chunk_rows > 0 ? rows[far < nnz ? far : last_pos] : static_cast<IndexT>(0);
+      sid[j] = sample_ids[at];
+      w[j] = kWeighted ? weights[at] : static_cast<GradT>(0);
+      name[j] = run_ids != nullptr ? run_ids[at] : static_cast<IndexT>(0);
+    }
+    raw_t g[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+      g[j] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(sid[j]), width));
+    bool active = false;                         // a run that started in this span is being chained
+    IndexT current = 0;
+    Pack<GradT, N> acc;
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc.v[e] = static_cast<GradT>(0);
+    auto store = [&](const IndexT row) {
+      *reinterpret_cast<Pack<GradT, N>*>(grad_out + static_cast<int64_t>(row) * width + column0) = acc;
+    };
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int64_t p = p0 + j;
+      const IndexT row = rid[j + 1];
+      const bool head = p < nnz && (p == 0 || rid[j] != row);
+      if (head) {
+        if (active) store(current);              // the run before this one started in the span too, and ends here
+        if (run_ids != nullptr && lane_x == 0) inverse_mapping[row] = name[j];
+        // (a long run is walked by the first half of the grid)
+        active = !(chunk_rows > 0 && p + long_run < nnz && ahead[j] == row);
+        current = row;
+        if (add_to_output && active) {
+          acc = *reinterpret_cast<const Pack<GradT, N>*>(grad_out + static_cast<int64_t>(row) * width + column0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc.v[e] = static_cast<GradT>(0);
         }
       }
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        if (j < count) {
-          const Pack<GradT, N> row_j = __builtin_bit_cast(Pack<GradT, N>, g[j]);
-#pragma unroll
-          for (int e = 0; e < N; ++e) {
-#pragma clang fp contract(off)
-            float x = static_cast<float>(row_j.v[e]);
-            if constexpr (kWeighted) x = static_cast<float>(static_cast<GradT>(x * static_cast<float>(w[j])));   // product in GradT
-            acc[e] = static_cast<float>(static_cast<GradT>(acc[e] + x));                                           // sum in GradT
-          }
-        }
-      }
-      if (count < K) break;
-      q += K;
+      if (active && p < nnz) ReferenceChainStep<GradT, N, kWeighted>(acc, __builtin_bit_cast(Pack<GradT, N>, g[j]), w[j]);
     }
-    Pack<GradT, N> result;
+    if (active) {
+      // the run goes on past the span (rid[S + 1] = rows[p0 + S]): batches of K lookups, loads first, comparisons after
+      bool more = p0 + S < nnz && rid[S + 1] == current;
+      for (int64_t q = p0 + S; more; q += K) {
+        IndexT r2[K], s2[K];
+        GradT w2[K];
 #pragma unroll
-    for (int e = 0; e < N; ++e) result.v[e] = static_cast<GradT>(acc[e]);
-    *reinterpret_cast<Pack<GradT, N>*>(dst) = result;
+        for (int j = 0; j < K; ++j) {
+          const int64_t at = q + j < nnz ? q + j : last_pos;
+          r2[j] = rows[at];
+          s2[j] = sample_ids[at];
+          w2[j] = kWeighted ? weights[at] : static_cast<GradT>(0);
+        }
+        raw_t g2[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          g2[j] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(s2[j]), width));
+        bool inside = true;                      // the run's lookups are a prefix of the batch (the COO is sorted)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          inside = inside && q + j < nnz && r2[j] == current;
+          if (inside) ReferenceChainStep<GradT, N, kWeighted>(acc, __builtin_bit_cast(Pack<GradT, N>, g2[j]), w2[j]);
+        }
+        more = inside;
+      }
+      store(current);
+    }
   }
   if (!long_phase) return;
   __syncthreads();
@@ -823,103 +945,150 @@ ReferenceSumsScatterKernel(const GradT* __restrict__ grad_y, const int width, co
   const ReferenceLongRunShape shape =
       ReferenceLongRun(static_cast<size_t>(width) * sizeof(GradT), static_cast<int>(blockDim.x), static_cast<int>(blockDim.y));
   const int gather_groups = shape.gather_groups, per = shape.per;
-  const bool chains = threadIdx.y == 0;
+  // the groups of the chain wavefront that share the chain, each lane on N / split of its group's elements
+  const int split = ReferenceChainSplit<GradT, N>(shape.chain_groups);
+  const bool chains = static_cast<int>(threadIdx.y) < split;
+  const int chain_column = static_cast<int>(column0) + (chains ? static_cast<int>(threadIdx.y) * (N / split) : 0);
   const bool gathers = static_cast<int>(threadIdx.y) >= shape.chain_groups;
   const int gi = static_cast<int>(threadIdx.y) - shape.chain_groups;      // this gather group's number
   GradT* stage = reinterpret_cast<GradT*>(reference_lds);      // [2][chunk_rows][width]
   GradT* stage_w = stage + 2 * static_cast<size_t>(chunk_rows) * width;   // [2][chunk_rows]
-  GradT* dst = grad_out + static_cast<int64_t>(row) * width + column0;
+  GradT* dst = grad_out + static_cast<int64_t>(row) * width + chain_column;
   Pack<GradT, N> sum;                        // the chain's state lives in GradT: it is rounded to it at every step anyway
-#pragma unroll
+#pragma unroll                               // (its first N / split elements are this lane's)
   for (int e = 0; e < N; ++e) sum.v[e] = static_cast<GradT>(0);
-  if (chains && add_to_output) sum = *reinterpret_cast<const Pack<GradT, N>*>(dst);
-  // what a gather group knows about ITS rows of a chunk: row id found there, sample id, weight -- for the chunk whose rows
-  // are being gathered (`now`) and for the one after it (`next`: its ids are requested a whole chunk ahead, so that a
-  // gather never waits for them)
-  struct Lookups {
-    IndexT rid[kReferenceMaxPer];      //!< the row id found at the slot's position (compared with the run's row when the chunk is parked)
+  if (chains && add_to_output)
+    ReferenceWithSplit<GradT, N>(split, [&](auto e) {
+      constexpr int E = decltype(e)::value;
+      const Pack<GradT, E> before = *reinterpret_cast<const Pack<GradT, E>*>(dst);
+#pragma unroll
+      for (int i = 0; i < E; ++i) sum.v[i] = before.v[i];
+    });
+  // The gather side is a pipeline TWO chunks deep, in two statically named register sets used in turn (A: even chunks,
+  // B: odd ones -- no register that a load is still writing is ever copied):
+  //   Ids   : sample ids and weights of a gather group's rows of a chunk, and the row id at the chunk's LAST position;
+  //           requested four chunks ahead of the chunk being chained, consumed two iterations later;
+  //   Stage : the rows themselves (16 bytes per lane and row), requested two chunks ahead, parked into LDS two
+  //           iterations later -- with one chunk of slack the loop ran at the latency of a memory round trip per chunk
+  //           (0.76 us without any chain: the streamed id arrays miss in every cache), whatever the chain cost.
+  // The COO is sorted, so a chunk whose last lookup still belongs to the run belongs to it entirely: nothing is compared
+  // or counted per row (that was half of the gather side's instructions); only the run's last chunk is counted, once.
+  struct Ids {
     IndexT sid[kReferenceMaxPer];
     GradT w[kReferenceMaxPer];
+    IndexT last_rid;                   //!< the row id at the chunk's last position (clamped)
+    bool last_inside;                  //!< that position exists
   };
-  Lookups now, next;
+  struct Stage {
+    raw_t held[kReferenceMaxPer];
+    GradT w[kReferenceMaxPer];
+    bool full;                         //!< the whole chunk belongs to the run
+  };
   // UNCONDITIONAL loads at clamped positions, nothing decided here: a load under a runtime condition, or a comparison of a
-  // loaded row id kept as a lane mask, becomes a full wait behind every single load (eight dependent round trips per
-  // chunk instead of one: 3.8 us per 64 lookups).  Slots beyond `per` repeat slot 0's position.
-  auto look_up = [&](Lookups& l, const int64_t first) {
+  // loaded row id kept as a lane mask while the load is in flight, becomes a full wait behind every single load (eight
+  // dependent round trips per chunk instead of one: 3.8 us per 64 lookups).  Slots beyond `per` repeat slot 0's position.
+  auto look_up = [&](Ids& l, const int64_t first) {
 #pragma unroll
     for (int k = 0; k < kReferenceMaxPer; ++k) {
       const int64_t at = first + gi + static_cast<int64_t>(k < per ? k : 0) * gather_groups;
       const int64_t safe = at < nnz ? at : nnz - 1;
-      l.rid[k] = rows[safe];
       l.sid[k] = sample_ids[safe];
       if constexpr (kWeighted) l.w[k] = weights[safe];
     }
+    const int64_t last = first + chunk_rows - 1;
+    l.last_inside = last < nnz;
+    l.last_rid = rows[last < nnz ? last : nnz - 1];
   };
-  raw_t held[kReferenceMaxPer];
-  auto gather = [&](const Lookups& l) {      // (every slot loads -- a row of the run or, past its end, whatever row the
-#pragma unroll                               //  clamped position names: a valid sample id either way)
-    for (int k = 0; k < kReferenceMaxPer; ++k)
-      held[k] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(l.sid[k]), width));
-  };
-  // registers -> LDS for the slots that still belong to the run, and how many of the chunk's rows those are
-  auto park = [&](const Lookups& l, const int64_t first, const int buffer) {
-    int mine = 0;
+  // (every slot loads -- a row of the run or, past its end, whatever row the clamped position names: a valid sample id)
+  auto request = [&](Stage& st, const Ids& l) {
 #pragma unroll
     for (int k = 0; k < kReferenceMaxPer; ++k) {
-      const int64_t at = first + gi + static_cast<int64_t>(k) * gather_groups;
-      if (k < per && at < nnz && l.rid[k] == row) {
+      st.held[k] = *reinterpret_cast<const raw_t*>(RowPtr(grad_y + column0, static_cast<int64_t>(l.sid[k]), width));
+      st.w[k] = l.w[k];
+    }
+    st.full = l.last_inside && l.last_rid == row;
+  };
+  // registers -> LDS, every slot of the chunk (rows past the run's end are parked too and never read)
+  auto park = [&](const Stage& st, const int buffer) {
+#pragma unroll
+    for (int k = 0; k < kReferenceMaxPer; ++k) {
+      if (k < per) {
         const int slot = gi + k * gather_groups;
-        *reinterpret_cast<raw_t*>(stage + (static_cast<size_t>(buffer) * chunk_rows + slot) * width + column0) = held[k];
+        *reinterpret_cast<raw_t*>(stage + (static_cast<size_t>(buffer) * chunk_rows + slot) * width + column0) = st.held[k];
         if constexpr (kWeighted)
-          if (lane_x == 0) stage_w[buffer * chunk_rows + slot] = l.w[k];
-        ++mine;
+          if (lane_x == 0) stage_w[buffer * chunk_rows + slot] = st.w[k];
       }
     }
-    if (lane_x == 0 && mine > 0) atomicAdd(&chunk_count[buffer], mine);
+    if (gi == 0 && lane_x == 0) chunk_full[buffer] = st.full ? 1 : 0;
   };
-  if (gathers) {
-    look_up(now, p);
-    gather(now);
-    look_up(next, p + chunk_rows);
-  }
   int64_t q = p;                             // first lookup of the chunk that is parked next
-  int seen[2] = {0, 0};                      // rows counted into each buffer's (never reset) counter so far
-  for (int buffer = 0;; buffer ^= 1) {
+  // one chunk: its rows into LDS, the requests of the chunk two further on, the barrier, the chain.  true = the run ended.
+  auto step = [&](Stage& st, Ids& l, const int buffer) -> bool {
     if (gathers) {
-      park(now, q, buffer);                  // (waits for this chunk's gathers, requested a whole iteration ago)
-      now = next;
-      look_up(next, q + 2 * static_cast<int64_t>(chunk_rows));
-      gather(now);                           // the next chunk's rows: in flight while this one is chained
+      park(st, buffer);                      // (waits for this chunk's rows, requested two iterations ago)
+      request(st, l);                        // the rows of chunk + 2 (their ids were requested two iterations ago)
+      look_up(l, q + 4 * static_cast<int64_t>(chunk_rows));
     }
     __syncthreads();                         // the chunk is in LDS; the buffer written next is the other one
-    const int count = chunk_count[buffer] - seen[buffer];   // the run's rows are a prefix of the chunk (the COO is sorted)
-    seen[buffer] += count;
+    int count = chunk_rows;
+    if (chunk_full[buffer] == 0) {           // (the same for every thread) the run ends inside this chunk: count its rows
+      if (threadIdx.y < static_cast<unsigned>(shape.chain_groups)) {      // the chain wavefront(s), all lanes
+        const int lane = static_cast<int>(threadIdx.y) * static_cast<int>(blockDim.x) + lane_x;
+        const int lanes_here = shape.chain_groups * static_cast<int>(blockDim.x);
+        int inside = 0;
+        for (int base = 0; base < chunk_rows; base += lanes_here) {
+          const int64_t at = q + base + lane;
+          const IndexT rid = rows[at < nnz ? at : nnz - 1];
+          inside += (base + lane < chunk_rows && at < nnz && rid == row) ? 1 : 0;
+        }
+        if (inside > 0) atomicAdd(&last_count, inside);
+      }
+      __syncthreads();
+      count = last_count;
+    }
     if (chains) {
-      const GradT* mine = stage + static_cast<size_t>(buffer) * chunk_rows * width + column0;
+      const GradT* mine = stage + static_cast<size_t>(buffer) * chunk_rows * width + chain_column;
       const GradT* w_now = stage_w + buffer * chunk_rows;
-      constexpr int kBatch = 8;              // LDS reads requested together, then the dependent additions over them
-      int j = 0;
-      for (; j + kBatch <= count; j += kBatch) {
-        raw_t x[kBatch];
-        GradT wj[kBatch];
+      ReferenceWithSplit<GradT, N>(split, [&](auto e) {
+        constexpr int E = decltype(e)::value;
+        Pack<GradT, E> part;
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          x[u] = *reinterpret_cast<const raw_t*>(mine + static_cast<size_t>(j + u) * width);
-          wj[u] = kWeighted ? w_now[j + u] : static_cast<GradT>(0);
+        for (int i = 0; i < E; ++i) part.v[i] = sum.v[i];
+        switch (width) {                       // (the common widths as constants; the same bits, fewer instructions)
+          case 128: ReferenceChainChunk<GradT, E, kWeighted, 128>(part, mine, w_now, count, width); break;
+          case 256: ReferenceChainChunk<GradT, E, kWeighted, 256>(part, mine, w_now, count, width); break;
+          case 512: ReferenceChainChunk<GradT, E, kWeighted, 512>(part, mine, w_now, count, width); break;
+          default: ReferenceChainChunk<GradT, E, kWeighted>(part, mine, w_now, count, width);
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u)
-          ReferenceChainStep<GradT, N, kWeighted>(sum, __builtin_bit_cast(Pack<GradT, N>, x[u]), wj[u]);
-      }
-      for (; j < count; ++j)
-        ReferenceChainStep<GradT, N, kWeighted>(
-            sum, *reinterpret_cast<const Pack<GradT, N>*>(mine + static_cast<size_t>(j) * width),
-            kWeighted ? w_now[j] : static_cast<GradT>(0));
+        for (int i = 0; i < E; ++i) sum.v[i] = part.v[i];
+      });
     }
-    if (count < chunk_rows) break;           // the run ended inside this chunk (the same count for every thread)
     q += chunk_rows;
+    return count < chunk_rows;               // the run ended inside this chunk (the same count for every thread)
+  };
+  Ids ids_a, ids_b;
+  Stage rows_a, rows_b;
+  if (gathers) {
+    look_up(ids_a, p);
+    look_up(ids_b, p + chunk_rows);
+    request(rows_a, ids_a);
+    request(rows_b, ids_b);
+    look_up(ids_a, p + 2 * static_cast<int64_t>(chunk_rows));
+    look_up(ids_b, p + 3 * static_cast<int64_t>(chunk_rows));
   }
-  if (chains) *reinterpret_cast<Pack<GradT, N>*>(dst) = sum;
+  for (;;) {
+    if (step(rows_a, ids_a, 0)) break;
+    if (step(rows_b, ids_b, 1)) break;
+  }
+  if (chains)
+    ReferenceWithSplit<GradT, N>(split, [&](auto e) {
+      constexpr int E = decltype(e)::value;
+      Pack<GradT, E> part;
+#pragma unroll
+      for (int i = 0; i < E; ++i) part.v[i] = sum.v[i];
+      *reinterpret_cast<Pack<GradT, E>*>(dst) = part;
+    });
 }
 
 }  // namespace detail

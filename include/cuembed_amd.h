@@ -199,8 +199,8 @@ void cuembed_embedding_backward(const void* grad_y, int elem_type, int embed_wid
  * keep fp32 partial sums (ARITHMETIC note above).  WHAT EXACTNESS COSTS: a rounding chain cannot be cut into partial
  * sums, so a table row's run is one chain of dependent additions (short runs: one lane group each; runs of 257 lookups
  * and more: a whole workgroup stages the rows in LDS and one wavefront chains them from there).  At BASELINE config 4
- * (10M x 256, 65,536 x 64 lookups, alpha 1.15: the hottest row is a chain of 65,528) 1.8 ms in fp16 and 2.9 ms in fp32
- * against 0.29 / 0.55 ms for the default entry point on the same data -- 6 x and 5 x (bench.py: roofline.other_kernels,
+ * (10M x 256, 65,536 x 64 lookups, alpha 1.15: the hottest row is a chain of 65,528) 1.2 ms in fp16 and 1.8 ms in fp32
+ * against 0.26 / 0.54 ms for the default entry point on the same data -- 4.5 x and 3.4 x (bench.py: roofline.other_kernels,
  * "cost_of_exactness", with bit_identical_to_oracle checked on non-representable data).
  * num_grad_embedding_rows >= 0; skip_grad_init != 0 adds to what grad_embedding holds. */
 void cuembed_embedding_backward_reference_sums(const void* grad_y, int elem_type, int embed_width,
